@@ -1,0 +1,201 @@
+/*
+ * mrag_hip.h -- flat C ABI of libmrag_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (MCG-NJU/MotionRAG) is 100 % Python: it has no FFI.  Every
+ * "kernel" on its hot path is a stock ATen op reached from three Python
+ * protocols.  The entry points below are what a HIP
+ * backend for those call sites binds; each one cites the reference call site
+ * it stands behind.  Host code (the motionrag_amd python modules) reaches them through
+ * ctypes with torch.Tensor.data_ptr(); INTEGRATION.md shows the reference-side
+ * stubs.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MRAG_E* code on a bad
+ *     argument, or the positive hipError_t of a failed launch; nothing throws;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - all pointers are device pointers unless the name ends in _host;
+ *   - bf16 tensors are raw uint16 bit patterns; fp32 accumulate everywhere;
+ *   - no hidden allocation, no global mutable state: workspaces are passed in;
+ *   - row-major, innermost dimension contiguous; ld* / stride* are in ELEMENTS.
+ */
+#ifndef MRAG_HIP_H
+#define MRAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRAG_OK 0
+#define MRAG_EINVAL (-1)   /* bad shape / alignment / null pointer          */
+#define MRAG_ENOTSUP (-2)  /* shape outside what the kernel was built for   */
+
+/* library identity: returns the ABI version (bumped on any signature change) */
+int mrag_abi_version(void);
+/* returns "gfx950" -- the only code object in the library */
+const char* mrag_target_arch(void);
+
+/* ------------------------------------------------------------------------ */
+/* GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])     bf16 in/out      */
+/* Stands behind every nn.Linear on the path:                                 */
+/*   attn.to_q/to_k/to_v/to_out, to_q_ip/to_k_ip/to_v_ip                      */
+/*     src/projects/condition/attn_processor.py:65-73,103-105,129,209-211,    */
+/*     250-252,276;  Resampler / PerceiverAttention / FeedForward             */
+/*     src/projects/condition/encoders/resampler.py:45-52,93-105,157-166;     */
+/*   nn.TransformerEncoder in_proj/out_proj/linear1/linear2                   */
+/*     src/projects/condition/module.py:305; diffusers CogVideoXBlock FF.     */
+/* ------------------------------------------------------------------------ */
+enum mrag_epilogue {
+  MRAG_EPI_NONE = 0,        /* C = acc + bias                                         */
+  MRAG_EPI_GELU_TANH = 1,   /* C = gelu_tanh(acc + bias)      (CogVideoX FF)          */
+  MRAG_EPI_GELU_ERF = 2,    /* C = gelu_erf(acc + bias)       (CAMA / Resampler FF)   */
+  MRAG_EPI_RESID = 3,       /* C = resid + (acc + bias)                               */
+  MRAG_EPI_GATE_RESID = 4,  /* C = resid + gate[b(m), n] * (acc + bias)  (AdaLN-zero) */
+  MRAG_EPI_SILU = 5         /* C = silu(acc + bias)            (timestep MLP)         */
+};
+
+typedef struct mrag_gemm_args {
+  const void* A;      /* [M, K] bf16, lda                                   */
+  const void* W;      /* [N, K] bf16, ldw  (nn.Linear weight layout)        */
+  const void* bias;   /* [N] bf16 or NULL                                   */
+  void* C;            /* [M, N] bf16, ldc                                   */
+  const void* resid;  /* [M, N] bf16, ldr (EPI_RESID / EPI_GATE_RESID)      */
+  /* EPI_GATE_RESID: row m belongs to sample b = m / rows_per_batch; rows with
+   * (m % rows_per_batch) < split use gate0, the others gate1 (text vs video
+   * tokens of the joint CogVideoX sequence).  gate pointers are [B, N] bf16
+   * with batch stride gate_stride.                                          */
+  const void* gate0;
+  const void* gate1;
+  int64_t M, N, K;
+  int64_t lda, ldw, ldc, ldr;
+  int64_t rows_per_batch, split, gate_stride;
+  int32_t epilogue;   /* enum mrag_epilogue */
+} mrag_gemm_args;
+
+int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
+
+/* ------------------------------------------------------------------------ */
+/* Attention, head_dim 64, bf16, flash-style (no S x S matrix in HBM).       */
+/*   O[b, sq, h*64+d] = resid + out_scale * softmax(Q K^T * scale [+mask]) V */
+/* Stands behind F.scaled_dot_product_attention at                           */
+/*   attn_processor.py:85-87,117-119 (SVD), :233-235,264-266 (CogVideoX),    */
+/*   resampler.py:102, DynamiCrafter lvdm/modules/attention.py:189,199,215,  */
+/*   and torch._native_multi_head_attention inside nn.TransformerEncoder     */
+/*   (module.py:305, block-causal bool mask from module.py:131-135).         */
+/* With resid != NULL it is the motion-injection update                      */
+/*   hidden = hidden + scale * ip_attention   (attn_processor.py:139,273).   */
+/* ------------------------------------------------------------------------ */
+typedef struct mrag_attn_args {
+  const void* Q;   /* element (b,h,s,d) at Q + b*q_sb + s*q_ss + h*q_sh + d */
+  const void* K;
+  const void* V;
+  void* O;         /* element (b,s,h,d) at O + b*o_sb + s*o_ss + h*64 + d   */
+  const void* resid;   /* same addressing as O, or NULL                     */
+  const uint8_t* mask; /* [Sq, Skv] bytes, nonzero = blocked, or NULL       */
+  int64_t q_sb, q_ss, q_sh;
+  int64_t k_sb, k_ss, k_sh;
+  int64_t v_sb, v_ss, v_sh;
+  int64_t o_sb, o_ss;
+  int32_t B, H, Sq, Skv;
+  int32_t kv_batch_div; /* K/V batch index = b / kv_batch_div (einops repeat
+                           'b ... -> (b r) ...' at attn_processor.py:108-110) */
+  float scale;          /* softmax scale, 1/sqrt(64) for every call site     */
+  float out_scale;      /* multiplies the attention output (adapter scale)   */
+  int32_t q_prescaled;  /* nonzero: Q already carries scale*log2(e) (q_premul
+                           of mrag_qknorm_rope_bf16); `scale` is then ignored */
+} mrag_attn_args;
+
+int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
+
+/* ------------------------------------------------------------------------ */
+/* LayerNorm (+ optional AdaLN modulation): y = LN(x)*gamma+beta, then       */
+/*   y = y*(1+scale[b])+shift[b].  nn.LayerNorm at resampler.py:47,76-77,    */
+/*   129; nn.TransformerEncoderLayer norm1/norm2; diffusers                  */
+/*   CogVideoXLayerNormZero / AdaLayerNorm.              */
+/* Rows with (m % rows_per_batch) < split use shift0/scale0, others 1.       */
+/* ------------------------------------------------------------------------ */
+typedef struct mrag_ln_args {
+  const void* x;      /* [rows, D] bf16, ldx */
+  void* y;            /* [rows, D] bf16, ldy */
+  const void* gamma;  /* [D] bf16 or NULL    */
+  const void* beta;   /* [D] bf16 or NULL    */
+  const void* shift0; const void* scale0;   /* [B, D] bf16, stride mod_stride, or NULL */
+  const void* shift1; const void* scale1;
+  int64_t rows, D, ldx, ldy;
+  int64_t rows_per_batch, split, mod_stride;
+  /* optional output row remap (0 = off): row m is written at
+   *   y + (m / y_rows_per_batch) * y_batch_stride + (m % y_rows_per_batch) * ldy
+   * -- writes LN(x) straight into the [x ; latents] K/V input of the Perceiver
+   * attention (torch.cat at resampler.py:95) without a copy.                  */
+  int64_t y_rows_per_batch, y_batch_stride;
+  float eps;
+} mrag_ln_args;
+
+int mrag_layernorm_bf16(void* stream, const mrag_ln_args* args);
+
+/* ------------------------------------------------------------------------ */
+/* Per-head qk LayerNorm (eps 1e-6, affine over 64) + 3-D RoPE on the video  */
+/* tokens of Q and K, in place on a fused QKV buffer [B, S, 3, H, 64].       */
+/* attn_processor.py:220-231 (attn.norm_q / norm_k, apply_rotary_emb).       */
+/* q_premul multiplies Q after RoPE (folds softmax scale * log2 e).          */
+/* ------------------------------------------------------------------------ */
+typedef struct mrag_qknorm_rope_args {
+  void* qkv;                 /* [B, S, 3*H*64] bf16, in place on the Q and K thirds */
+  const void* q_gamma; const void* q_beta;   /* [64] bf16 or NULL (no norm)        */
+  const void* k_gamma; const void* k_beta;
+  const float* cos;          /* [S - text_len, 64] fp32 or NULL (no RoPE)          */
+  const float* sin;
+  int32_t B, S, H, text_len;
+  float eps, q_premul;
+} mrag_qknorm_rope_args;
+
+int mrag_qknorm_rope_bf16(void* stream, const mrag_qknorm_rope_args* args);
+
+/* ------------------------------------------------------------------------ */
+/* Pointwise helpers of the denoising loop.                                   */
+/* ------------------------------------------------------------------------ */
+/* sinusoidal timestep embedding (diffusers Timesteps, flip_sin_to_cos=True,  */
+/* freq_shift 0): out[b, :dim] bf16                                           */
+int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim);
+/* y = silu(x) elementwise, bf16 */
+int mrag_silu_bf16(void* stream, const void* x, void* y, int64_t n);
+/* y[r, :] = x[r, :] + table[r % period, :]   (sinusoid PE: position_embeddings.py:172-174) */
+int mrag_add_rows_bf16(void* stream, const void* x, const void* table, void* y,
+                       int64_t rows, int64_t D, int64_t period);
+/* y = a + b elementwise bf16 */
+int mrag_add_bf16(void* stream, const void* a, const void* b, void* y, int64_t n);
+/* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
+ * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
+int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,
+                       int32_t B, int32_t Bl, int32_t F, int32_t C0, int32_t C1, int32_t H, int32_t W);
+/* unpatchify rows [B, F*(H/2)*(W/2), C*4] -> [B, F, C, H, W] */
+int mrag_unpatchify_bf16(void* stream, const void* src, void* dst,
+                         int32_t B, int32_t F, int32_t C, int32_t H, int32_t W);
+/* CFG combine + CogVideoX DDIM step (v-prediction), SURVEY Appendix E:
+ *   v = v_u + g (v_c - v_u); x0 = sa*x - sb*v; x_prev = a*x + b*x0
+ * v_pred [2, n] bf16 (uncond first), latents [n] bf16 in place. */
+int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n,
+                            float guidance, float sqrt_alpha_t, float sqrt_beta_t, float a_t, float b_t);
+
+/* ------------------------------------------------------------------------ */
+/* Retrieval: flat scan top-k (lancedb 0.14.0 `table.search(q).limit(k)`,     */
+/* src/data/rag.py:54; metric L2 unless an index was built with 'dot',        */
+/* tools/build_rag_database.py:51-52).                                        */
+/*   dist(q, r) = sum_d (q_d - x_rd)^2            (metric 0, "l2")            */
+/*              = 1 - sum_d q_d x_rd              (metric 1, "dot")           */
+/* accumulated as ONE fp32 fmaf chain over d = 0..D-1 (bit-reproducible, same */
+/* chain as oracle/topk_oracle.c).  Rows with group[r] == exclude[q] are      */
+/* skipped (the `video != "<self>"` filter, src/data/datamodule.py:235).      */
+/* Output sorted by (dist asc, row asc); missing entries are row = -1.        */
+/* ------------------------------------------------------------------------ */
+int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries);
+int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim,
+                  const float* queries, const int32_t* exclude, int32_t n_queries,
+                  int32_t k, int32_t metric,
+                  int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRAG_HIP_H */

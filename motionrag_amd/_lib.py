@@ -1,0 +1,158 @@
+"""ctypes binding of libmrag_hip.so (the C ABI declared in include/mrag_hip.h).
+
+The library is the product: there is NO CPU fallback anywhere in this package.  `lib()` raises
+`HipLibraryMissing` when the shared object has not been built, and every op in `ops.py` raises when
+handed a non-GPU tensor.  Build with `python -m motionrag_amd._lib` (or `__graft_entry__.build()`):
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libmrag_hip.so")
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "norm.hip", "pointwise.hip", "topk.hip"]
+ABI_VERSION = 1
+
+# every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_attn_fwd_bf16", "mrag_layernorm_bf16",
+    "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16",
+    "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
+]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("resid", c_void_p),
+        ("gate0", c_void_p), ("gate1", c_void_p),
+        ("M", c_int64), ("N", c_int64), ("K", c_int64),
+        ("lda", c_int64), ("ldw", c_int64), ("ldc", c_int64), ("ldr", c_int64),
+        ("rows_per_batch", c_int64), ("split", c_int64), ("gate_stride", c_int64),
+        ("epilogue", c_int32),
+    ]
+
+
+class AttnArgs(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("O", c_void_p), ("resid", c_void_p), ("mask", c_void_p),
+        ("q_sb", c_int64), ("q_ss", c_int64), ("q_sh", c_int64),
+        ("k_sb", c_int64), ("k_ss", c_int64), ("k_sh", c_int64),
+        ("v_sb", c_int64), ("v_ss", c_int64), ("v_sh", c_int64),
+        ("o_sb", c_int64), ("o_ss", c_int64),
+        ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Skv", c_int32), ("kv_batch_div", c_int32),
+        ("scale", c_float), ("out_scale", c_float), ("q_prescaled", c_int32),
+    ]
+
+
+class LnArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("shift0", c_void_p), ("scale0", c_void_p), ("shift1", c_void_p), ("scale1", c_void_p),
+        ("rows", c_int64), ("D", c_int64), ("ldx", c_int64), ("ldy", c_int64),
+        ("rows_per_batch", c_int64), ("split", c_int64), ("mod_stride", c_int64),
+        ("y_rows_per_batch", c_int64), ("y_batch_stride", c_int64),
+        ("eps", c_float),
+    ]
+
+
+class QkNormRopeArgs(Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p),
+        ("cos", c_void_p), ("sin", c_void_p),
+        ("B", c_int32), ("S", c_int32), ("H", c_int32), ("text_len", c_int32),
+        ("eps", c_float), ("q_premul", c_float),
+    ]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into motionrag_amd/libmrag_hip.so (in-tree; needs no GPU)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    newest_src = max(os.path.getmtime(os.path.join(_CSRC, f)) for f in os.listdir(_CSRC))
+    newest_src = max(newest_src, os.path.getmtime(os.path.join(_HERE, "..", "include", "mrag_hip.h")))
+    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest_src:
+        return LIB_PATH
+    build_dir = os.path.join(_HERE, "build")
+    os.makedirs(build_dir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(build_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c",
+               os.path.join(_CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError(f"link failed:\n{res.stdout.decode()}")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the C-ABI library; fail loudly when it is missing or stale (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m motionrag_amd._lib` (hipcc, gfx950). "
+            "motionrag_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.mrag_abi_version.restype = c_int32
+    L.mrag_target_arch.restype = c_char_p
+    if L.mrag_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"{LIB_PATH} has ABI {L.mrag_abi_version()}, expected {ABI_VERSION}: rebuild")
+    L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
+    L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
+    L.mrag_layernorm_bf16.argtypes = [c_void_p, POINTER(LnArgs)]
+    L.mrag_qknorm_rope_bf16.argtypes = [c_void_p, POINTER(QkNormRopeArgs)]
+    L.mrag_timestep_embedding_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32]
+    L.mrag_silu_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
+    L.mrag_add_rows_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64]
+    L.mrag_add_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
+    L.mrag_patchify_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 7
+    L.mrag_unpatchify_bf16.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int32] * 5
+    L.mrag_cfg_ddim_step_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 5
+    L.mrag_topk_workspace_bytes.argtypes = [c_int64, c_int32]
+    L.mrag_topk_workspace_bytes.restype = c_int64
+    L.mrag_topk_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                c_int32, c_void_p, c_void_p, c_void_p, c_int64]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("mrag_target_arch", "mrag_topk_workspace_bytes"):
+            fn.restype = c_int32
+    _lib = L
+    return L
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "MRAG_EINVAL", -2: "MRAG_ENOTSUP"}.get(rc, f"hipError {rc}")
+        raise HipError(f"{what} failed: {kind}")
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,221 @@
+"""Motion-injection attention processors -- the drop-in boundary.
+
+Same class names, constructor arguments, state-dict keys (`to_{q,k,v}_ip.0.weight`) and call
+signatures as the reference's src/projects/condition/attn_processor.py, installed with
+`model.set_attn_processor({name: processor})` exactly as src/projects/cogvideox/module.py:163-175 and
+src/projects/svd/module.py:145-165 do.  The arithmetic runs on hand-written gfx950 kernels
+(libmrag_hip.so): fused QKV GEMM, qk-LayerNorm + RoPE in place, flash attention, and the adapter
+branch `hidden += scale * SDPA(to_q_ip(hidden), to_k_ip(ip), to_v_ip(ip))` with the residual update fused
+into the small-KV attention epilogue.
+
+`Attention` below is the minimal stand-in for diffusers' `Attention` module (diffusers is not
+installed in the build image); a real diffusers `Attention` works too -- the processors only read the
+fields listed in SURVEY 8b.1.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Attention(nn.Module):
+    """Field-compatible stand-in for diffusers.models.attention_processor.Attention."""
+
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int] = None, heads: int = 8, dim_head: int = 64, bias: bool = False,
+                 out_bias: bool = True, qk_norm: Optional[str] = None, eps: float = 1e-5, processor=None):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.inner_dim = heads, inner
+        self.is_cross_attention = cross_attention_dim is not None
+        kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(kv_dim, inner, bias=bias)
+        self.to_v = nn.Linear(kv_dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(0.0)])
+        if qk_norm == "layer_norm":
+            self.norm_q = nn.LayerNorm(dim_head, eps=eps)
+            self.norm_k = nn.LayerNorm(dim_head, eps=eps)
+        else:
+            self.norm_q = self.norm_k = None
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = processor
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, **kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, **kwargs)
+
+
+def _cat_weights(mods, attr="weight"):
+    ts = [getattr(m, attr) for m in mods]
+    if any(t is None for t in ts):
+        return None
+    return torch.cat([t.detach() for t in ts], dim=0).contiguous()
+
+
+class _FusedWeights:
+    """per-`Attention` cache of concatenated projection weights (built once, memory plumbing only)."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, key, builder):
+        ent = self._cache.get(key)
+        if ent is None:
+            ent = builder()
+            self._cache[key] = ent
+        return ent
+
+    def clear(self):
+        self._cache.clear()
+
+
+def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hidden_states: Optional[torch.Tensor], scale: float):
+    """attn_processor.py:209-273 on the joint [text ; video] sequence x [B, S, D] (bf16, contiguous).
+    Returns the attention output BEFORE to_out: `o + scale * ip_attention(to_q_ip(o))`."""
+    B, S, D = x.shape
+    H = attn.heads
+    fw = proc._fused
+    wqkv, bqkv = fw.get(("qkv", attn.to_q.weight.data_ptr()), lambda: (_cat_weights([attn.to_q, attn.to_k, attn.to_v]),
+                                                      _cat_weights([attn.to_q, attn.to_k, attn.to_v], "bias")))
+    qkv = ops.linear(x, wqkv, bqkv)                                               # :209-211 (one GEMM)
+    cos = sin = None
+    if rope is not None:
+        cos, sin = fw.get(("rope", rope[0].data_ptr(), S, text_len),
+                          lambda: (rope[0].to(device=x.device, dtype=torch.float32).contiguous(),
+                                   rope[1].to(device=x.device, dtype=torch.float32).contiguous()))
+        if getattr(attn, "is_cross_attention", False):
+            raise NotImplementedError("RoPE on Q only (is_cross_attention=True) is not used by CogVideoX attn1")
+    nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)
+    ops.qknorm_rope_(qkv, H, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
+                     nk.weight if nk is not None else None, nk.bias if nk is not None else None, cos, sin, text_len,
+                     eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)     # :220-231
+    q5 = qkv.view(B, S, 3, H, 64)
+    o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237
+    if ip_hidden_states is not None and scale != 0:                               # :243-249
+        ip = ip_hidden_states if ip_hidden_states.dtype == torch.bfloat16 else ip_hidden_states.to(torch.bfloat16)
+        ip = ip.contiguous()
+        r = B // ip.size(0)                                                       # :254
+        ip_q = ops.linear(o, proc.to_q_ip[0].weight)                              # :250  (text tokens included)
+        wkv = fw.get(("ipkv", proc.to_k_ip[0].weight.data_ptr()), lambda: _cat_weights([proc.to_k_ip[0], proc.to_v_ip[0]]))
+        kv = ops.linear(ip, wkv)                                                  # :251-252 (one GEMM)
+        k_ip = kv[..., :D].unflatten(-1, (H, 64))
+        v_ip = kv[..., D:].unflatten(-1, (H, 64))
+        # :264-273  o = o + scale * SDPA(ip_q, ip_k, ip_v), residual fused in the attention epilogue (in place)
+        ops.attention(ip_q.view(B, S, H, 64), k_ip, v_ip, out=o, resid=o, kv_batch_div=r, out_scale=float(scale))
+    return o
+
+
+class APAdapterCogVideoXAttnProcessor2_0(nn.Module):
+    """attn_processor.py:144-283."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, num_tokens=(4,), scale=1.0):
+        super().__init__()
+        self.hidden_size, self.cross_attention_dim = hidden_size, cross_attention_dim
+        if not isinstance(num_tokens, (tuple, list)):
+            num_tokens = [num_tokens]
+        self.num_tokens = num_tokens
+        if not isinstance(scale, list):
+            scale = [scale] * len(num_tokens)
+        if len(scale) != len(num_tokens):
+            raise ValueError("`scale` should be a list of integers with the same length as `num_tokens`.")
+        self.scale = scale
+        self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+        self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+        self.to_q_ip = nn.ModuleList([nn.Linear(hidden_size, hidden_size, bias=False) for _ in num_tokens])
+        self._fused = _FusedWeights()
+
+    def _unpack(self, image_rotary_emb, action_hidden_states):
+        if isinstance(image_rotary_emb, tuple) and isinstance(image_rotary_emb[1], torch.Tensor) and isinstance(image_rotary_emb[0], tuple):
+            return image_rotary_emb                                                # ((cos, sin), ip)  :189-190
+        assert action_hidden_states is not None, "action_hidden_states must be provided"   # :192
+        return image_rotary_emb, action_hidden_states
+
+    def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                 action_hidden_states: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 image_rotary_emb=None):
+        if attention_mask is not None:
+            raise NotImplementedError("CogVideoX attn1 is called without a mask (SURVEY 2.2 K1)")
+        rope, ip_hidden_states = self._unpack(image_rotary_emb, action_hidden_states)
+        if len(self.num_tokens) != 1:
+            raise NotImplementedError("one adapter branch (the shipped configs use num_tokens=(4,))")
+        text_len = encoder_hidden_states.size(1)
+        x = torch.cat([encoder_hidden_states, hidden_states], dim=1)               # :199
+        o = joint_attention_core(attn, self, x, text_len, rope, ip_hidden_states, self.scale[0])
+        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias)            # :276 (dropout p=0 :278)
+        return out[:, text_len:], out[:, :text_len]                               # :280-283
+
+
+class APAdapterAttnProcessor2_0(nn.Module):
+    """attn_processor.py:10-141 (SVD cross-attention sites; IPAdapterAttnProcessor2_0 + to_q_ip)."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, num_tokens=(4,), scale=1.0):
+        super().__init__()
+        self.hidden_size, self.cross_attention_dim = hidden_size, cross_attention_dim
+        if not isinstance(num_tokens, (tuple, list)):
+            num_tokens = [num_tokens]
+        self.num_tokens = num_tokens
+        if not isinstance(scale, list):
+            scale = [scale] * len(num_tokens)
+        if len(scale) != len(num_tokens):
+            raise ValueError("`scale` should be a list of integers with the same length as `num_tokens`.")
+        self.scale = scale
+        self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+        self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+        self.to_q_ip = nn.ModuleList([nn.Linear(hidden_size, hidden_size, bias=False) for _ in num_tokens])
+        self._fused = _FusedWeights()
+
+    def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states=None, action_hidden_states=None,
+                 attention_mask=None, temb=None, scale: float = 1.0, ip_adapter_masks=None):
+        residual = hidden_states
+        ip_hidden_states = None
+        if encoder_hidden_states is not None:                                      # :34-41
+            if isinstance(encoder_hidden_states, tuple):
+                encoder_hidden_states, ip_hidden_states = encoder_hidden_states
+            else:
+                assert action_hidden_states is not None, "action_hidden_states must be provided"
+                ip_hidden_states = action_hidden_states
+        if attention_mask is not None or ip_adapter_masks is not None:
+            raise NotImplementedError("SVD attn2 sites run without masks")
+        if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
+            raise NotImplementedError("spatial_norm / group_norm / norm_cross are None on the SVD attn2 sites")
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:                                                        # :48-50
+            b, c, hh, ww = hidden_states.shape
+            hidden_states = hidden_states.view(b, c, hh * ww).transpose(1, 2)
+        hidden_states = hidden_states.contiguous()
+        B, L, C = hidden_states.shape
+        H = attn.heads
+        if C != H * 64:
+            raise NotImplementedError("head_dim 64 only")
+        q = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias)            # :65
+        enc = hidden_states if encoder_hidden_states is None else encoder_hidden_states.contiguous()
+        wkv, bkv = self._fused.get(("kv", attn.to_k.weight.data_ptr()), lambda: (_cat_weights([attn.to_k, attn.to_v]), _cat_weights([attn.to_k, attn.to_v], "bias")))
+        kv = ops.linear(enc, wkv, bkv)                                             # :72-73
+        o = ops.attention(q.view(B, L, H, 64), kv[..., :C].unflatten(-1, (H, 64)), kv[..., C:].unflatten(-1, (H, 64)))   # :85-90
+        if ip_hidden_states is not None and self.scale[0] != 0:                    # :93-139
+            ip = ip_hidden_states.to(torch.bfloat16).contiguous()
+            r = B // ip.size(0)
+            ip_q = ops.linear(o, self.to_q_ip[0].weight)
+            wip = self._fused.get(("ipkv", self.to_k_ip[0].weight.data_ptr()), lambda: _cat_weights([self.to_k_ip[0], self.to_v_ip[0]]))
+            ipkv = ops.linear(ip, wip)
+            ops.attention(ip_q.view(B, L, H, 64), ipkv[..., :C].unflatten(-1, (H, 64)), ipkv[..., C:].unflatten(-1, (H, 64)),
+                          out=o, resid=o, kv_batch_div=r, out_scale=float(self.scale[0]))
+        if attn.residual_connection and input_ndim != 4:
+            out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=residual.contiguous())
+        else:
+            out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias)        # :129-131
+        if input_ndim == 4:                                                        # :133-134
+            out = out.transpose(-1, -2).reshape(b, c, hh, ww)
+            if attn.residual_connection:
+                out = ops.add(out.contiguous(), residual.contiguous())
+        if attn.rescale_output_factor != 1.0:
+            raise NotImplementedError("rescale_output_factor != 1 is not used by the SVD attn2 sites")
+        return out

@@ -1,0 +1,301 @@
+"""CAMA -- the causal-transformer motion adapter of MotionRAG, on hand-written gfx950 kernels.
+
+Host-side mirror of the reference's CAMA interface (same class names, constructor arguments, state-dict
+keys and call semantics), with every arithmetic op routed through libmrag_hip.so:
+
+    reference                                                        here
+    src/projects/condition/position_embeddings.py:149-174            SinusoidPositionalEmbeddings
+    src/projects/condition/encoders/resampler.py:45-52,66-105,108-174  Resampler (+PerceiverAttention, FeedForward)
+    torch.nn.TransformerEncoder as configured in
+      configs/cogvideox/MotionRAG_open.yml:253-267                    TransformerEncoder / TransformerEncoderLayer
+    src/projects/condition/module.py:100-143,255-331                 ActionTransformer (inference path)
+    src/projects/condition/utils.py:7-36                             condition_fusion
+
+nn.Module / nn.Parameter are used as named weight containers only (checkpoint compatibility,
+SURVEY.md Appendix G); no torch arithmetic runs in the forward paths.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+class SinusoidPositionalEmbeddings(nn.Module):
+    """position_embeddings.py:149-174.  The table is a plain attribute (not a buffer), as in the reference."""
+
+    def __init__(self, dim: int, max_length: int):
+        super().__init__()
+        self.dim, self.max_length = dim, max_length
+        j = np.arange(dim)
+        pos = np.arange(max_length, dtype=np.float64)[:, None]
+        table = pos / np.power(10000.0, 2.0 * (j // 2) / dim)[None, :]
+        table[:, 0::2] = np.sin(table[:, 0::2])
+        table[:, 1::2] = np.cos(table[:, 1::2])
+        self.pos_table = torch.from_numpy(table.astype(np.float32)).unsqueeze(0)
+        self._dev_tables = {}
+
+    def table_for(self, length: int, device) -> torch.Tensor:
+        key = (length, str(device))
+        if key not in self._dev_tables:
+            self._dev_tables[key] = self.pos_table[0, :length].to(device=device, dtype=torch.bfloat16).contiguous()
+        return self._dev_tables[key]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.size(-2) <= self.max_length, f"seq_len {x.size(-2)} > max_len {self.max_length}"
+        return ops.add_rows(x.contiguous(), self.table_for(x.size(-2), x.device))
+
+
+class PerceiverAttention(nn.Module):
+    """resampler.py:66-105 (weight container; the math runs in Resampler.forward)."""
+
+    def __init__(self, *, dim, dim_head=64, heads=8):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("the gfx950 attention kernel is built for head_dim 64")
+        self.dim_head, self.heads = dim_head, heads
+        inner = dim_head * heads
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+
+
+def FeedForward(dim, mult=4):
+    inner = int(dim * mult)
+    return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner, bias=False), nn.GELU(), nn.Linear(inner, dim, bias=False))
+
+
+class Resampler(nn.Module):
+    """Perceiver resampler (motion / condition projector), resampler.py:108-174."""
+
+    def __init__(self, dim=1024, depth=8, dim_head=64, heads=16, num_queries=8, embedding_dim=768, output_dim=1024, ff_mult=4,
+                 video_length=None, with_cls_token=False, ckpt_path=None):
+        super().__init__()
+        self.num_queries, self.video_length, self.with_cls_token = num_queries, video_length, with_cls_token
+        self.dim, self.embedding_dim = dim, embedding_dim
+        self.cross_attention_dim = output_dim
+        self.output_dim = output_dim
+        if video_length is not None:
+            num_queries = num_queries * video_length
+        if with_cls_token:
+            num_queries += 1
+        self.latents = nn.Parameter(torch.randn(1, num_queries, dim) / dim ** 0.5)
+        self.proj_in = nn.Linear(embedding_dim, dim)
+        self.proj_out = nn.Linear(dim, output_dim)
+        self.norm_out = nn.LayerNorm(output_dim)
+        self.layers = nn.ModuleList(
+            [nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), FeedForward(dim=dim, mult=ff_mult)])
+             for _ in range(depth)])
+        if ckpt_path is not None:
+            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+
+    def forward(self, x: torch.Tensor, return_cls_tokens: bool = False):
+        x = _bf16(x)
+        N, n1, _ = x.shape
+        nq = self.latents.shape[1]
+        latents = self.latents.detach().expand(N, -1, -1).contiguous()          # latents.repeat(N, 1, 1)  :158
+        x = ops.linear(x, self.proj_in.weight, self.proj_in.bias)                # :159
+        kv_in = torch.empty(N, n1 + nq, self.dim, dtype=torch.bfloat16, device=x.device)
+        for attn, ff in self.layers:
+            H = attn.heads
+            # PerceiverAttention.forward :81-105 -- LN1(x) and LN2(latents) land directly in the concat buffer
+            ops.layernorm(x, attn.norm1.weight, attn.norm1.bias, attn.norm1.eps, out_batched=kv_in[:, :n1])
+            ops.layernorm(latents, attn.norm2.weight, attn.norm2.bias, attn.norm2.eps, out_batched=kv_in[:, n1:])
+            ln_lat = ops.layernorm(latents, attn.norm2.weight, attn.norm2.bias, attn.norm2.eps)
+            q = ops.linear(ln_lat, attn.to_q.weight)
+            kv = ops.linear(kv_in, attn.to_kv.weight)                           # K rows first (chunk(2)) :96
+            inner = H * 64
+            o = ops.attention(q.view(N, nq, H, 64), kv[..., :inner].unflatten(-1, (H, 64)), kv[..., inner:].unflatten(-1, (H, 64)))
+            latents = ops.linear(o, attn.to_out.weight, epilogue=ops.EPI_RESID, resid=latents)      # attn(...) + latents :162
+            h = ops.layernorm(latents, ff[0].weight, ff[0].bias, ff[0].eps)
+            h = ops.linear(h, ff[1].weight, epilogue=ops.EPI_GELU_ERF)
+            latents = ops.linear(h, ff[3].weight, epilogue=ops.EPI_RESID, resid=latents)            # ff(...) + latents :163
+        latents = ops.linear(latents, self.proj_out.weight, self.proj_out.bias)
+        latents = ops.layernorm(latents, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
+        if return_cls_tokens:
+            assert self.with_cls_token is True, "with_cls_token must be True if return_cls_tokens is True"
+            return latents[:, 0], latents[:, 1:]
+        if self.with_cls_token:
+            return latents[:, 1:]
+        return latents
+
+
+class _SelfAttnParams(nn.Module):
+    """key-compatible stand-in for nn.MultiheadAttention: in_proj_weight/in_proj_bias/out_proj.*"""
+
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.randn(3 * d_model, d_model) * 0.02)
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """post-norm encoder layer: x = LN1(x + MHA(x)); x = LN2(x + W2 gelu(W1 x))."""
+
+    def __init__(self, d_model=1024, nhead=16, dim_feedforward=4096, dropout=0.0, activation="gelu", layer_norm_eps=1e-5,
+                 batch_first=True, norm_first=False, bias=True):
+        super().__init__()
+        if norm_first or not batch_first or activation != "gelu" or d_model // nhead != 64:
+            raise NotImplementedError("CAMA uses post-norm, batch_first, GELU, head_dim 64")
+        self.nhead = nhead
+        self.self_attn = _SelfAttnParams(d_model)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        b, l, d = x.shape
+        H = self.nhead
+        qkv = ops.linear(x, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias).view(b, l, 3, H, 64)
+        a = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask=mask)
+        y = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, epilogue=ops.EPI_RESID, resid=x)
+        x = ops.layernorm(y, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        f = ops.linear(x, self.linear1.weight, self.linear1.bias, epilogue=ops.EPI_GELU_ERF)
+        y = ops.linear(f, self.linear2.weight, self.linear2.bias, epilogue=ops.EPI_RESID, resid=x)
+        return ops.layernorm(y, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer: Optional[TransformerEncoderLayer] = None, num_layers: int = 4, d_model=1024, nhead=16,
+                 dim_feedforward=4096):
+        super().__init__()
+        if encoder_layer is not None:
+            d_model, nhead = encoder_layer.norm1.normalized_shape[0], encoder_layer.nhead
+            dim_feedforward = encoder_layer.linear1.out_features
+        self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead, dim_feedforward) for _ in range(num_layers)])
+
+    def forward(self, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        for layer in self.layers:
+            x = layer(x, mask)
+        return x
+
+
+def condition_fusion(condition_emb: torch.Tensor, fusion_type: str = "mean", weight: Optional[Iterable] = None) -> torch.Tensor:
+    """condition/utils.py:7-36.  'concat' and 'top1' are views; 'mean'/'weight' are one small GEMM with the
+    per-sample weight row (k <= 16 references), run on the HIP GEMM."""
+    assert fusion_type in ["mean", "concat", "top1", "weight"]
+    assert condition_emb.dim() == 4
+    b, k, l, c = condition_emb.shape
+    if fusion_type == "concat":
+        return condition_emb.reshape(b, k * l, c)
+    if fusion_type == "top1":
+        return condition_emb[:, 0]
+    if fusion_type == "mean":
+        w = torch.full((b, k), 1.0 / k, dtype=torch.float32)
+    else:
+        d = torch.as_tensor(weight, dtype=torch.float32)
+        w = (1 - d) / (1 - d).sum(dim=1, keepdim=True)
+    # out[b, (l c)] = sum_k w[b, k] emb[b, k, (l c)]  == emb_b^T [l*c, k] . w_b [1, k]^T ; K padded to 64
+    x = _bf16(condition_emb)
+    out = torch.empty(b, l, c, dtype=torch.bfloat16, device=x.device)
+    for i in range(b):
+        a = torch.zeros(l * c, 64, dtype=torch.bfloat16, device=x.device)
+        a[:, :k] = x[i].reshape(k, l * c).t()
+        wrow = torch.zeros(8, 64, dtype=torch.bfloat16, device=x.device)
+        wrow[0, :k] = w[i].to(torch.bfloat16)
+        out[i] = ops.linear(a, wrow)[:, 0].view(l, c)
+    return out
+
+
+class ActionTransformer(nn.Module):
+    """CAMA entry point (module.py:255-331, base class :100-143), inference path.
+
+    `vision_model` / `condition_model` are the frozen VideoMAE / DINOv2 feature extractors (third-party,
+    out of scope: SURVEY 2.1 #6): any callable returning `[N, tokens, dim]` features on the GPU.
+    """
+
+    def __init__(self, ckpt_path: Optional[str] = None, *, condition_model=None, condition_proj: Optional[Resampler] = None,
+                 vision_model=None, vision_proj: Optional[Resampler] = None, transformer: Optional[TransformerEncoder] = None,
+                 condition_pe: Optional[SinusoidPositionalEmbeddings] = None, vision_pe: Optional[SinusoidPositionalEmbeddings] = None,
+                 **_unused):
+        super().__init__()
+        self.condition_model, self.vision_model = condition_model, vision_model
+        self.condition_proj, self.vision_proj = condition_proj, vision_proj
+        self.transformer = transformer
+        self.condition_pe, self.vision_pe = condition_pe, vision_pe
+        self.sos_token = nn.Parameter(torch.randn(1, vision_proj.num_queries, vision_proj.output_dim) / vision_proj.output_dim ** 0.5)
+        self._mask_cache = {}
+        if ckpt_path is not None:
+            self.load_state_dict(torch.load(ckpt_path, "cpu")["state_dict"], strict=False)
+
+    @property
+    def device(self):
+        return self.sos_token.device
+
+    def get_mask(self, num_frames: int, frame_tokens: int) -> torch.Tensor:
+        """module.py:131-135 (True = blocked); built once per shape on the host, cached on the device."""
+        key = (num_frames, frame_tokens)
+        if key not in self._mask_cache:
+            n = num_frames * frame_tokens
+            row_frame = torch.arange(n) // frame_tokens
+            mask = torch.arange(n)[None, :] >= ((row_frame + 1) * frame_tokens)[:, None]
+            self._mask_cache[key] = mask.to(self.device).contiguous()
+        return self._mask_cache[key]
+
+    def encode_vision(self, videos: torch.Tensor) -> torch.Tensor:
+        """module.py:264-268: [b, k, t, c, h, w] -> [b, k, l, c]"""
+        b, k = videos.shape[:2]
+        feats = self.vision_model(videos.reshape(b * k, *videos.shape[2:]))
+        emb = self.vision_proj(feats)
+        return emb.view(b, k, emb.shape[-2], emb.shape[-1])
+
+    def encode_condition(self, condition: torch.Tensor) -> torch.Tensor:
+        """module.py:270-276 + :137-143: PE applied per image over its l positions, then b (k l) c."""
+        b, k = condition.shape[:2]
+        feats = self.condition_model(condition.reshape(b * k, *condition.shape[2:]))
+        emb = self.condition_proj(feats)
+        if self.condition_pe is not None:
+            emb = self.condition_pe(emb)
+        return emb.reshape(b, k * emb.shape[-2], emb.shape[-1])
+
+    def forward(self, visions: torch.Tensor, condition: torch.Tensor, return_loss: bool = False, ignore_ref_loss: bool = False):
+        if return_loss:
+            raise NotImplementedError("training losses are out of scope (SURVEY 2.1 #1)")
+        vision_emb = self.encode_vision(visions)
+        condition_emb = self.encode_condition(condition)
+        b, num_frames, frame_tokens, d = vision_emb.shape
+        sos = _bf16(self.sos_token.detach()).expand(b, -1, -1)
+        x = torch.cat([sos, vision_emb[:, :-1].reshape(b, (num_frames - 1) * frame_tokens, d)], dim=1).contiguous()   # :298
+        if self.vision_pe is not None:
+            x = self.vision_pe(x)                                                                                       # :299-300
+        x = ops.add(x, condition_emb.contiguous())                                                                      # :301
+        mask = self.get_mask(num_frames, frame_tokens)
+        y = self.transformer(x, mask)                                                                                   # :305
+        return y.view(b, num_frames, frame_tokens, d)
+
+    def batch_forward(self, batch, return_loss: bool = False, ignore_ref_loss: bool = False):
+        ref_videos = batch["ref_videos"].flip(1)                                  # reverse the similarity  :319
+        videos = torch.cat([ref_videos, batch["video"][:, None]], dim=1)
+        ref_images = videos[:, :, 0]
+        return self.forward(videos, ref_images, return_loss, ignore_ref_loss)
+
+    @torch.no_grad()
+    def predict(self, batch, do_classifier_free_guidance: bool = False) -> torch.Tensor:
+        action_emb = self.batch_forward(batch, return_loss=False)[:, -1]
+        if do_classifier_free_guidance:
+            uncond = self.encode_vision(torch.zeros_like(batch["ref_videos"][:, 0:1]))[:, 0]
+            action_emb = torch.cat([uncond, action_emb], dim=0)                    # uncond FIRST  :329
+        return action_emb
+
+
+def build_cama(vision_model, condition_model, vision_dim=768, cond_dim=1024, dim=1024, tokens=25, heads=12, depth=4, nhead=16,
+               ff=4096, layers=4) -> ActionTransformer:
+    """the shipped configuration: configs/cogvideox/MotionRAG_open.yml:201-267"""
+    return ActionTransformer(
+        condition_model=condition_model, vision_model=vision_model,
+        vision_proj=Resampler(dim=dim, depth=depth, dim_head=64, heads=heads, num_queries=tokens, embedding_dim=vision_dim, output_dim=dim),
+        condition_proj=Resampler(dim=dim, depth=depth, dim_head=64, heads=heads, num_queries=tokens, embedding_dim=cond_dim, output_dim=dim),
+        transformer=TransformerEncoder(num_layers=layers, d_model=dim, nhead=nhead, dim_feedforward=ff),
+        condition_pe=SinusoidPositionalEmbeddings(dim, 2560), vision_pe=SinusoidPositionalEmbeddings(dim, 256))

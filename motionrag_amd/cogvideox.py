@@ -1,0 +1,339 @@
+"""Motion-injected CogVideoX-5B-I2V denoising loop on hand-written gfx950 kernels.
+
+Mirrors, for the hot path only, what the reference reaches through diffusers==0.32.2 (not vendored;
+SURVEY.md Appendix E) and its own thin subclasses:
+
+    reference                                                     here
+    diffusers CogVideoXTransformer3DModel / CogVideoXBlock         CogVideoXTransformer3DModel / CogVideoXBlock
+      (installed via cogvideox/module.py:23-48, adapters :163-175)   (same state-dict keys, set_attn_processor)
+    diffusers CogVideoXDDIMScheduler (module.py:28-35)             CogVideoXDDIMScheduler
+    CogVideoXImageToVideoCTPipeline (cogvideox/pipeline.py:92-130) CogVideoXImageToVideoCTPipeline
+      ._prepare_rotary_positional_embeddings :46-57                  (rope, action_emb) hand-off kept
+      .prepare_action_embeddings :117-130                            -> ActionTransformer.predict
+      .__call__ :80-89                                               denoise loop: CFG concat, DiT, DDIM
+
+The DiT keeps the residual stream as ONE joint [text ; video] buffer [B, S, D] for all 42 blocks (the
+reference's processor concatenates and splits per block, attn_processor.py:199,280-283): AdaLN-zero
+modulation, gated residuals and the text/video split are row-range parameters of the LayerNorm and
+GEMM-epilogue kernels.  T5 / VAE are third-party and outside the hot path: the pipeline
+takes prompt embeddings and image latents, or user-supplied encoders.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .attn_processor import APAdapterCogVideoXAttnProcessor2_0, Attention, joint_attention_core
+
+
+class _LayerNormZero(nn.Module):
+    """CogVideoXLayerNormZero weight container: linear (512 -> 6 D) + LayerNorm(D)."""
+
+    def __init__(self, cond_dim: int, dim: int, eps: float):
+        super().__init__()
+        self.linear = nn.Linear(cond_dim, 6 * dim)
+        self.norm = nn.LayerNorm(dim, eps=eps)
+
+
+class _GeluProj(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner)
+
+
+class _FeedForward(nn.Module):
+    """diffusers FeedForward('gelu-approximate') container: net.0.proj, net.2"""
+
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.net = nn.ModuleList([_GeluProj(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim)])
+
+
+class CogVideoXBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, time_embed_dim: int, norm_eps: float, qk_eps: float = 1e-6):
+        super().__init__()
+        self.norm1 = _LayerNormZero(time_embed_dim, dim, norm_eps)
+        self.attn1 = Attention(dim, heads=heads, dim_head=dim // heads, bias=True, out_bias=True, qk_norm="layer_norm", eps=qk_eps)
+        self.norm2 = _LayerNormZero(time_embed_dim, dim, norm_eps)
+        self.ff = _FeedForward(dim, 4 * dim)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch, in_channels, dim, text_dim, n_pos):
+        super().__init__()
+        self.proj = nn.Conv2d(in_channels, dim, kernel_size=patch, stride=patch)
+        self.text_proj = nn.Linear(text_dim, dim)
+        self.register_buffer("pos_embedding", torch.zeros(1, n_pos, dim), persistent=True)
+
+
+class _TimeEmbedding(nn.Module):
+    def __init__(self, dim, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(dim, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+class _AdaLayerNorm(nn.Module):
+    def __init__(self, cond_dim, dim, eps):
+        super().__init__()
+        self.linear = nn.Linear(cond_dim, 2 * dim)
+        self.norm = nn.LayerNorm(dim, eps=eps)
+
+
+class _PlainProcessor:
+    """blocks without a motion adapter: same fused path, adapter branch skipped"""
+
+    def __init__(self):
+        from .attn_processor import _FusedWeights
+        self._fused = _FusedWeights()
+        self.scale = [0.0]
+
+
+class CogVideoXTransformer3DModel(nn.Module):
+    """CogVideoX-5B-I2V DiT (rotary + learned positional embedding flavour)."""
+
+    def __init__(self, num_layers=42, num_attention_heads=48, attention_head_dim=64, in_channels=32, out_channels=16, time_embed_dim=512,
+                 text_embed_dim=4096, max_text_seq_length=226, patch_size=2, sample_frames=13, sample_height=60, sample_width=90,
+                 norm_eps=1e-5):
+        super().__init__()
+        if attention_head_dim != 64:
+            raise NotImplementedError("head_dim 64 only")
+        D = num_attention_heads * attention_head_dim
+        self.cfg = dict(num_layers=num_layers, heads=num_attention_heads, dim=D, in_channels=in_channels, out_channels=out_channels,
+                        time_embed_dim=time_embed_dim, text_embed_dim=text_embed_dim, max_text=max_text_seq_length, patch=patch_size,
+                        norm_eps=norm_eps)
+        n_video = sample_frames * (sample_height // patch_size) * (sample_width // patch_size)
+        self.patch_embed = _PatchEmbed(patch_size, in_channels, D, text_embed_dim, max_text_seq_length + n_video)
+        self.time_embedding = _TimeEmbedding(D, time_embed_dim)
+        self.transformer_blocks = nn.ModuleList(
+            [CogVideoXBlock(D, num_attention_heads, time_embed_dim, norm_eps) for _ in range(num_layers)])
+        self.norm_final = nn.LayerNorm(D, eps=norm_eps)
+        self.norm_out = _AdaLayerNorm(time_embed_dim, D, norm_eps)
+        self.proj_out = nn.Linear(D, patch_size * patch_size * out_channels)
+        self._fused: Dict[str, torch.Tensor] = {}
+        self._plain = _PlainProcessor()
+
+    # ---- diffusers-style processor plumbing (cogvideox/module.py:163-175 uses exactly these two) ----
+    @property
+    def attn_processors(self):
+        return {f"transformer_blocks.{i}.attn1.processor": blk.attn1.processor for i, blk in enumerate(self.transformer_blocks)}
+
+    def set_attn_processor(self, processors):
+        for i, blk in enumerate(self.transformer_blocks):
+            name = f"transformer_blocks.{i}.attn1.processor"
+            blk.attn1.set_processor(processors[name] if isinstance(processors, dict) else processors)
+
+    def install_motion_adapters(self, cross_attention_dim: int, scale: float = 1.0):
+        """set_attention_processors of cogvideox/module.py:163-175 with every attn1 adapted (42 sites)."""
+        self.set_attn_processor({name: APAdapterCogVideoXAttnProcessor2_0(self.cfg["dim"], cross_attention_dim, scale=scale)
+                                 for name in self.attn_processors})
+        return self
+
+    # ---- fused weights (built once) ----
+    def _mod_weights(self):
+        tag = (self.norm_out.linear.weight.data_ptr(), self.norm_out.linear.weight.dtype)
+        if self._fused.get("tag") != tag:
+            self._fused = {"tag": tag}
+            ws, bs = [], []
+            for blk in self.transformer_blocks:
+                for n in (blk.norm1, blk.norm2):
+                    ws.append(n.linear.weight.detach()); bs.append(n.linear.bias.detach())
+            ws.append(self.norm_out.linear.weight.detach()); bs.append(self.norm_out.linear.bias.detach())
+            self._fused["mod_w"] = torch.cat(ws, 0).contiguous()
+            self._fused["mod_b"] = torch.cat(bs, 0).contiguous()
+            self._fused["patch_w"] = self.patch_embed.proj.weight.detach().reshape(self.cfg["dim"], -1).contiguous()
+        return self._fused["mod_w"], self._fused["mod_b"]
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
+                image_rotary_emb=None, image_latents: Optional[torch.Tensor] = None, batch: Optional[int] = None) -> torch.Tensor:
+        """hidden_states [Bl, F, C, H, W] bf16 (C = in_channels, or the noisy half when `image_latents`
+        carries the other half); encoder_hidden_states [B, L, text_dim]; timestep [B] fp32;
+        image_rotary_emb = ((cos, sin), action_emb) as handed over by the pipeline (pipeline.py:46-57).
+        Batch entry b reads latent b % Bl (CFG duplication without materialising torch.cat([latents] * 2))."""
+        cfg = self.cfg
+        D, Hh, p = cfg["dim"], cfg["heads"], cfg["patch"]
+        B = encoder_hidden_states.shape[0] if batch is None else batch
+        Bl, F, C0, H, W = hidden_states.shape
+        Lt = encoder_hidden_states.shape[1]
+        Nv = F * (H // p) * (W // p)
+        S = Lt + Nv
+        (rope, ip) = image_rotary_emb if (isinstance(image_rotary_emb, tuple) and isinstance(image_rotary_emb[0], tuple)) else (image_rotary_emb, None)
+        mod_w, mod_b = self._mod_weights()
+
+        # timestep embedding -> temb -> every block's AdaLN-zero modulation in one GEMM
+        temb = ops.timestep_embedding(timestep.to(torch.float32), D)
+        temb = ops.linear(temb, self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, epilogue=ops.EPI_SILU)
+        temb = ops.linear(temb, self.time_embedding.linear_2.weight, self.time_embedding.linear_2.bias, epilogue=ops.EPI_SILU)  # silu(temb)
+        mod = ops.linear(temb, mod_w, mod_b)                        # [B, (2L*6 + 2) D]
+        ms = mod.stride(0)
+
+        # patch embed (Conv2d k=2 s=2 as a GEMM over patch rows) + text projection + positional embedding
+        x = torch.empty(B, S, D, dtype=torch.bfloat16, device=hidden_states.device)
+        pos = self.patch_embed.pos_embedding[0]
+        patches = ops.patchify(hidden_states, image_latents, B).view(B, Nv, -1)
+        for b in range(B):
+            ops.linear(encoder_hidden_states[b], self.patch_embed.text_proj.weight, self.patch_embed.text_proj.bias, out=x[b, :Lt],
+                       epilogue=ops.EPI_RESID, resid=pos[:Lt])
+            ops.linear(patches[b], self._fused["patch_w"], self.patch_embed.proj.bias, out=x[b, Lt:], epilogue=ops.EPI_RESID,
+                       resid=pos[Lt:Lt + Nv])
+
+        def chunk(layer_slot: int, j: int) -> torch.Tensor:
+            off = (layer_slot * 6 + j) * D
+            return mod[:, off:off + D]
+
+        for i, blk in enumerate(self.transformer_blocks):
+            proc = blk.attn1.processor if isinstance(blk.attn1.processor, APAdapterCogVideoXAttnProcessor2_0) else self._plain
+            # norm1: shift, scale, gate, enc_shift, enc_scale, enc_gate = chunk(6)
+            nh = ops.layernorm(x, blk.norm1.norm.weight, blk.norm1.norm.bias, cfg["norm_eps"], shift0=chunk(2 * i, 3), scale0=chunk(2 * i, 4),
+                               shift1=chunk(2 * i, 0), scale1=chunk(2 * i, 1), rows_per_batch=S, split=Lt, mod_stride=ms)
+            scale = proc.scale[0] if ip is not None else 0.0
+            o = joint_attention_core(blk.attn1, proc, nh, Lt, rope, ip, scale)
+            ops.linear(o, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, out=x, epilogue=ops.EPI_GATE_RESID, resid=x,
+                       gate0=chunk(2 * i, 5), gate1=chunk(2 * i, 2), rows_per_batch=S, split=Lt, gate_stride=ms)
+            nh = ops.layernorm(x, blk.norm2.norm.weight, blk.norm2.norm.bias, cfg["norm_eps"], shift0=chunk(2 * i + 1, 3),
+                               scale0=chunk(2 * i + 1, 4), shift1=chunk(2 * i + 1, 0), scale1=chunk(2 * i + 1, 1), rows_per_batch=S,
+                               split=Lt, mod_stride=ms, out=nh)
+            f = ops.linear(nh, blk.ff.net[0].proj.weight, blk.ff.net[0].proj.bias, epilogue=ops.EPI_GELU_TANH)
+            ops.linear(f, blk.ff.net[2].weight, blk.ff.net[2].bias, out=x, epilogue=ops.EPI_GATE_RESID, resid=x,
+                       gate0=chunk(2 * i + 1, 5), gate1=chunk(2 * i + 1, 2), rows_per_batch=S, split=Lt, gate_stride=ms)
+
+        # tail: norm_final over the joint sequence, AdaLayerNorm (shift, scale = chunk(2)), proj_out, unpatchify
+        y = ops.layernorm(x, self.norm_final.weight, self.norm_final.bias, cfg["norm_eps"])
+        base = 2 * len(self.transformer_blocks) * 6 * D
+        sh, sc = mod[:, base:base + D], mod[:, base + D:base + 2 * D]
+        y = ops.layernorm(y, self.norm_out.norm.weight, self.norm_out.norm.bias, cfg["norm_eps"], shift0=sh, scale0=sc, shift1=sh, scale1=sc,
+                          rows_per_batch=S, split=Lt, mod_stride=ms, out=y)
+        out = ops.linear(y, self.proj_out.weight, self.proj_out.bias)
+        out = out[:, Lt:].contiguous()
+        return ops.unpatchify(out, B, F, cfg["out_channels"], H, W)
+
+
+# ------------------------------------------------------------------------------------------------------
+def get_3d_rotary_pos_embed(head_dim: int, t: int, h: int, w: int, theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """host-side table (diffusers get_3d_rotary_pos_embed, use_real=True, crop == full grid): [t*h*w, d] fp32."""
+    def one(dim, n):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+        f = torch.outer(torch.arange(n, dtype=torch.float32), freqs)
+        return f.cos().repeat_interleave(2, dim=1), f.sin().repeat_interleave(2, dim=1)
+    dt, dh, dw = head_dim // 4, head_dim // 8 * 3, head_dim // 8 * 3
+    (ct, st), (ch, sh), (cw, sw) = one(dt, t), one(dh, h), one(dw, w)
+
+    def bc(a_t, a_h, a_w):
+        return torch.cat([a_t[:, None, None, :].expand(t, h, w, dt), a_h[None, :, None, :].expand(t, h, w, dh),
+                          a_w[None, None, :, :].expand(t, h, w, dw)], dim=-1).reshape(t * h * w, head_dim).contiguous()
+    return bc(ct, ch, cw), bc(st, sh, sw)
+
+
+class CogVideoXDDIMScheduler:
+    """v-prediction DDIM, trailing spacing, zero-terminal-SNR scaled-linear betas (module.py:28-35 selects it;
+    tables are host-side float64 scalars, the update itself is the mrag_cfg_ddim_step kernel)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, snr_shift_scale=1.0):
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float64) ** 2
+        ac = np.cumprod(1.0 - betas)
+        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+        s = np.sqrt(ac)
+        s0, sT = s[0], s[-1]
+        s = (s - sT) * (s0 / (s0 - sT))
+        self.alphas_cumprod = s ** 2
+        self.num_train_timesteps = num_train_timesteps
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+        self.num_inference_steps = None
+
+    def set_timesteps(self, num_inference_steps: int):
+        n = self.num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = (np.round(np.arange(n, 0, -n / num_inference_steps)) - 1).astype(np.int64)
+        return self.timesteps
+
+    def coeffs(self, t: int):
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev] if prev >= 0 else 1.0
+        a = ((1 - a_prev) / (1 - a_t)) ** 0.5
+        b = a_prev ** 0.5 - a_t ** 0.5 * a
+        return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a), float(b)
+
+
+class CogVideoXImageToVideoCTPipeline:
+    """Hot-path mirror of src/projects/cogvideox/pipeline.py:92-130 (+ :46-57, :80-89).
+
+    `text_encoder` / `vae` are optional third-party callables; without them the caller passes
+    `prompt_embeds` / `negative_prompt_embeds` [b, 226, 4096] and `image_latents` [b, F, 16, H/8, W/8].
+    """
+
+    def __init__(self, transformer: CogVideoXTransformer3DModel, scheduler: CogVideoXDDIMScheduler, condition_transformer=None,
+                 text_encoder=None, vae=None):
+        self.transformer, self.scheduler = transformer, scheduler
+        self.condition_transformer, self.text_encoder, self.vae = condition_transformer, text_encoder, vae
+        self._rope_cache = {}
+
+    def _prepare_rotary_positional_embeddings(self, frames: int, gh: int, gw: int, device):
+        """pipeline.py:46-57: returns ((cos, sin), action_emb)"""
+        assert hasattr(self, "action_emb"), "action_emb is not set"
+        key = (frames, gh, gw, str(device))
+        if key not in self._rope_cache:
+            cos, sin = get_3d_rotary_pos_embed(64, frames, gh, gw)
+            self._rope_cache[key] = (cos.to(device), sin.to(device))
+        return self._rope_cache[key], self.action_emb
+
+    def prepare_action_embeddings(self, ref_videos: torch.Tensor, metadata=None, do_classifier_free_guidance: bool = False, image=None, **_):
+        """pipeline.py:117-130"""
+        image = image.to(ref_videos.device, ref_videos.dtype)
+        batch_ = {"ref_videos": ref_videos, "video": image[:, None].expand(-1, ref_videos.size(2), -1, -1, -1)}
+        return self.condition_transformer.predict(batch_, do_classifier_free_guidance=do_classifier_free_guidance)
+
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
+                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None) -> torch.Tensor:
+        """the hot loop: latents [b, F, 16, h, w] bf16 (N(0,1) noise), prompt_embeds = cat([negative, positive])
+        [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329)."""
+        self.action_emb = action_emb
+        b, F, C, h, w = latents.shape
+        p = self.transformer.cfg["patch"]
+        rope_ip = self._prepare_rotary_positional_embeddings(F, h // p, w // p, latents.device)
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        B = 2 * b
+        for i, t in enumerate(ts):
+            timestep = torch.full((B,), float(t), dtype=torch.float32, device=latents.device)
+            v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B)
+            sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))
+            ops.cfg_ddim_step_(v, latents, guidance_scale, sa, sb, a_t, b_t)
+            if callback is not None:
+                callback(i, int(t), latents)
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, ref_videos: torch.Tensor = None, metadata=None, *, image=None, prompt_embeds=None, negative_prompt_embeds=None,
+                 image_latents=None, latents=None, num_inference_steps: int = 50, guidance_scale: float = 6.0, num_frames: int = 49,
+                 height: int = 480, width: int = 720, generator: Optional[torch.Generator] = None, output_type: str = "latent", **kwargs):
+        """pipeline.py:80-89: action embeddings first, then the denoising loop."""
+        dev = next(self.transformer.parameters()).device
+        action_emb = self.prepare_action_embeddings(ref_videos, metadata, do_classifier_free_guidance=True, image=image)
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise ValueError("pass prompt_embeds / negative_prompt_embeds or a text_encoder callable")
+            prompt_embeds = self.text_encoder(kwargs["prompt"])
+            negative_prompt_embeds = self.text_encoder(kwargs.get("negative_prompt", [""] * len(kwargs["prompt"])))
+        pe = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dev, torch.bfloat16).contiguous()
+        b = prompt_embeds.shape[0]
+        F = (num_frames - 1) // 4 + 1
+        if image_latents is None:
+            if self.vae is None:
+                raise ValueError("pass image_latents or a vae callable")
+            image_latents = self.vae.encode_image(image, F)
+        if latents is None:
+            noise = torch.randn(b, F, 16, height // 8, width // 8, generator=generator, dtype=torch.float32)   # CPU-seeded
+            latents = noise.to(dev, torch.bfloat16)
+        latents = self.denoise(latents.contiguous(), image_latents.to(dev, torch.bfloat16).contiguous(), pe, action_emb, num_inference_steps,
+                               guidance_scale)
+        if output_type == "latent" or self.vae is None:
+            return (latents,)
+        return (self.vae.decode(latents),)

@@ -1,0 +1,216 @@
+// norm.hip -- HBM-bound normalisation kernels for gfx950: LayerNorm (+AdaLN modulation) and the
+// per-head qk-LayerNorm + 3-D RoPE applied in place on a fused QKV buffer.
+// One wavefront (64 lanes) per row, 16-byte bf16 vectors per lane, reductions by wave shuffles.
+#include "common.h"
+#include "../../include/mrag_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(r[i] << 16);
+    f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return r;
+}
+
+struct LnP {
+  const bf16_t* x; bf16_t* y; const bf16_t* gamma; const bf16_t* beta;
+  const bf16_t* shift0; const bf16_t* scale0; const bf16_t* shift1; const bf16_t* scale1;
+  long long rows, D, ldx, ldy, rows_per_batch, split, mod_stride, y_rpb, y_bstride;
+  float eps;
+};
+
+// y = LN(x) * gamma + beta ; y = y * (1 + scale[b]) + shift[b]
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= p.rows) return;
+  const bf16_t* x = p.x + row * p.ldx;
+  float v[MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const long long idx = ((long long)c * 64 + lane) * 8;
+    if (idx < p.D) {
+      unpack8(*(const u32x4*)(x + idx), v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[c][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)p.D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const long long idx = ((long long)c * 64 + lane) * 8;
+    if (idx < p.D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+
+  const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
+  if (p.shift0) {
+    const long long b = row / p.rows_per_batch, pos = row - b * p.rows_per_batch;
+    shift = (pos < p.split ? p.shift0 : p.shift1) + b * p.mod_stride;
+    scale = (pos < p.split ? p.scale0 : p.scale1) + b * p.mod_stride;
+  }
+  bf16_t* y = p.y_rpb > 0 ? p.y + (row / p.y_rpb) * p.y_bstride + (row % p.y_rpb) * p.ldy : p.y + row * p.ldy;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const long long idx = ((long long)c * 64 + lane) * 8;
+    if (idx >= p.D) continue;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+    if (p.gamma) {
+      float g[8]; unpack8(*(const u32x4*)(p.gamma + idx), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] *= g[e];
+    }
+    if (p.beta) {
+      float bb[8]; unpack8(*(const u32x4*)(p.beta + idx), bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += bb[e];
+    }
+    if (shift) {
+      float sc[8], sh[8];
+      unpack8(*(const u32x4*)(scale + idx), sc);
+      unpack8(*(const u32x4*)(shift + idx), sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+    }
+    *(u32x4*)(y + idx) = pack8(o);
+  }
+}
+
+struct QkP {
+  bf16_t* qkv; const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb;
+  const float* cos; const float* sin;
+  int B, S, H, text_len; float eps, q_premul;
+};
+
+// one wave = 8 heads x 64 dims of one token's Q (or K); LN over the 8 lanes of a head, RoPE pairs lane-local
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(const QkP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hgroups = (p.H + 7) / 8;
+  const long long units = (long long)p.B * p.S * 2 * hgroups;
+  const int sub = lane >> 3, d0 = (lane & 7) * 8;
+  for (long long u = (long long)blockIdx.x * 4 + wave; u < units; u += (long long)gridDim.x * 4) {
+    const int hg = (int)(u % hgroups);
+    const int which = (int)((u / hgroups) & 1);
+    const long long tok = u / (2 * hgroups);
+    const int s = (int)(tok % p.S);
+    const int head = hg * 8 + sub;
+    if (head >= p.H) continue;
+    bf16_t* ptr = p.qkv + tok * (3LL * p.H * 64) + (long long)which * p.H * 64 + head * 64 + d0;
+    float v[8];
+    unpack8(*(const u32x4*)ptr, v);
+    const bf16_t* g = which ? p.kg : p.qg;
+    const bf16_t* bt = which ? p.kb : p.qb;
+    if (g) {
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[e];
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+      const float mean = sum * (1.0f / 64.0f);
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+      sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+      const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
+      float gg[8], bb[8];
+      unpack8(*(const u32x4*)(g + d0), gg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gg[e];
+      if (bt) {
+        unpack8(*(const u32x4*)(bt + d0), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+      }
+    }
+    if (p.cos && s >= p.text_len) {
+      const long long ro = (long long)(s - p.text_len) * 64 + d0;
+      const f32x4 c0 = *(const f32x4*)(p.cos + ro), c1 = *(const f32x4*)(p.cos + ro + 4);
+      const f32x4 s0 = *(const f32x4*)(p.sin + ro), s1 = *(const f32x4*)(p.sin + ro + 4);
+      const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // x_rotated = stack([-x_imag, x_real]); out = x*cos + x_rotated*sin   (diffusers apply_rotary_emb)
+        o[2 * i] = v[2 * i] * cc[2 * i] - v[2 * i + 1] * ss[2 * i];
+        o[2 * i + 1] = v[2 * i + 1] * cc[2 * i + 1] + v[2 * i] * ss[2 * i + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = o[e];
+    }
+    if (!which && p.q_premul != 1.0f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.q_premul;
+    }
+    *(u32x4*)ptr = pack8(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
+  if (!a || !a->x || !a->y || a->rows <= 0 || a->D <= 0) return MRAG_EINVAL;
+  if (a->D % 8 != 0 || a->ldx % 8 != 0 || a->ldy % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)a->x | (uintptr_t)a->y) & 15) return MRAG_EINVAL;
+  if (a->D > 8192) return MRAG_ENOTSUP;
+  if (a->shift0 && (!a->scale0 || !a->shift1 || !a->scale1 || a->rows_per_batch <= 0 || a->mod_stride % 8 != 0))
+    return MRAG_EINVAL;
+  LnP p{};
+  p.x = (const bf16_t*)a->x; p.y = (bf16_t*)a->y; p.gamma = (const bf16_t*)a->gamma; p.beta = (const bf16_t*)a->beta;
+  p.shift0 = (const bf16_t*)a->shift0; p.scale0 = (const bf16_t*)a->scale0;
+  p.shift1 = (const bf16_t*)a->shift1; p.scale1 = (const bf16_t*)a->scale1;
+  p.rows = a->rows; p.D = a->D; p.ldx = a->ldx; p.ldy = a->ldy;
+  p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.mod_stride = a->mod_stride; p.eps = a->eps;
+  p.y_rpb = a->y_rows_per_batch; p.y_bstride = a->y_batch_stride;
+  if (p.y_rpb < 0 || (p.y_rpb > 0 && p.y_bstride % 8 != 0)) return MRAG_EINVAL;
+  const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->D <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, p);
+  else if (a->D <= 4096) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_qknorm_rope_bf16(void* stream, const mrag_qknorm_rope_args* a) {
+  if (!a || !a->qkv || a->B <= 0 || a->S <= 0 || a->H <= 0) return MRAG_EINVAL;
+  if ((uintptr_t)a->qkv & 15) return MRAG_EINVAL;
+  if ((a->cos == nullptr) != (a->sin == nullptr)) return MRAG_EINVAL;
+  if (a->cos && (((uintptr_t)a->cos | (uintptr_t)a->sin) & 15)) return MRAG_EINVAL;
+  if (a->text_len < 0 || a->text_len > a->S) return MRAG_EINVAL;
+  QkP p{};
+  p.qkv = (bf16_t*)a->qkv; p.qg = (const bf16_t*)a->q_gamma; p.qb = (const bf16_t*)a->q_beta;
+  p.kg = (const bf16_t*)a->k_gamma; p.kb = (const bf16_t*)a->k_beta;
+  p.cos = a->cos; p.sin = a->sin; p.B = a->B; p.S = a->S; p.H = a->H; p.text_len = a->text_len;
+  p.eps = a->eps; p.q_premul = a->q_premul;
+  const long long units = (long long)a->B * a->S * 2 * ((a->H + 7) / 8);
+  long long blocks = (units + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}

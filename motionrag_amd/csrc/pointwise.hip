@@ -1,0 +1,206 @@
+// pointwise.hip -- HBM-bound elementwise kernels of the denoising loop (gfx950).
+// All of them stream 16-byte bf16 vectors per lane (grid-stride over <= 2048 workgroups).
+#include "common.h"
+#include "../../include/mrag_hip.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(r[i] << 16);
+    f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return r;
+}
+
+inline unsigned grid_for(long long work_items) {
+  long long b = (work_items + 255) / 256;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0) == lvdm timestep_embedding:
+// out[b, i] = cos(t_b * f_i), out[b, half + i] = sin(t_b * f_i), f_i = exp(-ln(1e4) * i / half)
+__global__ void timestep_embedding_kernel(const float* t, bf16_t* out, int B, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, j = i % half;
+  const float f = expf(-9.210340371976184f * (float)j / (float)half);
+  const float arg = t[b] * f;
+  out[(long long)b * dim + j] = f2bf(cosf(arg));
+  out[(long long)b * dim + half + j] = f2bf(sinf(arg));
+}
+
+__global__ void silu_kernel(const bf16_t* x, bf16_t* y, long long n8, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float v[8]; unpack8(*(const u32x4*)(x + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    *(u32x4*)(y + i * 8) = pack8(v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) {
+    const long long i = n8 * 8 + threadIdx.x;
+    y[i] = f2bf(silu_f(bf2f(x[i])));
+  }
+}
+
+__global__ void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* y, long long n8, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    unpack8(*(const u32x4*)(a + i * 8), u);
+    unpack8(*(const u32x4*)(b + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] += v[e];
+    *(u32x4*)(y + i * 8) = pack8(u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) {
+    const long long i = n8 * 8 + threadIdx.x;
+    y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+  }
+}
+
+// y[r, :] = x[r, :] + table[r % period, :]
+__global__ void add_rows_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long period) {
+  const long long total = rows * D8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / D8, c = i - r * D8;
+    float u[8], v[8];
+    unpack8(*(const u32x4*)(x + i * 8), u);
+    unpack8(*(const u32x4*)(table + ((r % period) * D8 + c) * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] += v[e];
+    *(u32x4*)(y + i * 8) = pack8(u);
+  }
+}
+
+// dst[((b*F+f)*Hp+ph)*Wp+pw, c*4+dy*2+dx] = src[b % Bl, f, c, 2ph+dy, 2pw+dx]; src = cat(src0, src1) on c.
+// one thread writes the 4 values (dy,dx) of one (row, c): 8 contiguous bytes.
+__global__ void patchify_kernel(const bf16_t* s0, const bf16_t* s1, bf16_t* dst, int B, int Bl, int F, int C0, int C1, int H, int W) {
+  const int Hp = H / 2, Wp = W / 2, C = C0 + C1;
+  const long long total = (long long)B * F * Hp * Wp * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int pw = (int)(r % Wp); long long r2 = r / Wp;
+    const int ph = (int)(r2 % Hp); r2 /= Hp;
+    const int f = (int)(r2 % F);
+    const int b = (int)(r2 / F);
+    const int bl = b % Bl;
+    const bf16_t* src; int cc, CC;
+    if (c < C0) { src = s0; cc = c; CC = C0; } else { src = s1; cc = c - C0; CC = C1; }
+    const bf16_t* sp = src + (((long long)(bl * F + f) * CC + cc) * H + 2 * ph) * W + 2 * pw;
+    const unsigned top = *(const unsigned*)sp;        // (dy=0, dx=0..1)
+    const unsigned bot = *(const unsigned*)(sp + W);  // (dy=1, dx=0..1)
+    u32x2 o; o[0] = top; o[1] = bot;
+    *(u32x2*)(dst + r * (C * 4) + c * 4) = o;
+  }
+}
+
+// dst[b, f, c, 2ph+dy, 2pw+dx] = src[b, (f*Hp+ph)*Wp+pw, c*4+dy*2+dx]
+__global__ void unpatchify_kernel(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W) {
+  const int Hp = H / 2, Wp = W / 2;
+  const long long total = (long long)B * F * C * Hp * Wp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int pw = (int)(i % Wp); long long r = i / Wp;
+    const int ph = (int)(r % Hp); r /= Hp;
+    const int c = (int)(r % C); r /= C;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    const long long srow = ((long long)(b * F + f) * Hp + ph) * Wp + pw;
+    const u32x2 v = *(const u32x2*)(src + srow * (C * 4) + c * 4);
+    bf16_t* dp = dst + (((long long)(b * F + f) * C + c) * H + 2 * ph) * W + 2 * pw;
+    *(unsigned*)dp = v[0];
+    *(unsigned*)(dp + W) = v[1];
+  }
+}
+
+// v = v_u + g (v_c - v_u); x0 = sa x - sb v; x <- a x + b x0      (CogVideoX DDIM, v-prediction)
+__global__ void cfg_ddim_kernel(const bf16_t* vp, bf16_t* x, long long n8, long long n, float g, float sa, float sb, float a, float b) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float vu[8], vc[8], xx[8];
+    unpack8(*(const u32x4*)(vp + i * 8), vu);
+    unpack8(*(const u32x4*)(vp + n + i * 8), vc);
+    unpack8(*(const u32x4*)(x + i * 8), xx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = vu[e] + g * (vc[e] - vu[e]);
+      const float x0 = sa * xx[e] - sb * v;
+      xx[e] = a * xx[e] + b * x0;
+    }
+    *(u32x4*)(x + i * 8) = pack8(xx);
+  }
+}
+
+}  // namespace
+
+extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
+  if (!t || !out || B <= 0 || dim <= 0 || (dim & 1)) return MRAG_EINVAL;
+  const int total = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, B, dim);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_silu_bf16(void* stream, const void* x, void* y, int64_t n) {
+  if (!x || !y || n <= 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return MRAG_EINVAL;
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)(n / 8), (long long)n);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_add_bf16(void* stream, const void* a, const void* b, void* y, int64_t n) {
+  if (!a || !b || !y || n <= 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15)) return MRAG_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long long)(n / 8), (long long)n);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_add_rows_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t period) {
+  if (!x || !table || !y || rows <= 0 || D <= 0 || period <= 0 || D % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)table | (uintptr_t)y) & 15) return MRAG_EINVAL;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * D / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)table, (bf16_t*)y, (long long)rows, (long long)(D / 8), (long long)period);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst, int32_t B, int32_t Bl, int32_t F,
+                                  int32_t C0, int32_t C1, int32_t H, int32_t W) {
+  if (!src0 || !dst || B <= 0 || Bl <= 0 || F <= 0 || C0 <= 0 || C1 < 0 || H <= 0 || W <= 0) return MRAG_EINVAL;
+  if ((H & 1) || (W & 1) || (C1 > 0 && !src1) || B % Bl != 0) return MRAG_EINVAL;
+  if (((uintptr_t)src0 | (uintptr_t)src1) & 3) return MRAG_EINVAL;
+  if ((uintptr_t)dst & 7) return MRAG_EINVAL;
+  const long long total = (long long)B * F * (H / 2) * (W / 2) * (C0 + C1);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, (const bf16_t*)src1,
+                     (bf16_t*)dst, B, Bl, F, C0, C1, H, W);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_unpatchify_bf16(void* stream, const void* src, void* dst, int32_t B, int32_t F, int32_t C, int32_t H, int32_t W) {
+  if (!src || !dst || B <= 0 || F <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return MRAG_EINVAL;
+  if (((uintptr_t)src & 7) || ((uintptr_t)dst & 3)) return MRAG_EINVAL;
+  const long long total = (long long)B * F * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, F, C, H, W);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n, float guidance, float sqrt_alpha_t,
+                                       float sqrt_beta_t, float a_t, float b_t) {
+  if (!v_pred || !latents || n <= 0 || n % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents,
+                     (long long)(n / 8), (long long)n, guidance, sqrt_alpha_t, sqrt_beta_t, a_t, b_t);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}

@@ -1,0 +1,263 @@
+"""Thin torch-tensor front end of the C ABI (include/mrag_hip.h).
+
+torch is plumbing here: it owns device memory and the HIP stream; every arithmetic op below is a
+hand-written gfx950 kernel in libmrag_hip.so.  There is no CPU path: tensors must be bf16 (or fp32 /
+int32 where stated) on a ROCm device, otherwise `HipOnly` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, GemmArgs, LnArgs, QkNormRopeArgs, check
+
+EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU = range(6)
+LOG2E = 1.4426950408889634
+
+
+class HipOnly(RuntimeError):
+    """Raised when an op is handed a tensor that is not on the GPU (no CPU fallback exists)."""
+
+
+def _dev(t: torch.Tensor, dtype=torch.bfloat16, name="tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipOnly(f"{name}: motionrag_amd ops run only on a ROCm GPU (got {getattr(t, 'device', type(t))})")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """view as [rows, D] with D contiguous"""
+    if t.stride(-1) != 1:
+        raise ValueError("innermost dimension must be contiguous")
+    return t.reshape(-1, t.shape[-1]) if t.dim() != 2 else t
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
+           epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate0: Optional[torch.Tensor] = None,
+           gate1: Optional[torch.Tensor] = None, rows_per_batch: int = 0, split: int = 0, gate_stride: int = 0) -> torch.Tensor:
+    """out = epilogue(x @ weight.T + bias); x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout)."""
+    _dev(x, name="x"); _dev(weight, name="weight")
+    x2 = _rows(x)
+    M, K = x2.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match K={K}")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
+    o2 = _rows(out)
+    a = GemmArgs()
+    a.A, a.W, a.bias, a.C = _p(x2), _p(weight), _p(bias), _p(o2)
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldw, a.ldc = x2.stride(0), weight.stride(0), o2.stride(0)
+    a.epilogue = epilogue
+    if resid is not None:
+        r2 = _rows(_dev(resid, name="resid"))
+        a.resid, a.ldr = _p(r2), r2.stride(0)
+    if epilogue == EPI_GATE_RESID:
+        a.gate0, a.gate1 = _p(_dev(gate0, name="gate0")), _p(_dev(gate1, name="gate1"))
+        a.rows_per_batch, a.split, a.gate_stride = rows_per_batch, split, gate_stride
+    check(_lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a)), "mrag_gemm_bf16")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+              resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, kv_batch_div: int = 1,
+              scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False) -> torch.Tensor:
+    """softmax(q k^T * scale [masked]) v for head_dim 64.
+
+    q [B, Sq, H, 64], k/v [Bkv, Skv, H, 64] (any strides with the last dim contiguous, e.g. views of a
+    fused QKV buffer); out/resid [B, Sq, H*64] with the last two dims packed.  mask: bool/uint8
+    [Sq, Skv], True = blocked.  out = resid + out_scale * attention when resid is given.
+    """
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _dev(t, name=n)
+        if t.dim() != 4 or t.shape[-1] != 64 or t.stride(-1) != 1:
+            raise ValueError(f"{n}: expected [B, S, H, 64] with contiguous head dim, got {tuple(t.shape)}")
+    B, Sq, H, _ = q.shape
+    Bkv, Skv = k.shape[0], k.shape[1]
+    if Bkv * kv_batch_div != B:
+        raise ValueError("kv batch * kv_batch_div must equal q batch")
+    if out is None:
+        out = torch.empty(B, Sq, H * 64, dtype=torch.bfloat16, device=q.device)
+    a = AttnArgs()
+    a.Q, a.K, a.V, a.O = _p(q), _p(k), _p(v), _p(out)
+    a.q_sb, a.q_ss, a.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    a.k_sb, a.k_ss, a.k_sh = k.stride(0), k.stride(1), k.stride(2)
+    a.v_sb, a.v_ss, a.v_sh = v.stride(0), v.stride(1), v.stride(2)
+    if out.stride(-1) != 1:
+        raise ValueError("out must have a contiguous last dim")
+    a.o_sb, a.o_ss = out.stride(0), out.stride(1)
+    if resid is not None:
+        _dev(resid, name="resid")
+        if resid.stride() != out.stride():
+            raise ValueError("resid must share out's layout")
+        a.resid = _p(resid)
+    if mask is not None:
+        if not mask.is_cuda:
+            raise HipOnly("mask must be on the GPU")
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.dtype != torch.uint8 or tuple(mask.shape) != (Sq, Skv) or not mask.is_contiguous():
+            raise ValueError("mask must be a contiguous bool/uint8 [Sq, Skv]")
+        a.mask = _p(mask)
+    a.B, a.H, a.Sq, a.Skv, a.kv_batch_div = B, H, Sq, Skv, kv_batch_div
+    a.scale = (64 ** -0.5) if scale is None else scale
+    a.out_scale = out_scale
+    a.q_prescaled = 1 if q_prescaled else 0
+    check(_lib.lib().mrag_attn_fwd_bf16(_stream(), ctypes.byref(a)), "mrag_attn_fwd_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float, *,
+              out: Optional[torch.Tensor] = None, shift0=None, scale0=None, shift1=None, scale1=None,
+              rows_per_batch: int = 0, split: int = 0, mod_stride: int = 0, out_batched: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over the last dim (+ AdaLN modulation).  `out_batched` [B, L', D] (a view whose batch
+    stride differs from L*D, e.g. a slice of a concat buffer) receives x [B, L, D] row by row."""
+    _dev(x, name="x")
+    x2 = _rows(x)
+    a = LnArgs()
+    if out_batched is not None:
+        if x.dim() != 3 or out_batched.stride(-1) != 1 or out_batched.shape != x.shape:
+            raise ValueError("out_batched must be a [B, L, D] view matching x")
+        out = out_batched
+        a.y, a.ldy = _p(out_batched), out_batched.stride(1)
+        a.y_rows_per_batch, a.y_batch_stride = x.shape[1], out_batched.stride(0)
+    else:
+        if out is None:
+            out = torch.empty_like(x)
+        o2 = _rows(out)
+        a.y, a.ldy = _p(o2), o2.stride(0)
+    a.x, a.gamma, a.beta = _p(x2), _p(gamma), _p(beta)
+    a.rows, a.D, a.ldx = x2.shape[0], x2.shape[1], x2.stride(0)
+    a.eps = eps
+    if shift0 is not None:
+        a.shift0, a.scale0, a.shift1, a.scale1 = _p(shift0), _p(scale0), _p(shift1), _p(scale1)
+        a.rows_per_batch, a.split, a.mod_stride = rows_per_batch, split, mod_stride
+    check(_lib.lib().mrag_layernorm_bf16(_stream(), ctypes.byref(a)), "mrag_layernorm_bf16")
+    return out
+
+
+def qknorm_rope_(qkv: torch.Tensor, H: int, q_gamma, q_beta, k_gamma, k_beta, cos: Optional[torch.Tensor],
+                 sin: Optional[torch.Tensor], text_len: int, eps: float = 1e-6, q_premul: float = 1.0) -> torch.Tensor:
+    """in place on a fused [B, S, 3*H*64] buffer: per-head LayerNorm of Q and K, RoPE on tokens >= text_len."""
+    _dev(qkv, name="qkv")
+    B, S, W = qkv.shape
+    if W != 3 * H * 64 or not qkv.is_contiguous():
+        raise ValueError("qkv must be a contiguous [B, S, 3*H*64]")
+    a = QkNormRopeArgs()
+    a.qkv, a.q_gamma, a.q_beta, a.k_gamma, a.k_beta = _p(qkv), _p(q_gamma), _p(q_beta), _p(k_gamma), _p(k_beta)
+    if cos is not None:
+        _dev(cos, torch.float32, "cos"); _dev(sin, torch.float32, "sin")
+        if tuple(cos.shape) != (S - text_len, 64) or not cos.is_contiguous() or not sin.is_contiguous():
+            raise ValueError("cos/sin must be contiguous [S - text_len, 64] fp32")
+        a.cos, a.sin = _p(cos), _p(sin)
+    a.B, a.S, a.H, a.text_len, a.eps, a.q_premul = B, S, H, text_len, eps, q_premul
+    check(_lib.lib().mrag_qknorm_rope_bf16(_stream(), ctypes.byref(a)), "mrag_qknorm_rope_bf16")
+    return qkv
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _dev(t, torch.float32, "t")
+    out = torch.empty(t.shape[0], dim, dtype=torch.bfloat16, device=t.device)
+    check(_lib.lib().mrag_timestep_embedding_bf16(_stream(), _p(t), _p(out), t.shape[0], dim), "mrag_timestep_embedding_bf16")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, name="x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().mrag_silu_bf16(_stream(), _p(x), _p(y), x.numel()), "mrag_silu_bf16")
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(a, name="a"); _dev(b, name="b")
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add: same-shape contiguous tensors required")
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().mrag_add_bf16(_stream(), _p(a), _p(b), _p(out), a.numel()), "mrag_add_bf16")
+    return out
+
+
+def add_rows(x: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [..., L, D] + table [L, D] broadcast over the leading dims (sinusoid position table)."""
+    _dev(x, name="x"); _dev(table, name="table")
+    if not x.is_contiguous() or not table.is_contiguous() or x.shape[-2:] != table.shape:
+        raise ValueError("add_rows: x [..., L, D], table [L, D], both contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    L, D = table.shape
+    check(_lib.lib().mrag_add_rows_bf16(_stream(), _p(x), _p(table), _p(out), x.numel() // D, D, L), "mrag_add_rows_bf16")
+    return out
+
+
+def patchify(src0: torch.Tensor, src1: Optional[torch.Tensor], B: int) -> torch.Tensor:
+    """[Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> [B*F*(H/2)*(W/2), (C0+C1)*4]; batch b reads latent b % Bl."""
+    _dev(src0, name="src0")
+    Bl, F, C0, H, W = src0.shape
+    C1 = 0
+    if src1 is not None:
+        _dev(src1, name="src1")
+        C1 = src1.shape[2]
+    if not src0.is_contiguous() or (src1 is not None and not src1.is_contiguous()):
+        raise ValueError("patchify: contiguous inputs required")
+    out = torch.empty(B * F * (H // 2) * (W // 2), (C0 + C1) * 4, dtype=torch.bfloat16, device=src0.device)
+    check(_lib.lib().mrag_patchify_bf16(_stream(), _p(src0), _p(src1), _p(out), B, Bl, F, C0, C1, H, W), "mrag_patchify_bf16")
+    return out
+
+
+def unpatchify(rows: torch.Tensor, B: int, F: int, C: int, H: int, W: int) -> torch.Tensor:
+    _dev(rows, name="rows")
+    if not rows.is_contiguous():
+        raise ValueError("unpatchify: contiguous input required")
+    out = torch.empty(B, F, C, H, W, dtype=torch.bfloat16, device=rows.device)
+    check(_lib.lib().mrag_unpatchify_bf16(_stream(), _p(rows), _p(out), B, F, C, H, W), "mrag_unpatchify_bf16")
+    return out
+
+
+def cfg_ddim_step_(v_pred: torch.Tensor, latents: torch.Tensor, guidance: float, sqrt_alpha_t: float, sqrt_beta_t: float,
+                   a_t: float, b_t: float) -> torch.Tensor:
+    """latents <- DDIM(v_u + g (v_c - v_u)); v_pred [2, ...] (uncond first), latents [...] in place."""
+    _dev(v_pred, name="v_pred"); _dev(latents, name="latents")
+    n = latents.numel()
+    if v_pred.numel() != 2 * n or not v_pred.is_contiguous() or not latents.is_contiguous():
+        raise ValueError("cfg_ddim_step_: v_pred must be [2, *latents.shape], contiguous")
+    check(_lib.lib().mrag_cfg_ddim_step_bf16(_stream(), _p(v_pred), _p(latents), n, guidance, sqrt_alpha_t, sqrt_beta_t, a_t, b_t),
+          "mrag_cfg_ddim_step_bf16")
+    return latents
+
+
+def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None,
+         exclude: Optional[torch.Tensor] = None):
+    """flat-scan top-k: returns (rows int32 [Q, k], dist fp32 [Q, k]) sorted by (dist asc, row asc)."""
+    _dev(db, torch.float32, "db"); _dev(queries, torch.float32, "queries")
+    if not db.is_contiguous() or not queries.is_contiguous():
+        raise ValueError("topk: contiguous db / queries required")
+    N, D = db.shape
+    Q = queries.shape[0]
+    m = {"l2": 0, "dot": 1}[metric]
+    if exclude is not None:
+        _dev(group, torch.int32, "group"); _dev(exclude, torch.int32, "exclude")
+    L = _lib.lib()
+    ws_bytes = L.mrag_topk_workspace_bytes(N, Q)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=db.device)
+    rows = torch.empty(Q, k, dtype=torch.int32, device=db.device)
+    dist = torch.empty(Q, k, dtype=torch.float32, device=db.device)
+    check(L.mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
+                          _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws_bytes), "mrag_topk_f32")
+    return rows, dist

@@ -1,0 +1,68 @@
+/* ORACLE (test infrastructure only -- never linked or called by the product path).
+ *
+ * Plain-C restatement of the retrieval step of MCG-NJU/MotionRAG:
+ *   RAGDatabase.text_search -> vector_search (src/data/rag.py:63-80,36-61), i.e.
+ *   table.search(vec, "text_embedding").limit(k)[.where('video != "<self>"')]
+ * The arithmetic lives in the third-party dependency lancedb==0.14.0 (requirements.txt:18, Rust `lance`
+ * core), absent from /root/reference.  Its published flat-scan algorithm is restated here: without an
+ * index (tools/build_rag_database.py:51-52 only builds one above 1 M rows) every row is scored and the
+ * k smallest distances are returned in ascending order; `_distance` is the squared L2 distance (LanceDB
+ * default metric "l2") or 1 - dot for metric "dot" (the metric the reference's index uses).  The
+ * `where` prefilter removes rows before selection (the caller over-fetches k+3 and keeps k:
+ * src/data/datamodule.py:234, src/data/dataset.py:296).  PARITY UNPINNED against LanceDB itself: the
+ * reference holds no test or golden vector for retrieval.
+ *
+ * Two scoring modes:
+ *   mode 0: float32 sequential fmaf chain over d = 0..D-1 -- the exact chain the HIP kernel runs, so
+ *           distances and indices are BIT-EXACT comparable;
+ *   mode 1: float64 accumulation (canonical math), used to check that mode 0 ranks the same rows.
+ * Ties: (distance asc, row asc).  Missing results: row = -1, dist = +inf.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+typedef struct { double d; int32_t r; } cand_t;
+
+static int cand_less(cand_t a, cand_t b) { return a.d < b.d || (a.d == b.d && a.r < b.r); }
+
+static double score(const float* q, const float* x, int dim, int metric, int mode) {
+  if (mode == 0) {
+    float acc = 0.0f;
+    if (metric == 0) { for (int d = 0; d < dim; ++d) { float df = q[d] - x[d]; acc = fmaf(df, df, acc); } return (double)acc; }
+    for (int d = 0; d < dim; ++d) acc = fmaf(q[d], x[d], acc);
+    return (double)(1.0f - acc);
+  } else {
+    double acc = 0.0;
+    if (metric == 0) { for (int d = 0; d < dim; ++d) { double df = (double)q[d] - (double)x[d]; acc += df * df; } return acc; }
+    for (int d = 0; d < dim; ++d) acc += (double)q[d] * (double)x[d];
+    return 1.0 - acc;
+  }
+}
+
+/* out_rows [nq, k] int32, out_dist [nq, k] double */
+int topk_oracle(const float* db, const int32_t* group, int64_t n_rows, int dim, const float* queries, const int32_t* exclude,
+                int nq, int k, int metric, int mode, int32_t* out_rows, double* out_dist) {
+  if (k <= 0 || n_rows <= 0 || nq <= 0) return -1;
+  cand_t* best = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+  if (!best) return -2;
+  for (int qi = 0; qi < nq; ++qi) {
+    int nb = 0;
+    const float* q = queries + (size_t)qi * dim;
+    for (int64_t r = 0; r < n_rows; ++r) {
+      if (exclude && group && group[r] == exclude[qi]) continue;
+      cand_t c; c.d = score(q, db + (size_t)r * dim, dim, metric, mode); c.r = (int32_t)r;
+      if (nb == k && !cand_less(c, best[k - 1])) continue;
+      int pos = nb < k ? nb : k - 1;           /* insertion into the sorted list */
+      while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
+      best[pos] = c;
+      if (nb < k) ++nb;
+    }
+    for (int j = 0; j < k; ++j) {
+      out_rows[(size_t)qi * k + j] = j < nb ? best[j].r : -1;
+      out_dist[(size_t)qi * k + j] = j < nb ? best[j].d : INFINITY;
+    }
+  }
+  free(best);
+  return 0;
+}

@@ -1,0 +1,59 @@
+"""ORACLE (test infrastructure only): ctypes front end of oracle/topk_oracle.c plus a pure-numpy
+float64 restatement used to cross-check it.  See topk_oracle.c for the reference citations."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtopk_oracle.so")
+
+
+def build() -> str:
+    src = os.path.join(_HERE, "topk_oracle.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libtopk_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, mode: str = "f32chain"):
+    """returns (rows int32 [Q, k], dist float64 [Q, k]); mode 'f32chain' (bit-comparable with the HIP
+    kernel) or 'f64'."""
+    lib = ctypes.CDLL(build())
+    db = np.ascontiguousarray(db, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    n, d = db.shape
+    q = queries.shape[0]
+    rows = np.empty((q, k), dtype=np.int32)
+    dist = np.empty((q, k), dtype=np.float64)
+    gp = ep = None
+    if exclude is not None:
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        exclude = np.ascontiguousarray(exclude, dtype=np.int32)
+        gp, ep = group.ctypes.data_as(ctypes.c_void_p), exclude.ctypes.data_as(ctypes.c_void_p)
+    lib.topk_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = lib.topk_oracle(db.ctypes.data_as(ctypes.c_void_p), gp, n, d, queries.ctypes.data_as(ctypes.c_void_p), ep, q, k,
+                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1}[mode], rows.ctypes.data_as(ctypes.c_void_p),
+                         dist.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"topk_oracle rc={rc}")
+    return rows, dist
+
+
+def topk_numpy(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None):
+    """float64 numpy restatement (small cases): stable argsort on (dist, row)."""
+    db64, q64 = db.astype(np.float64), queries.astype(np.float64)
+    if metric == "l2":
+        dist = ((q64[:, None, :] - db64[None, :, :]) ** 2).sum(-1)
+    else:
+        dist = 1.0 - q64 @ db64.T
+    if exclude is not None:
+        dist = np.where(np.asarray(group)[None, :] == np.asarray(exclude)[:, None], np.inf, dist)
+    order = np.argsort(dist, axis=1, kind="stable")[:, :k]
+    d = np.take_along_axis(dist, order, axis=1)
+    rows = np.where(np.isinf(d), -1, order).astype(np.int32)
+    return rows, d

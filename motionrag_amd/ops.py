@@ -117,8 +117,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
     a.scale = (64 ** -0.5) if scale is None else scale
     a.out_scale = out_scale
     a.q_prescaled = 1 if q_prescaled else 0
+    timed = KERNEL_TIMING is not None and Skv >= 1024
+    if timed:  # bench.py's roofline leg: HIP events on the launch stream around this one kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().mrag_attn_fwd_bf16(_stream(), ctypes.byref(a)), "mrag_attn_fwd_bf16")
+    if timed:
+        e1.record()
+        KERNEL_TIMING.append(("attn_fwd", 4.0 * B * H * Sq * Skv * 64, e0, e1))
     return out
+
+
+# bench.py sets this to a list to collect (name, algorithmic_flops, start_event, end_event) per big attention launch
+KERNEL_TIMING = None
 
 
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float, *,

@@ -1,0 +1,117 @@
+"""CPU suite: the C-ABI library builds, loads and exports every symbol include/mrag_hip.h declares (no compute calls),
+host-side logic (scheduler tables, RoPE tables, masks, retrieval table I/O), and the product path's refusal to run
+without the GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from motionrag_amd import _lib
+    _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "mrag_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mrag_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    lib = _lib.lib()
+    assert lib.mrag_abi_version() == _lib.ABI_VERSION and lib.mrag_target_arch() == b"gfx950"
+    assert lib.mrag_topk_workspace_bytes(10000, 256) > 0
+
+
+def test_struct_layouts_match_the_header():
+    """field order / count of the ctypes structs follows the header's typedefs"""
+    from motionrag_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mrag_hip.h")).read()
+    for cname, st in (("mrag_gemm_args", _lib.GemmArgs), ("mrag_attn_args", _lib.AttnArgs), ("mrag_ln_args", _lib.LnArgs),
+                      ("mrag_qknorm_rope_args", _lib.QkNormRopeArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+        assert names == [f[0] for f in st._fields_], (cname, names)
+
+
+def test_ops_refuse_cpu_tensors():
+    from motionrag_amd import ops, rag
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(ops.HipOnly):
+        ops.linear(x, x)
+    with pytest.raises(ops.HipOnly):
+        ops.layernorm(x, None, None, 1e-5)
+    with pytest.raises(ops.HipOnly):
+        ops.topk(torch.zeros(4, 32), torch.zeros(1, 32), 2)
+    with pytest.raises(ops.HipOnly):
+        rag.RAGDatabase.from_arrays(np.zeros((4, 32), np.float32), [{"video": "a"}] * 4, device="cpu")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from motionrag_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmrag_hip.so")
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()
+
+
+def test_scheduler_and_rope_tables_match_oracle():
+    from motionrag_amd.cogvideox import CogVideoXDDIMScheduler, get_3d_rotary_pos_embed
+    from oracle import cogvideox_ref
+    s = CogVideoXDDIMScheduler()
+    np.testing.assert_array_equal(s.alphas_cumprod, cogvideox_ref.ddim_alphas_cumprod())
+    for n in (50, 25, 3):
+        np.testing.assert_array_equal(s.set_timesteps(n), cogvideox_ref.ddim_timesteps(n))
+        for t in s.timesteps:
+            assert s.coeffs(int(t)) == cogvideox_ref.ddim_coeffs(cogvideox_ref.ddim_alphas_cumprod(), int(t), n)
+    cos, sin = get_3d_rotary_pos_embed(64, 13, 30, 45)
+    rc, rs = cogvideox_ref.rope_3d(64, 13, 30, 45)
+    assert cos.shape == (17550, 64) and torch.equal(cos, rc) and torch.equal(sin, rs)
+
+
+def test_cama_host_tables_match_reference_golden():
+    from motionrag_amd import cama
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sinusoid.npz"))
+    pe = cama.SinusoidPositionalEmbeddings(1024, 256)
+    np.testing.assert_array_equal(pe.pos_table[0][g["rows"]].numpy(), g["t256"])
+    m = np.load(os.path.join(ROOT, "tests", "golden", "mask.npz"))
+    at = cama.build_cama(None, None, layers=1, depth=1)
+    np.testing.assert_array_equal(at.get_mask(4, 3).numpy(), m["m4x3"])
+    np.testing.assert_array_equal(np.packbits(at.get_mask(10, 25).numpy()), m["m10x25"])
+
+
+def test_state_dict_keys_follow_the_checkpoint_layout():
+    from motionrag_amd import cama
+    from motionrag_amd.cogvideox import CogVideoXTransformer3DModel
+    from oracle import cama_ref, cogvideox_ref
+    at = cama.build_cama(None, None)
+    assert set(at.state_dict().keys()) == set(cama_ref.random_cama_sd(0, layers=4).keys())
+    cfg = cogvideox_ref.DiTConfig(num_layers=1, heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                  max_text_len=10, ip_dim=64, frames=3, height=8, width=12)
+    m = CogVideoXTransformer3DModel(num_layers=1, num_attention_heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                    max_text_seq_length=10, sample_frames=3, sample_height=8, sample_width=12).install_motion_adapters(64)
+    assert set(m.state_dict().keys()) == set(cogvideox_ref.random_dit_sd(cfg).keys())
+    assert list(m.attn_processors) == ["transformer_blocks.0.attn1.processor"]
+
+
+def test_rag_table_io_and_filter_parsing(tmp_path):
+    from motionrag_amd import rag
+    annos = [{"llm_caption": None if i == 1 else f"c{i}", "id": i, "video": f"v{i}", "start_sec": 0.0, "end_sec": 1.0} for i in range(3)]
+    rows = rag.prepare_annotations(annos)
+    assert rows[1]["text"] == "" and rows[2]["uid"] == "coin/2" and set(rows[0]) == set(rag.SCHEMA)
+    rag.add_to_db(rows, np.eye(3, 32, dtype=np.float32), text_name="t", db_path=str(tmp_path))
+    rag.add_to_db(rows[:1], np.ones((1, 32), np.float32), text_name="t", db_path=str(tmp_path))
+    assert np.load(tmp_path / "t" / "vectors.npy").shape == (4, 32)
+    assert rag._WHERE_RE.match('video != "a b/c.mp4"').group(2) == "a b/c.mp4"
+    assert rag._WHERE_RE.match("video != 'x'").group(2) == "x"
+    assert rag._WHERE_RE.match("start_sec > 3") is None

@@ -1,0 +1,326 @@
+"""GPU parity tests: every kernel of libmrag_hip.so, called through the C ABI (motionrag_amd.ops -> ctypes), against the
+CPU oracle / a plain torch fp32 reference on the same seeded inputs.
+
+Tolerances (stated per the task): bf16 outputs carry 8 significant bits, accumulation is fp32 ->
+  |got - want| <= 2e-2 * |want| + 2e-2 * scale     (scale = typical magnitude of the output)
+retrieval rows and distances are BIT-EXACT against oracle/topk_oracle.c (same fp32 fmaf chain)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close(got, want, scale=None, rtol=2e-2, atol_frac=2e-2):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), "non-finite output"
+    s = want.abs().mean().item() if scale is None else scale
+    err = (got - want).abs()
+    tol = rtol * want.abs() + atol_frac * s
+    bad = (err > tol)
+    assert not bad.any(), f"{bad.sum().item()} / {bad.numel()} outside tolerance; max err {err.max().item():.4g}, scale {s:.4g}"
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(300, 256, 128), (17, 64, 64), (1000, 520, 192), (4096, 3072, 256), (2, 1024, 512), (257, 132, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain_and_bias(hip, M, N, K):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1), bf(torch.randn(N, generator=g))
+    want = x.float() @ w.float().t()
+    got = ops.linear(x.to(DEV), w.to(DEV))
+    close(got, want, scale=want.abs().mean().item())
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV))
+    close(got, want + b.float(), scale=want.abs().mean().item())
+
+
+@pytest.mark.parametrize("epi", ["gelu_tanh", "gelu_erf", "silu", "resid", "gate_resid"])
+@pytest.mark.parametrize("M,N,K", [(500, 384, 128), (4100, 3072, 64)])
+def test_gemm_epilogues(hip, epi, M, N, K):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x, w, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1), bf(torch.randn(N, generator=g))
+    acc = x.float() @ w.float().t() + b.float()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    if epi == "gelu_tanh":
+        got, want = ops.linear(xd, wd, bd, epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(acc, approximate="tanh")
+    elif epi == "gelu_erf":
+        got, want = ops.linear(xd, wd, bd, epilogue=ops.EPI_GELU_ERF), torch.nn.functional.gelu(acc)
+    elif epi == "silu":
+        got, want = ops.linear(xd, wd, bd, epilogue=ops.EPI_SILU), torch.nn.functional.silu(acc)
+    elif epi == "resid":
+        r = bf(torch.randn(M, N, generator=g))
+        got, want = ops.linear(xd, wd, bd, epilogue=ops.EPI_RESID, resid=r.to(DEV)), r.float() + acc
+    else:
+        B, rpb, split = 2, M // 2, 37
+        M2 = B * rpb
+        r = bf(torch.randn(M2, N, generator=g))
+        gates = bf(torch.randn(B, 2, N, generator=g))                       # [:, 0] text gate, [:, 1] video gate
+        gd = gates.to(DEV)
+        rd = r.to(DEV)
+        got = ops.linear(xd[:M2], wd, bd, out=rd, epilogue=ops.EPI_GATE_RESID, resid=rd, gate0=gd[:, 0], gate1=gd[:, 1],
+                         rows_per_batch=rpb, split=split, gate_stride=gd.stride(0))        # in place, like the DiT
+        pos = torch.arange(M2) % rpb
+        gsel = torch.where((pos < split)[:, None], gates[torch.arange(M2) // rpb, 0].float(), gates[torch.arange(M2) // rpb, 1].float())
+        want = r.float() + gsel * acc[:M2]
+    close(got, want, scale=acc.abs().mean().item())
+
+
+def test_gemm_rejects_bad_arguments(hip):
+    from motionrag_amd import ops, _lib
+    x, w = torch.zeros(8, 72, dtype=torch.bfloat16, device=DEV), torch.zeros(16, 72, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.HipError, match="ENOTSUP"):
+        ops.linear(x, w)                         # K % 64 != 0
+    with pytest.raises(ops.HipOnly):
+        ops.linear(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(16, 64, dtype=torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def sdpa_ref(q, k, v, mask=None, kv_div=1):
+    """fp32 reference on [B, S, H, 64] tensors (bf16-rounded inputs)"""
+    q, k, v = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    if kv_div > 1:
+        k, v = k.repeat_interleave(kv_div, dim=0), v.repeat_interleave(kv_div, dim=0)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    o = torch.softmax(s, dim=-1) @ v
+    return o.permute(0, 2, 1, 3).reshape(q.shape[0], q.shape[2], -1)
+
+
+ATTN_SHAPES = [(2, 3, 300, 300), (1, 2, 1000, 777), (2, 2, 64, 64), (1, 1, 257, 130), (3, 12, 25, 1593), (1, 4, 33, 1), (2, 1, 600, 64)]
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv", ATTN_SHAPES)
+def test_attention_matches_reference(hip, B, H, Sq, Skv):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Sq)
+    q, k, v = (bf(torch.randn(B if i == 0 else B, Sq if i == 0 else Skv, H, 64, generator=g)) for i in range(3))
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    close(got, sdpa_ref(q, k, v), scale=0.3)
+
+
+def test_attention_fused_qkv_views_and_residual(hip):
+    """strided views of a fused QKV buffer + the motion-injection update out = resid + scale * attn (kv batch repeat)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, S, H = 4, 333, 3
+    qkv = bf(torch.randn(B, S, 3, H, 64, generator=g))
+    d = qkv.to(DEV)
+    got = ops.attention(d[:, :, 0], d[:, :, 1], d[:, :, 2])
+    close(got, sdpa_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]), scale=0.3)
+    kv = bf(torch.randn(2, 25, 2, H, 64, generator=g))                   # B' = 2 motion-token sets, r = 2
+    resid = bf(torch.randn(B, S, H * 64, generator=g))
+    kd, rd = kv.to(DEV), resid.to(DEV)
+    out = ops.attention(d[:, :, 0], kd[:, :, 0], kd[:, :, 1], out=rd, resid=rd, kv_batch_div=2, out_scale=0.75)   # in place
+    want = resid.float() + 0.75 * sdpa_ref(qkv[:, :, 0], kv[:, :, 0], kv[:, :, 1], kv_div=2)
+    close(out, want, scale=1.0)
+
+
+def test_attention_block_causal_mask(hip):
+    from motionrag_amd import ops
+    from oracle import cama_ref
+    g = torch.Generator().manual_seed(6)
+    B, H, n, l = 2, 4, 10, 25
+    q, k, v = (bf(torch.randn(B, n * l, H, 64, generator=g)) for _ in range(3))
+    mask = cama_ref.block_causal_mask(n, l)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), mask=mask.to(DEV))
+    close(got, sdpa_ref(q, k, v, mask=mask), scale=0.3)
+
+
+def test_attention_deferred_rescale_branch(hip):
+    """cdna guide rule 26: force the running max to jump far past the deferred-rescale threshold at a late tile (and
+    again later), and make the first tile strongly negative, so every branch of the online softmax is exercised."""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, H, Sq, Skv = 1, 2, 96, 640
+    q, k, v = (torch.randn(B, S, H, 64, generator=g) for S in (Sq, Skv, Skv))
+    k[:, :64] -= 3.0 * q[:, :1].mean(dim=1, keepdim=True)                 # first tile: low scores
+    k[:, 200] = 6.0 * q[:, 5] / q[:, 5].norm(dim=-1, keepdim=True)        # row 5's max jumps at key 200 (tile 3)
+    k[:, 450] = 9.0 * q[:, 40] / q[:, 40].norm(dim=-1, keepdim=True)      # row 40 jumps at key 450 (tile 7)
+    k[:, 451] = 12.0 * q[:, 5] / q[:, 5].norm(dim=-1, keepdim=True)       # row 5 jumps again
+    q, k, v = bf(q), bf(k), bf(v)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    close(got, sdpa_ref(q, k, v), scale=0.3)
+
+
+def test_attention_large_sequence_properties(hip):
+    """BASELINE-size sequence (S = 17 776, the CogVideoX joint length), checked through size-independent properties:
+    (1) with V = ones the output is exactly 1 (softmax rows sum to one); (2) permuting the keys/values does not change
+    the output; (3) a random subset of query rows equals the fp32 reference."""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, H, S = 1, 2, 17776
+    q, k, v = (bf(torch.randn(B, S, H, 64, generator=g)) for _ in range(3))
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ones = ops.attention(qd, kd, torch.ones_like(vd))
+    assert (ones.float() - 1.0).abs().max().item() < 1e-2
+    out = ops.attention(qd, kd, vd)
+    perm = torch.randperm(S, generator=g).to(DEV)
+    out_p = ops.attention(qd, kd[:, perm].contiguous(), vd[:, perm].contiguous())
+    assert (out.float() - out_p.float()).abs().max().item() < 2e-2
+    rows = torch.randint(0, S, (64,), generator=g)
+    want = sdpa_ref(q[:, rows], k, v)
+    close(out[:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104)])
+def test_layernorm(hip, rows, D):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x, w, b = bf(torch.randn(rows, D, generator=g) * 2 + 0.5), bf(1 + 0.1 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
+    want = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    close(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5), want, scale=1.0)
+    close(ops.layernorm(x.to(DEV), None, None, 1e-6), torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6), scale=1.0)
+
+
+def test_layernorm_adaln_modulation_and_batched_output(hip):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, S, D, split = 2, 50, 256, 7
+    x = bf(torch.randn(B, S, D, generator=g))
+    w, b = bf(1 + 0.1 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
+    mod = bf(0.3 * torch.randn(B, 4, D, generator=g))                      # enc_shift, enc_scale, shift, scale
+    md = mod.to(DEV)
+    got = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, shift0=md[:, 0], scale0=md[:, 1], shift1=md[:, 2], scale1=md[:, 3],
+                        rows_per_batch=S, split=split, mod_stride=md.stride(0))
+    ln = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    want = ln.clone()
+    want[:, :split] = ln[:, :split] * (1 + mod[:, 1].float()[:, None]) + mod[:, 0].float()[:, None]
+    want[:, split:] = ln[:, split:] * (1 + mod[:, 3].float()[:, None]) + mod[:, 2].float()[:, None]
+    close(got, want, scale=1.0)
+    buf = torch.zeros(B, S + 9, D, dtype=torch.bfloat16, device=DEV)       # write into a slice of a concat buffer
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_batched=buf[:, 9:])
+    close(buf[:, 9:], ln, scale=1.0)
+    assert buf[:, :9].abs().max().item() == 0
+
+
+def test_qknorm_rope(hip):
+    from motionrag_amd import ops
+    from oracle import cogvideox_ref, cama_ref
+    g = torch.Generator().manual_seed(4)
+    B, H, text_len, (t, h, w) = 2, 3, 5, (2, 3, 4)
+    S = text_len + t * h * w
+    qkv = bf(torch.randn(B, S, 3, H, 64, generator=g))
+    qg, qb, kg, kb = (bf(1 + 0.2 * torch.randn(64, generator=g)) for _ in range(4))
+    cos, sin = cogvideox_ref.rope_3d(64, t, h, w)
+    got = ops.qknorm_rope_(qkv.reshape(B, S, 3 * H * 64).to(DEV).clone(), H, qg.to(DEV), qb.to(DEV), kg.to(DEV), kb.to(DEV), cos.to(DEV), sin.to(DEV),
+                           text_len, eps=1e-6, q_premul=0.37).view(B, S, 3, H, 64)
+    for which, (gm, bt, mul) in enumerate(((qg, qb, 0.37), (kg, kb, 1.0))):
+        x = cama_ref.layer_norm(qkv[:, :, which].float(), gm.float(), bt.float(), 1e-6).permute(0, 2, 1, 3)     # [B, H, S, 64]
+        x = x.clone()
+        x[:, :, text_len:] = cogvideox_ref.apply_rotary_emb(x[:, :, text_len:], cos, sin)
+        close(got[:, :, which], (x * mul).permute(0, 2, 1, 3), scale=1.0 * mul)
+    assert torch.equal(got[:, :, 2].cpu(), qkv[:, :, 2])                    # V untouched
+
+
+# ---------------------------------------------------------------------------------------------- pointwise
+def test_pointwise_kernels(hip):
+    from motionrag_amd import ops
+    from oracle import cogvideox_ref
+    g = torch.Generator().manual_seed(9)
+    t = torch.tensor([999.0, 19.0, 500.0])
+    close(ops.timestep_embedding(t.to(DEV), 256), cogvideox_ref.timestep_embedding(t, 256), scale=0.7)
+    x = bf(torch.randn(1003, generator=g) * 3)
+    close(ops.silu(x.to(DEV)), torch.nn.functional.silu(x.float()), scale=1.0)
+    a, b = bf(torch.randn(77, 40, generator=g)), bf(torch.randn(77, 40, generator=g))
+    close(ops.add(a.to(DEV), b.to(DEV)), a.float() + b.float(), scale=1.0)
+    xx, tab = bf(torch.randn(3, 25, 64, generator=g)), bf(torch.randn(25, 64, generator=g))
+    close(ops.add_rows(xx.to(DEV), tab.to(DEV)), xx.float() + tab.float()[None], scale=1.0)
+
+
+def test_patchify_unpatchify_exact(hip):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(10)
+    Bl, F, C, H, W = 1, 3, 4, 6, 10
+    lat, img = bf(torch.randn(Bl, F, C, H, W, generator=g)), bf(torch.randn(Bl, F, C, H, W, generator=g))
+    rows = ops.patchify(lat.to(DEV), img.to(DEV), 2).cpu()
+    x = torch.cat([lat, img], dim=2).repeat(2, 1, 1, 1, 1).float()          # cat([latents]*2) ; cat on channels
+    want = torch.nn.functional.unfold(x.reshape(2 * F, 2 * C, H, W), kernel_size=2, stride=2)      # [BF, C*4, L]
+    want = want.transpose(1, 2).reshape(-1, 2 * C * 4)
+    assert torch.equal(rows.float(), want)
+    back = ops.unpatchify(rows.to(DEV).contiguous(), 2, F, 2 * C, H, W).cpu()
+    assert torch.equal(back.float(), x)
+
+
+def test_cfg_ddim_step(hip):
+    from motionrag_amd import ops
+    from oracle import cogvideox_ref
+    g = torch.Generator().manual_seed(12)
+    lat = bf(torch.randn(1, 3, 4, 6, 8, generator=g))
+    v = bf(torch.randn(2, 3, 4, 6, 8, generator=g))
+    ac = cogvideox_ref.ddim_alphas_cumprod()
+    for t in (999, 499, 19):
+        co = cogvideox_ref.ddim_coeffs(ac, t, 50)
+        got = ops.cfg_ddim_step_(v.to(DEV), lat.to(DEV).clone(), 6.0, *co)
+        close(got, cogvideox_ref.cfg_ddim_step(v, lat, 6.0, co), scale=1.0)
+
+
+# ---------------------------------------------------------------------------------------------- retrieval
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("N,Q,D,k", [(1000, 5, 64, 12), (300, 33, 768, 12), (5000, 16, 128, 64), (70, 3, 32, 12)])
+def test_topk_bit_exact(hip, metric, N, Q, D, k):
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    rng = np.random.default_rng(N + Q)
+    db, q = _unit(rng, N, D), _unit(rng, Q, D)
+    group = (np.arange(N) // 2).astype(np.int32)
+    excl = group[rng.integers(0, N, Q)].astype(np.int32)
+    want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32chain")
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
+                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
+    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))      # same fmaf chain -> same bits
+    rows2, _ = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric)
+    np.testing.assert_array_equal(rows2.cpu().numpy(), topk_ref.topk(db, q, k, metric)[0])
+
+
+def test_topk_ties_and_short_results(hip):
+    from motionrag_amd import ops
+    db = np.zeros((40, 32), dtype=np.float32)
+    db[3, 0] = 1.0
+    q = np.zeros((2, 32), dtype=np.float32)
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 4)
+    assert rows.cpu().tolist() == [[0, 1, 2, 4]] * 2 and dist.cpu().tolist() == [[0.0] * 4] * 2
+    group = torch.zeros(40, dtype=torch.int32); group[38:] = 1
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 4, group=group.to(DEV),
+                          exclude=torch.tensor([0, 5], dtype=torch.int32, device=DEV))
+    assert rows.cpu().tolist() == [[38, 39, -1, -1], [0, 1, 2, 4]]
+    assert torch.isinf(dist[0, 2:]).all()
+
+
+def test_topk_baseline_size(hip):
+    """BASELINE config #1 size: 10 000 x 768 database, 256 queries, k = 12 -- equal to the oracle, sorted, filtered."""
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    rng = np.random.default_rng(0)
+    db, q = _unit(rng, 10000, 768), _unit(rng, 256, 768)
+    group = np.arange(10000, dtype=np.int32)
+    excl = rng.integers(0, 10000, 256).astype(np.int32)
+    q[:64] = db[excl[:64]] + 0.01 * q[:64]                                   # queries whose own row must be filtered out
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
+                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
+    rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")
+    np.testing.assert_array_equal(rows, want_r)
+    np.testing.assert_array_equal(dist, want_d.astype(np.float32))
+    assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])

@@ -1,0 +1,208 @@
+"""GPU parity tests of the host-side mirrors (CAMA, attention processors, DiT + DDIM loop, RAGDatabase) against the
+oracle and the golden vectors generated from the reference's own code.  Everything runs through libmrag_hip.so.
+
+Tolerance: activations are bf16 end to end (reference `precision: bf16-true`), the oracle is fp32 ->
+  |got - want| <= 3e-2 * |want| + 3e-2 * mean|want|  for multi-layer paths."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_kernels import close
+from test_oracle_golden import cama_fixture_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _to_dev(sd):
+    return {k: v.to(DEV, torch.bfloat16) for k, v in sd.items()}
+
+
+def _bf_round(sd):
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def test_resampler_against_reference_golden(hip, golden_dir):
+    from motionrag_amd.cama import Resampler
+    from oracle import cama_ref
+    g = np.load(os.path.join(golden_dir, "resampler.npz"))
+    sd = cama_ref.random_resampler_sd(torch.Generator().manual_seed(int(g["weight_seed"])), embedding_dim=768)
+    x = torch.randn(*g["input_shape"].tolist(), generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    m = Resampler(dim=1024, depth=4, dim_head=64, heads=12, num_queries=25, embedding_dim=768, output_dim=1024)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV, torch.bfloat16)
+    y = m(x.to(DEV, torch.bfloat16))
+    close(y, torch.from_numpy(g["out"]), rtol=3e-2, atol_frac=3e-2)         # vs the REFERENCE's output
+    close(y, cama_ref.resampler(_bf_round(sd), x.to(torch.bfloat16).float(), 12, 4), rtol=3e-2, atol_frac=3e-2)
+
+
+def test_cama_predict_against_reference_golden(hip, golden_dir):
+    from motionrag_amd import cama
+    from oracle import cama_ref
+    g = np.load(os.path.join(golden_dir, "cama_predict.npz"))
+    sd = cama_ref.random_cama_sd(seed=int(g["weight_seed"]))
+    inp = cama_fixture_inputs(g)
+
+    class Enc(torch.nn.Module):                                              # frozen third-party encoders: feature stubs
+        def __init__(self, stub):
+            super().__init__()
+            self.stub = stub
+
+        def forward(self, x):
+            return self.stub(x.float().cpu()).to(DEV, torch.bfloat16)
+
+    model = cama.build_cama(Enc(inp["vis"]), Enc(inp["con"]))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)            # checkpoint key layout
+    model = model.to(DEV, torch.bfloat16)
+    batch = {"ref_videos": inp["ref_videos"].to(DEV, torch.bfloat16), "video": inp["video"].to(DEV, torch.bfloat16)}
+    out = model.predict(batch, do_classifier_free_guidance=True)
+    assert out.shape == (4, 25, 1024)
+    close(out, torch.from_numpy(g["predict"]), rtol=4e-2, atol_frac=4e-2)   # vs the REFERENCE's predict()
+    assert model.vision_proj.cross_attention_dim == 1024                     # read by cogvideox/module.py:260
+    ev = model.encode_vision(torch.zeros_like(batch["ref_videos"][:, 0:1]))
+    close(ev[:, 0], out[:2], rtol=1e-6, atol_frac=1e-6)                      # uncond half == encode_vision(zeros)[:, 0]
+
+
+def test_cogvideox_processor_dropin(hip):
+    """APAdapterCogVideoXAttnProcessor2_0 called through the diffusers processor protocol vs the oracle restatement
+    of attn_processor.py:176-283 (incl. `((cos, sin), ip)` smuggled through image_rotary_emb and B % B' repeat)."""
+    from motionrag_amd.attn_processor import APAdapterCogVideoXAttnProcessor2_0, Attention
+    from oracle import cogvideox_ref
+    g = torch.Generator().manual_seed(21)
+    D, H, ipd, text_len, (t, h, w) = 128, 2, 96, 6, (2, 3, 5)
+    attn = Attention(D, heads=H, dim_head=64, bias=True, out_bias=True, qk_norm="layer_norm", eps=1e-6)
+    proc = APAdapterCogVideoXAttnProcessor2_0(D, ipd)
+    attn.set_processor(proc)
+    for p in attn.parameters():
+        torch.nn.init.normal_(p, std=0.15, generator=g)
+    for n in ("norm_q", "norm_k"):
+        getattr(attn, n).weight.data.add_(1.0)
+    attn = attn.to(DEV, torch.bfloat16)
+    sd = {k: v.float().cpu() for k, v in attn.state_dict().items()}
+    assert {"processor.to_q_ip.0.weight", "processor.to_k_ip.0.weight", "processor.to_v_ip.0.weight"} <= set(sd)
+    hidden = torch.randn(4, t * h * w, D, generator=g).to(torch.bfloat16)
+    enc = torch.randn(4, text_len, D, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, ipd, generator=g).to(torch.bfloat16)
+    cos, sin = cogvideox_ref.rope_3d(64, t, h, w)
+    got_h, got_e = attn(hidden.to(DEV), enc.to(DEV), image_rotary_emb=((cos.to(DEV), sin.to(DEV)), ip.to(DEV)))
+    want_h, want_e = cogvideox_ref.adapter_attn_processor(
+        {k: v for k, v in sd.items() if not k.startswith("processor.")}, {k[len("processor."):]: v for k, v in sd.items() if k.startswith("processor.")},
+        hidden.float(), enc.float(), (cos, sin), ip.float(), H, 1.0)
+    close(got_h, want_h, rtol=3e-2, atol_frac=3e-2)
+    close(got_e, want_e, rtol=3e-2, atol_frac=3e-2)
+    # explicit action_hidden_states + plain (cos, sin), and scale 0 == no adapter
+    got_h2, _ = attn(hidden.to(DEV), enc.to(DEV), image_rotary_emb=(cos.to(DEV), sin.to(DEV)), action_hidden_states=ip.to(DEV))
+    close(got_h2, got_h, rtol=1e-6, atol_frac=1e-6)
+    with pytest.raises(AssertionError, match="action_hidden_states must be provided"):
+        attn(hidden.to(DEV), enc.to(DEV), image_rotary_emb=(cos.to(DEV), sin.to(DEV)))
+
+
+def test_svd_processor_dropin(hip):
+    """APAdapterAttnProcessor2_0 (SVD attn2 sites): tuple `(image_emb, action_emb)` in encoder_hidden_states."""
+    from motionrag_amd.attn_processor import APAdapterAttnProcessor2_0, Attention
+    from oracle import dynamicrafter_ref
+    g = torch.Generator().manual_seed(22)
+    C, H, cd = 320, 5, 1024
+    attn = Attention(C, cross_attention_dim=cd, heads=H, dim_head=64, bias=False, out_bias=True)
+    proc = APAdapterAttnProcessor2_0(C, cd)
+    attn.set_processor(proc)
+    for p in attn.parameters():
+        torch.nn.init.normal_(p, std=0.05, generator=g)
+    attn = attn.to(DEV, torch.bfloat16)
+    sd = {k: v.float().cpu() for k, v in attn.state_dict().items()}
+    hidden = torch.randn(6, 144, C, generator=g).to(torch.bfloat16)           # [2F, HW, C]
+    img = torch.randn(6, 1, cd, generator=g).to(torch.bfloat16)               # 1-token CLIP image embedding per frame
+    act = torch.randn(2, 25, cd, generator=g).to(torch.bfloat16)              # motion tokens, repeated over frames (r = 3)
+    got = attn(hidden.to(DEV), (img.to(DEV), act.to(DEV)))
+    dc = {"to_q.weight": sd["to_q.weight"], "to_k.weight": sd["to_k.weight"], "to_v.weight": sd["to_v.weight"],
+          "to_q_a.weight": sd["processor.to_q_ip.0.weight"], "to_k_a.weight": sd["processor.to_k_ip.0.weight"],
+          "to_v_a.weight": sd["processor.to_v_ip.0.weight"], "to_out.0.weight": sd["to_out.0.weight"], "to_out.0.bias": sd["to_out.0.bias"]}
+    want = dynamicrafter_ref.cross_attention(dc, hidden.float(), {"prompt": img.float(), "action": act.float().repeat_interleave(3, dim=0)}, heads=H)
+    close(got, want, rtol=3e-2, atol_frac=3e-2)
+
+
+def _small_dit(seed=31, layers=2):
+    from motionrag_amd.cogvideox import CogVideoXTransformer3DModel
+    from oracle import cogvideox_ref
+    cfg = cogvideox_ref.DiTConfig(num_layers=layers, heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                  max_text_len=10, ip_dim=64, frames=3, height=8, width=12)
+    sd = cogvideox_ref.random_dit_sd(cfg, seed=seed, std=0.08)
+    model = CogVideoXTransformer3DModel(num_layers=layers, num_attention_heads=2, in_channels=16, out_channels=8, time_embed_dim=64,
+                                        text_embed_dim=64, max_text_seq_length=10, sample_frames=3, sample_height=8, sample_width=12)
+    model.install_motion_adapters(64)
+    model.load_state_dict(sd, strict=True)                                    # diffusers / MotionRAG checkpoint key layout
+    return cfg, sd, model.to(DEV, torch.bfloat16)
+
+
+def test_dit_forward_matches_oracle(hip):
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit()
+    g = torch.Generator().manual_seed(32)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(torch.bfloat16)
+    t = torch.tensor([481.0, 481.0])
+    cos, sin = cogvideox_ref.rope_3d(64, 3, 4, 6)
+    got = model(lat.to(DEV), text.to(DEV), t.to(DEV), image_rotary_emb=((cos.to(DEV), sin.to(DEV)), ip.to(DEV)), image_latents=img.to(DEV), batch=2)
+    x = torch.cat([torch.cat([lat] * 2), torch.cat([img] * 2)], dim=2).float()       # pipeline: cat([latents]*2), cat on channels
+    want = cogvideox_ref.dit_forward(_bf_round(sd), cfg, x, text.float(), t, (cos, sin), ip.float())
+    assert got.shape == want.shape == (2, 3, 8, 8, 12)
+    close(got, want, rtol=4e-2, atol_frac=4e-2)
+
+
+def test_denoise_loop_matches_oracle(hip):
+    """3 DDIM steps of the motion-injected loop (CFG, v-prediction) with pre-generated CPU noise."""
+    from motionrag_amd.cogvideox import CogVideoXDDIMScheduler, CogVideoXImageToVideoCTPipeline
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit(seed=33)
+    g = torch.Generator().manual_seed(34)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(torch.bfloat16)
+    pipe = CogVideoXImageToVideoCTPipeline(model, CogVideoXDDIMScheduler())
+    steps, guidance = 3, 6.0
+    got = pipe.denoise(lat.to(DEV).clone(), img.to(DEV), text.to(DEV), ip.to(DEV), num_inference_steps=steps, guidance_scale=guidance)
+    ac = cogvideox_ref.ddim_alphas_cumprod()
+    np.testing.assert_allclose(pipe.scheduler.alphas_cumprod, ac, rtol=0, atol=0)
+    cos, sin = cogvideox_ref.rope_3d(64, 3, 4, 6)
+    x = lat.float()
+    sdr = _bf_round(sd)
+    for t in cogvideox_ref.ddim_timesteps(steps):
+        inp = torch.cat([torch.cat([x] * 2), torch.cat([img.float()] * 2)], dim=2)
+        v = cogvideox_ref.dit_forward(sdr, cfg, inp, text.float(), torch.full((2,), float(t)), (cos, sin), ip.float())
+        x = cogvideox_ref.cfg_ddim_step(v, x, guidance, cogvideox_ref.ddim_coeffs(ac, int(t), steps))
+        x = x.to(torch.bfloat16).float()                                    # the pipeline keeps latents in bf16 between steps
+    close(got, x, rtol=6e-2, atol_frac=6e-2)
+
+
+def test_rag_database_text_search(hip, tmp_path):
+    """RAGDatabase.text_search (rag.py:63-80) over a table built with add_to_db (build_rag_database.py:16-52)."""
+    from motionrag_amd import rag
+    from oracle import topk_ref
+    rng = np.random.default_rng(3)
+    N, D = 1500, 768
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    annos = [{"motion_caption": f"clip {i}", "id": i, "video": f"v{i // 2}.mp4", "start_sec": float(i), "end_sec": float(i + 2)} for i in range(N)]
+    rows = rag.prepare_annotations(annos, text_name="motion_caption", dataset_name="openvid")
+    rag.add_to_db(rows[:1000], emb[:1000], text_name="motion_caption", db_path=str(tmp_path / "openvid.db"))
+    rag.add_to_db(rows[1000:], emb[1000:], text_name="motion_caption", db_path=str(tmp_path / "openvid.db"))     # chunked append
+    db = rag.RAGDatabase(str(tmp_path / "openvid.db"), "motion_caption", device="cuda")
+    assert len(db) == N
+    q = emb[10] + 0.01 * rng.standard_normal(D).astype(np.float32)
+    res = db.text_search(text=q, top_k=12, where='video != "v5.mp4"', select=["video", "start_sec", "end_sec"])
+    group = np.array([i // 2 for i in range(N)], dtype=np.int32)
+    want_r, want_d = topk_ref.topk(emb, q[None], 12, "l2", group, np.array([5], np.int32))
+    assert [r["start_sec"] for r in res] == [float(i) for i in want_r[0]]
+    assert set(res[0].keys()) == {"video", "start_sec", "end_sec", "_distance"}
+    np.testing.assert_array_equal(np.array([r["_distance"] for r in res], dtype=np.float32), want_d[0].astype(np.float32))
+    assert all(r["video"] != "v5.mp4" for r in res)
+    res2 = db.text_search(text=torch.from_numpy(q), top_k=3)
+    assert res2[0]["id"] == 10 and res2[0]["video"] == "v5.mp4"
+    batch = db.text_search_batch(emb[:40], top_k=12, where=[f'video != "v{i // 2}.mp4"' for i in range(40)], select=["video"])
+    assert len(batch) == 40 and all(len(b) == 12 for b in batch) and all(b[0]["video"] != f"v{i // 2}.mp4" for i, b in enumerate(batch))
+    with pytest.raises(NotImplementedError):
+        db.text_search(text=q, where="start_sec > 3")

@@ -116,6 +116,9 @@ def lib() -> ctypes.CDLL:
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m motionrag_amd._lib` (hipcc, gfx950). "
             "motionrag_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so: it must be the HIP runtime of the process (it owns the streams and the
+    # device memory handed to the kernels), so make sure it is loaded BEFORE our library resolves the same soname.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.mrag_abi_version.restype = c_int32
     L.mrag_target_arch.restype = c_char_p

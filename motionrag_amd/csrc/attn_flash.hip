@@ -300,8 +300,8 @@ int launch_attn(hipStream_t s, AttnP p) {
   p.n_qtiles = (p.Sq + NW * 32 - 1) / (NW * 32);
   const dim3 grid(p.n_qtiles * p.B * p.H), block(NW * 64);
   const size_t lds = 2 * STAGE;
-  if (p.mask) hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<NW, false>), grid, block, lds, s, p);
+  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true>), grid, block, lds, s, p);
+  else MRAG_LAUNCH((attn_fwd_kernel<NW, false>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -57,3 +57,11 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     hipError_t e__ = hipGetLastError();             \
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
+
+// hipGetLastError() is per-thread and sticky across unrelated runtime calls (torch leaves benign errors behind):
+// clear it right before our launch so that MRAG_LAUNCH_CHECK reports only this launch's status.
+#define MRAG_LAUNCH(...)            \
+  do {                              \
+    (void)hipGetLastError();        \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)

@@ -165,7 +165,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
     auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E>;                                                    \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                \
-    hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                   \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                   \
     break;                                                                                             \
   }
   switch (epi) {

@@ -189,9 +189,9 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   if (p.y_rpb < 0 || (p.y_rpb > 0 && p.y_bstride % 8 != 0)) return MRAG_EINVAL;
   const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (a->D <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, p);
-  else if (a->D <= 4096) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, p);
+  if (a->D <= 1024) MRAG_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, p);
+  else if (a->D <= 4096) MRAG_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, p);
+  else MRAG_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -210,7 +210,7 @@ extern "C" int mrag_qknorm_rope_bf16(void* stream, const mrag_qknorm_rope_args* 
   const long long units = (long long)a->B * a->S * 2 * ((a->H + 7) / 8);
   long long blocks = (units + 3) / 4;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  MRAG_LAUNCH(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

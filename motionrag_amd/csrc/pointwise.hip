@@ -146,21 +146,21 @@ __global__ void cfg_ddim_kernel(const bf16_t* vp, bf16_t* x, long long n8, long 
 extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
   if (!t || !out || B <= 0 || dim <= 0 || (dim & 1)) return MRAG_EINVAL;
   const int total = B * (dim / 2);
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, B, dim);
+  MRAG_LAUNCH(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, B, dim);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
 
 extern "C" int mrag_silu_bf16(void* stream, const void* x, void* y, int64_t n) {
   if (!x || !y || n <= 0 || (((uintptr_t)x | (uintptr_t)y) & 15)) return MRAG_EINVAL;
-  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)(n / 8), (long long)n);
+  MRAG_LAUNCH(silu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)(n / 8), (long long)n);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
 
 extern "C" int mrag_add_bf16(void* stream, const void* a, const void* b, void* y, int64_t n) {
   if (!a || !b || !y || n <= 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15)) return MRAG_EINVAL;
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long long)(n / 8), (long long)n);
+  MRAG_LAUNCH(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, (long long)(n / 8), (long long)n);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -168,7 +168,7 @@ extern "C" int mrag_add_bf16(void* stream, const void* a, const void* b, void* y
 extern "C" int mrag_add_rows_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t period) {
   if (!x || !table || !y || rows <= 0 || D <= 0 || period <= 0 || D % 8 != 0) return MRAG_EINVAL;
   if (((uintptr_t)x | (uintptr_t)table | (uintptr_t)y) & 15) return MRAG_EINVAL;
-  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * D / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)table, (bf16_t*)y, (long long)rows, (long long)(D / 8), (long long)period);
+  MRAG_LAUNCH(add_rows_kernel, dim3(grid_for(rows * D / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)table, (bf16_t*)y, (long long)rows, (long long)(D / 8), (long long)period);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -180,7 +180,7 @@ extern "C" int mrag_patchify_bf16(void* stream, const void* src0, const void* sr
   if (((uintptr_t)src0 | (uintptr_t)src1) & 3) return MRAG_EINVAL;
   if ((uintptr_t)dst & 7) return MRAG_EINVAL;
   const long long total = (long long)B * F * (H / 2) * (W / 2) * (C0 + C1);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, (const bf16_t*)src1,
+  MRAG_LAUNCH(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, (const bf16_t*)src1,
                      (bf16_t*)dst, B, Bl, F, C0, C1, H, W);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
@@ -190,7 +190,7 @@ extern "C" int mrag_unpatchify_bf16(void* stream, const void* src, void* dst, in
   if (!src || !dst || B <= 0 || F <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return MRAG_EINVAL;
   if (((uintptr_t)src & 7) || ((uintptr_t)dst & 3)) return MRAG_EINVAL;
   const long long total = (long long)B * F * C * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, F, C, H, W);
+  MRAG_LAUNCH(unpatchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, F, C, H, W);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -199,7 +199,7 @@ extern "C" int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* l
                                        float sqrt_beta_t, float a_t, float b_t) {
   if (!v_pred || !latents || n <= 0 || n % 8 != 0) return MRAG_EINVAL;
   if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
-  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents,
+  MRAG_LAUNCH(cfg_ddim_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents,
                      (long long)(n / 8), (long long)n, guidance, sqrt_alpha_t, sqrt_beta_t, a_t, b_t);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;

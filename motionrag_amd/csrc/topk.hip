@@ -230,9 +230,9 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   auto kfn = metric == 0 ? topk_scan_kernel<0> : topk_scan_kernel<1>;
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kfn, dim3(p.slices, (n_queries + QT - 1) / QT), dim3(256), lds, s, p);
+  MRAG_LAUNCH(kfn, dim3(p.slices, (n_queries + QT - 1) / QT), dim3(256), lds, s, p);
   MRAG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(n_queries), dim3(256), 0, s, p);
+  MRAG_LAUNCH(topk_merge_kernel, dim3(n_queries), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -18,6 +18,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmrag_hip.so")
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "norm.hip", "pointwise.hip", "topk.hip"]
 ABI_VERSION = 1
+# per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
+EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"]}
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -90,8 +92,8 @@ def build(verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c",
-               os.path.join(_CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + EXTRA_FLAGS.get(src, []) + [
+            "-c", os.path.join(_CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

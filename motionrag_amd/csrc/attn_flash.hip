@@ -2,7 +2,7 @@
 //
 //   O[b, q, h, :] = resid + out_scale * softmax(Q K^T * scale  [masked])  V
 //
-// One kernel serves every F.scaled_dot_product_attention call site of the MotionRAG hot path
+// One kernel family serves every F.scaled_dot_product_attention call site of the MotionRAG hot path
 // (include/mrag_hip.h): the 17 776-token CogVideoX joint attention, the 25-key motion
 // ("ip") cross-attention with its fused `hidden + scale * ip` update, the Perceiver resampler
 // (25 queries x 1 593 keys) and the block-causal CAMA encoder (bool mask).
@@ -13,17 +13,21 @@
 //     accumulator registers are already the B operand of the PV product (no LDS round trip for P);
 //   * each wave owns 32 query rows (Q fragments live in registers, pre-multiplied by
 //     scale*log2 e so the softmax is a bare v_exp_f32); a workgroup is NW waves;
-//   * K/V tiles of 64 keys are staged by 16-byte LDS-DMA (global_load_lds) into two LDS stages;
-//     K is XOR-swizzled on the source side for conflict-free ds_read_b128, V keeps row-major
-//     [key][d] with its 64-byte halves swapped on odd key pairs and is consumed through
+//   * K/V tiles of 64 keys are staged by 16-byte LDS-DMA (global_load_lds) into two K stages and two
+//     V stages; K is XOR-swizzled on the source side for conflict-free ds_read_b128, V keeps
+//     row-major [key][d] with its 64-byte halves swapped on odd key pairs and is consumed through
 //     ds_read_b64_tr_b16 (hardware transpose) as the A operand of O^T = V^T . P^T;
+//   * PIPE variant (long sequences): software-pipelined inside the wave -- the QK^T MFMAs of tile
+//     t+1 are issued before the softmax VALU work of tile t, so the matrix pipe and the vector pipe
+//     of a SIMD are busy together instead of taking turns behind the per-tile barrier;
 //   * the running max is carried as the MFMA's C operand (S' = K.Q^T - m comes out of the chain,
 //     no per-score subtract) and only moved when a tile raises it by more than THR (deferred
-//     rescale): the rare path rescales O, l and the pending S' together;
+//     rescale): the rare path rescales O, l, the pending S' and the prefetched S' together;
 //   * grid = q-tiles x (b, h) with an XCD-aware order: all q-tiles of one (b, h) run on one XCD,
 //     so its K/V (4.5 MB at S = 17 776) streams from that XCD's L2.
 #include "common.h"
 #include "../../include/mrag_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,11 +38,11 @@ struct AttnP {
   float qscale, out_scale;
 };
 
-constexpr float kThr = 5.0f;  // deferred-rescale threshold in log2 units (P <= 32)
-constexpr int KVB = 64;       // keys per tile
-constexpr int STAGE = 2 * KVB * 128;  // K tile + V tile, bytes
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr float kThr = 5.0f;          // deferred-rescale threshold in log2 units (P <= 32)
+constexpr int KVB = 64;               // keys per tile
+constexpr int TILE_BYTES = KVB * 128; // one K (or V) tile
+constexpr int NS = 5;                 // LDS ring stages per operand (DMA runs D = NS-2 tiles ahead)
+constexpr int V_BASE = NS * TILE_BYTES;  // LDS: K stages 0..NS-1, then V stages 0..NS-1
 
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float s) {
   u32x4 r;
@@ -51,18 +55,192 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float s) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max per operand
 __device__ __forceinline__ float max3_asm(float a, float b, float c) {
   float d;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 
-template <int NW, bool HAS_MASK>
+__device__ __forceinline__ float half_swap_max(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max3_asm(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+}
+
+struct Lane {
+  int hh, k_row_off, k_swz, v_lane_off, v_half0, v_half1;
+};
+
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// S'^T = K . Q^T + C for the two 32-key blocks of one tile (8 MFMAs); C = -running max.
+// All 8 K fragments are requested in one asm statement (hipcc otherwise serialises read -> wait -> MFMA pairs and
+// exposes the LDS latency four times per tile); `between()` runs while they are in flight (the DMA issue of a later
+// tile), then one wait statement that names every destination releases them to the MFMAs.
+template <typename Between = NoHook>
+__device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const bf16x8 (&qf)[4], const f32x16& negm, f32x16& s0, f32x16& s1,
+                                        Between between = Between()) {
+  u32x4 k0f[4], k1f[4];
+  const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
+  const unsigned a0 = base + ((0 + ln.hh) ^ ln.k_swz) * 16, a1 = base + ((2 + ln.hh) ^ ln.k_swz) * 16;
+  const unsigned a2 = base + ((4 + ln.hh) ^ ln.k_swz) * 16, a3 = base + ((6 + ln.hh) ^ ln.k_swz) * 16;
+  asm volatile(
+      "ds_read_b128 %0, %8\n\t"
+      "ds_read_b128 %4, %8 offset:4096\n\t"
+      "ds_read_b128 %1, %9\n\t"
+      "ds_read_b128 %5, %9 offset:4096\n\t"
+      "ds_read_b128 %2, %10\n\t"
+      "ds_read_b128 %6, %10 offset:4096\n\t"
+      "ds_read_b128 %3, %11\n\t"
+      "ds_read_b128 %7, %11 offset:4096"
+      : "=&v"(k0f[0]), "=&v"(k0f[1]), "=&v"(k0f[2]), "=&v"(k0f[3]), "=&v"(k1f[0]), "=&v"(k1f[1]), "=&v"(k1f[2]), "=&v"(k1f[3])
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+  between();
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(k0f[0]), "+v"(k0f[1]), "+v"(k0f[2]), "+v"(k0f[3]), "+v"(k1f[0]), "+v"(k1f[1]), "+v"(k1f[2]), "+v"(k1f[3])
+               :
+               : "memory");
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0f[0]), qf[0], negm, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1f[0]), qf[0], negm, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) {
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0f[ks]), qf[ks], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1f[ks]), qf[ks], s1, 0, 0, 0);
+  }
+}
+
+// O^T += V^T . P^T (8 MFMAs).  The 16 transposed reads go through ONE asm statement: hipcc cannot see that the
+// ds_read_tr16 builtin does not alias the in-flight LDS-DMA of later tiles and would drain it (s_waitcnt vmcnt(0))
+// in the middle of the tile.  EXEC is all ones here (wave-uniform control flow only).
+__device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
+  u32x2 t0[8], t1[8];
+  const unsigned a0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0);
+  const unsigned a1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:0\n\t"
+      "ds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %8, %17 offset:0\n\t"
+      "ds_read_b64_tr_b16 %9, %17 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:2048\n\t"
+      "ds_read_b64_tr_b16 %3, %16 offset:3072\n\t"
+      "ds_read_b64_tr_b16 %10, %17 offset:2048\n\t"
+      "ds_read_b64_tr_b16 %11, %17 offset:3072\n\t"
+      "ds_read_b64_tr_b16 %4, %16 offset:4096\n\t"
+      "ds_read_b64_tr_b16 %5, %16 offset:5120\n\t"
+      "ds_read_b64_tr_b16 %12, %17 offset:4096\n\t"
+      "ds_read_b64_tr_b16 %13, %17 offset:5120\n\t"
+      "ds_read_b64_tr_b16 %6, %16 offset:6144\n\t"
+      "ds_read_b64_tr_b16 %7, %16 offset:7168\n\t"
+      "ds_read_b64_tr_b16 %14, %17 offset:6144\n\t"
+      "ds_read_b64_tr_b16 %15, %17 offset:7168\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(t0[0]), "=&v"(t0[1]), "=&v"(t0[2]), "=&v"(t0[3]), "=&v"(t0[4]), "=&v"(t0[5]), "=&v"(t0[6]), "=&v"(t0[7]),
+        "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]), "=&v"(t1[6]), "=&v"(t1[7])
+      : "v"(a0), "v"(a1)
+      : "memory");
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const u32x4 w0 = {t0[2 * kk][0], t0[2 * kk][1], t0[2 * kk + 1][0], t0[2 * kk + 1][1]};
+    const u32x4 w1 = {t1[2 * kk][0], t1[2 * kk][1], t1[2 * kk + 1][0], t1[2 * kk + 1][1]};
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[kk], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[kk], o1, 0, 0, 0);
+  }
+}
+
+struct Run {
+  f32x16 o0, o1, negm;
+  float m, l;
+};
+
+// softmax bookkeeping of one tile: masks, tile max, deferred rescale, P = exp2(S'), row sum, bf16 B fragments.
+// register i of block kb holds key t*64 + kb*32 + (i&3) + 8*(i>>2) + 4*hh for query (lane & 31).
+template <bool HAS_MASK, bool HAS_NEXT, typename Mid = NoHook>
+__device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int t, int nt, int qrow_c, f32x16& s0, f32x16& s1, f32x16& n0,
+                                             f32x16& n1, Run& r, bf16x8 (&pb)[4], Mid mid = Mid()) {
+  const int kbase_idx = t * KVB + 4 * ln.hh;
+  if (t == nt - 1 && (p.Skv & (KVB - 1))) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
+      if (key >= p.Skv) s0[i] = -INFINITY;
+      if (key + 32 >= p.Skv) s1[i] = -INFINITY;
+    }
+  }
+  if constexpr (HAS_MASK) {
+    const uint8_t* mrow = p.mask + (long long)qrow_c * p.Skv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
+      if (key < p.Skv && mrow[key]) s0[i] = -INFINITY;
+      if (key + 32 < p.Skv && mrow[key + 32]) s1[i] = -INFINITY;
+    }
+  }
+  // tile max: four independent v_max3 chains, then across the two half-waves
+  float ma = max3_asm(s0[0], s0[1], s0[2]), mb = max3_asm(s1[0], s1[1], s1[2]);
+  float mc = max3_asm(s0[3], s0[4], s0[5]), md = max3_asm(s1[3], s1[4], s1[5]);
+#pragma unroll
+  for (int i = 6; i < 16; i += 4) {
+    ma = max3_asm(ma, s0[i], s0[i + 1]);
+    mb = max3_asm(mb, s1[i], s1[i + 1]);
+    if (i + 3 < 16) {
+      mc = max3_asm(mc, s0[i + 2], s0[i + 3]);
+      md = max3_asm(md, s1[i + 2], s1[i + 3]);
+    }
+  }
+  float tm = half_swap_max(max3_asm(max3_asm(ma, mb, mc), md, md));
+  // deferred rescale: move the running max only on the first tile or when a row grew past THR
+  const bool first = (t == 0);
+  if (first || __any(tm > kThr)) {
+    const float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
+    if (!first) {
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      r.l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { r.o0[i] *= alpha; r.o1[i] *= alpha; }
+    }
+    r.m += delta;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; r.negm[i] = -r.m; }
+    if constexpr (HAS_NEXT) {  // the prefetched S' of tile t+1 was formed against the old max
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { n0[i] -= delta; n1[i] -= delta; }
+    }
+  }
+  mid();  // staggered waves rendezvous here (between the max / rescale head and the exp body)
+  float la = 0.f, lb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s0[i] = __builtin_amdgcn_exp2f(s0[i]);
+    s1[i] = __builtin_amdgcn_exp2f(s1[i]);
+    la += s0[i];
+    lb += s1[i];
+  }
+  r.l += la + lb;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 w0, w1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w0[j] = pack_bf2(s0[8 * s + 2 * j], s0[8 * s + 2 * j + 1]);
+      w1[j] = pack_bf2(s1[8 * s + 2 * j], s1[8 * s + 2 * j + 1]);
+    }
+    pb[s] = __builtin_bit_cast(bf16x8, w0);
+    pb[2 + s] = __builtin_bit_cast(bf16x8, w1);
+  }
+}
+
+template <int NW, bool HAS_MASK, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
-  constexpr int PPW = 16 / NW;  // 1 KiB DMA pieces per wave per tile (8 K pieces + 8 V pieces)
+  constexpr int PPW = NW >= 8 ? 1 : 8 / NW;  // 1 KiB DMA pieces per wave per K (or V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hh = lane >> 5, r32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR LDS bases
+  const int r32 = lane & 31;
+  Lane ln;
+  ln.hh = lane >> 5;
 
   // ---- XCD-aware block -> (q-tile, b, h)
   const int nbh = p.B * p.H;
@@ -86,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
   // ---- Q fragments: B operand of S^T = K.Q^T : lane holds Q[q = lane&31][d = 16 ks + 8 hh + j]
   bf16x8 qf[4];
   {
-    const bf16_t* qp = p.Q + (long long)b * p.q_sb + (long long)qrow_c * p.q_ss + (long long)h * p.q_sh + hh * 8;
+    const bf16_t* qp = p.Q + (long long)b * p.q_sb + (long long)qrow_c * p.q_ss + (long long)h * p.q_sh + ln.hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const u32x4 raw = *(const u32x4*)(qp + ks * 16);
@@ -94,193 +272,149 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
     }
   }
 
-  // ---- DMA source bookkeeping
+  // ---- LDS-DMA staging: piece = 8 keys x 128 B; lane i -> key (i >> 3), 16-byte position (i & 7)
   const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh;
   const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh;
   const int prow = lane >> 3, ppos = lane & 7;
-
-  auto issue = [&](int stage, int t) {
-    char* base = smem + stage * STAGE;
+  unsigned k_loff[PPW], v_loff[PPW];   // loop-invariant per-lane byte offsets inside a tile (source-side swizzles folded in)
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wave + i * NW;  // 0..7 -> K, 8..15 -> V
-      const bool isv = piece >= 8;
-      const int kit = (piece & 7) * 8 + prow;  // key inside the tile
-      long long key = (long long)t * KVB + kit;
-      key = key < p.Skv ? key : p.Skv - 1;  // tail keys re-read a valid row; their scores are masked
-      const int chunk = isv ? (ppos ^ (((kit >> 1) & 1) << 2)) : (ppos ^ ((kit >> 1) & 7));
-      const bf16_t* src = isv ? (vbase + key * p.v_ss) : (kbase + key * p.k_ss);
-      glds16(src + chunk * 8, base + piece * 1024);
+  for (int i = 0; i < PPW; ++i) {
+    const int kit = ((wave + i * NW) & 7) * 8 + prow;
+    k_loff[i] = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;
+    v_loff[i] = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8) * 2u;
+  }
+  auto issue_k = [&](int stage, int t) {
+    if ((t + 1) * KVB <= p.Skv) {   // whole tile in range (wave-uniform): scalar tile base + invariant lane offset
+      const char* tile = (const char*)kbase + (long long)t * KVB * p.k_ss * 2;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) glds16(tile + k_loff[i], smem + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int piece = (wave + i * NW) & 7;
+        const int kit = piece * 8 + prow;
+        long long key = (long long)t * KVB + kit;
+        key = key < p.Skv ? key : p.Skv - 1;  // tail keys re-read a valid row; their scores are masked
+        glds16(kbase + key * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8, smem + stage * TILE_BYTES + piece * 1024);
+      }
+    }
+  };
+  auto issue_v = [&](int stage, int t) {
+    if ((t + 1) * KVB <= p.Skv) {
+      const char* tile = (const char*)vbase + (long long)t * KVB * p.v_ss * 2;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) glds16(tile + v_loff[i], smem + V_BASE + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int piece = (wave + i * NW) & 7;
+        const int kit = piece * 8 + prow;
+        long long key = (long long)t * KVB + kit;
+        key = key < p.Skv ? key : p.Skv - 1;
+        glds16(vbase + key * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8, smem + V_BASE + stage * TILE_BYTES + piece * 1024);
+      }
     }
   };
 
-  // ---- fragment read addresses (bytes, relative to the stage base)
+  // ---- fragment read addresses (bytes, relative to the tile base)
   // K (A operand of K.Q^T): lane reads row key = kb*32 + r32, 16-byte chunk (2 ks + hh) ^ ((key>>1)&7)
-  const int k_row_off = r32 * 128;
-  const int k_swz = (r32 >> 1) & 7;
-  // V^T (A operand of V^T.P^T) through ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies the
-  // address of key row (k0 + q), columns 4p..4p+3 of the block; it receives column (lane & 15).
+  ln.k_row_off = r32 * 128;
+  ln.k_swz = (r32 >> 1) & 7;
+  // V^T (A operand of V^T.P^T) through ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies the address of
+  // key row (k0 + q), columns 4p..4p+3 of the block; it receives column (lane & 15).
   const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-  const int v_lane_off = KVB * 128 + (4 * hh + q4) * 128 + (g16 & 1) * 32 + p4 * 8;
-  const int v_half0 = (q4 >> 1) * 64;        // d-tile 0: 64-byte half index 0 ^ (key>>1 & 1)
-  const int v_half1 = (1 - (q4 >> 1)) * 64;  // d-tile 1
+  ln.v_lane_off = (4 * ln.hh + q4) * 128 + (g16 & 1) * 32 + p4 * 8;
+  ln.v_half0 = (q4 >> 1) * 64;        // d-tile 0: 64-byte half index 0 ^ ((key >> 1) & 1)
+  ln.v_half1 = (1 - (q4 >> 1)) * 64;  // d-tile 1
 
-  f32x16 o0, o1, negm;
+  Run r;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; negm[i] = 0.f; }
-  float m_run = 0.f, l_run = 0.f;
+  for (int i = 0; i < 16; ++i) { r.o0[i] = 0.f; r.o1[i] = 0.f; r.negm[i] = 0.f; }
+  r.m = 0.f; r.l = 0.f;
 
+  // ---- main loop.  K and V each own a ring of NS stages; the DMA runs D = NS-1 tiles ahead of the compute and is
+  // retired by a COUNTED vmcnt (every wave issues exactly 2*PPW DMA instructions per tile pair, tiles past the end
+  // re-read clamped rows so the count never changes) + a raw s_barrier: __syncthreads() would drain the queue.
   const int nt = (p.Skv + KVB - 1) / KVB;
-  issue(0, 0);
-  for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nt) issue((t + 1) & 1, t + 1);
-    if (!wave_active) continue;
-    const char* st = smem + (t & 1) * STAGE;
-
-    // ---- S'^T = K . Q^T - m  (two 32-key blocks)
-    f32x16 s0 = negm, s1 = negm;
-    {
-      bf16x8 k0f[4], k1f[4];  // all 8 K fragments in flight before the first MFMA
+  constexpr int D = NS - 2;
+  auto wait_pair = [&]() {   // all but the (D-1) youngest tile pairs of this wave have landed; then rendezvous
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (D - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if constexpr (!PIPE) {
+    // iteration t reads K(t), V(t) from stage t % NS.  Barrier #j guarantees tile j has landed for every wave; after it each
+    // wave issues tile j + D into the stage of tile j - 2 (ring of NS = D + 2).  The "late" half of the workgroup (waves
+    // NW/2..NW-1, the SIMD partners of the early half) runs HALF A TILE BEHIND: it takes barrier #j in the middle of its
+    // softmax(j-1), so while one wave of a SIMD is in its MFMA phase (QK^T / PV) its partner is in its exp/convert phase,
+    // instead of both queueing on the same pipe right after a common barrier.
+    const bool late = NW >= 8 && wave >= NW / 2;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int coff = ((2 * ks + hh) ^ k_swz) * 16;
-        k0f[ks] = *(const bf16x8*)(st + k_row_off + coff);
-        k1f[ks] = *(const bf16x8*)(st + 32 * 128 + k_row_off + coff);
+    for (int i = 0; i < D; ++i) { issue_k(i, i); issue_v(i, i); }
+    if (late) { wait_pair(); issue_k(D % NS, D); issue_v(D % NS, D); }   // barrier #0
+    for (int t = 0; t < nt; ++t) {
+      if (!late) wait_pair();   // barrier #t
+      auto early_issue = [&]() {
+        if (!late) { issue_k((t + D) % NS, t + D); issue_v((t + D) % NS, t + D); }
+      };
+      auto mid = [&]() {
+        if (late) { wait_pair(); issue_k((t + 1 + D) % NS, t + 1 + D); issue_v((t + 1 + D) % NS, t + 1 + D); }   // barrier #(t+1)
+      };
+      if (!wave_active) { early_issue(); mid(); continue; }
+      f32x16 s0, s1;
+      bf16x8 pb[4];
+      qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
+      softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
+      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1);
+    }
+    if (!late && NW >= 8) __builtin_amdgcn_s_barrier();   // barrier #nt pairs with the late half's last rendezvous
+  } else {
+    // software-pipelined: iteration t issues QK^T(t+1) (matrix pipe) ahead of softmax(t) (vector pipe) and PV(t).
+    // It reads K(t+1), V(t) and issues the pair [K(t+D+1), V(t+D)] into the stages of K(t), V(t-1) (read in iteration t-1).
+    issue_k(0, 0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { issue_k((i + 1) % NS, i + 1); issue_v(i % NS, i); }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * D) : "memory");   // K(0) landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 sA0, sA1, sB0, sB1;
+    if (wave_active) qk_tile(smem, ln, qf, r.negm, sA0, sA1);
+    auto step = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+      wait_pair();
+      issue_k((t + D + 1) % NS, t + D + 1); issue_v((t + D) % NS, t + D);
+      if (!wave_active) return;
+      bf16x8 pb[4];
+      if (t + 1 < nt) {
+        qk_tile(smem + ((t + 1) % NS) * TILE_BYTES, ln, qf, r.negm, n0, n1);
+        softmax_tile<HAS_MASK, true>(p, ln, t, nt, qrow_c, c0, c1, n0, n1, r, pb);
+      } else {
+        softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, c0, c1, c0, c1, r, pb);
       }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[ks], qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[ks], qf[ks], s1, 0, 0, 0);
-      }
-    }
-    // register i of block kb holds key t*64 + kb*32 + (i&3) + 8*(i>>2) + 4*hh for query lane&31
-    const int kbase_idx = t * KVB + 4 * hh;
-    if (t == nt - 1 && (p.Skv & (KVB - 1))) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
-        if (key >= p.Skv) s0[i] = -INFINITY;
-        if (key + 32 >= p.Skv) s1[i] = -INFINITY;
-      }
-    }
-    if constexpr (HAS_MASK) {
-      const uint8_t* mrow = p.mask + (long long)qrow_c * p.Skv;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
-        if (key < p.Skv && mrow[key]) s0[i] = -INFINITY;
-        if (key + 32 < p.Skv && mrow[key + 32]) s1[i] = -INFINITY;
-      }
-    }
-
-    // ---- tile max over this lane's 32 scores and the other half-wave's 32
-    // v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising
-    // v_max per operand (3x the VALU work on the softmax critical path)
-    float tm = max3_asm(s0[0], s1[0], s0[1]);
-    tm = max3_asm(tm, s1[1], s0[2]);
-#pragma unroll
-    for (int i = 2; i < 15; ++i) tm = max3_asm(tm, s1[i], s0[i + 1]);
-    tm = max3_asm(tm, s1[15], s1[15]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
-      tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    // deferred rescale: move the running max only on the first tile or when a row grew past THR
-    const bool first = (t == 0);
-    if (first || __any(tm > kThr)) {
-      float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
-      if (!first) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-        l_run *= alpha;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      }
-      m_run += delta;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; negm[i] = -m_run; }
-    }
-
-    // ---- P = exp2(S'), row-sum, pack to bf16 B fragments (key order is already the MFMA k order)
-    float lsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s0[i] = __builtin_amdgcn_exp2f(s0[i]);
-      s1[i] = __builtin_amdgcn_exp2f(s1[i]);
-      lsum += s0[i] + s1[i];
-    }
-    l_run += lsum;
-    bf16x8 pb[4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 w0, w1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        w0[j] = pack_bf2(s0[8 * s + 2 * j], s0[8 * s + 2 * j + 1]);
-        w1[j] = pack_bf2(s1[8 * s + 2 * j], s1[8 * s + 2 * j + 1]);
-      }
-      pb[s] = __builtin_bit_cast(bf16x8, w0);
-      pb[2 + s] = __builtin_bit_cast(bf16x8, w1);
-    }
-
-    // ---- O^T += V^T . P^T   (4 key steps of 16, two 32-wide d tiles)
-    // The 16 transposed reads go through ONE asm statement: hipcc cannot see that the
-    // ds_read_tr16 builtin does not alias the LDS-DMA of the next tile and would drain it
-    // (s_waitcnt vmcnt(0)) in the middle of the tile.  EXEC is all ones here (wave-uniform flow).
-    u32x2 t0[8], t1[8];
-    {
-      const unsigned a0 = (unsigned)(size_t)(st + v_lane_off + v_half0);
-      const unsigned a1 = (unsigned)(size_t)(st + v_lane_off + v_half1);
-      asm volatile(
-          "ds_read_b64_tr_b16 %0, %16 offset:0\n\t"
-          "ds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %8, %17 offset:0\n\t"
-          "ds_read_b64_tr_b16 %9, %17 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %2, %16 offset:2048\n\t"
-          "ds_read_b64_tr_b16 %3, %16 offset:3072\n\t"
-          "ds_read_b64_tr_b16 %10, %17 offset:2048\n\t"
-          "ds_read_b64_tr_b16 %11, %17 offset:3072\n\t"
-          "ds_read_b64_tr_b16 %4, %16 offset:4096\n\t"
-          "ds_read_b64_tr_b16 %5, %16 offset:5120\n\t"
-          "ds_read_b64_tr_b16 %12, %17 offset:4096\n\t"
-          "ds_read_b64_tr_b16 %13, %17 offset:5120\n\t"
-          "ds_read_b64_tr_b16 %6, %16 offset:6144\n\t"
-          "ds_read_b64_tr_b16 %7, %16 offset:7168\n\t"
-          "ds_read_b64_tr_b16 %14, %17 offset:6144\n\t"
-          "ds_read_b64_tr_b16 %15, %17 offset:7168\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(t0[0]), "=&v"(t0[1]), "=&v"(t0[2]), "=&v"(t0[3]), "=&v"(t0[4]), "=&v"(t0[5]), "=&v"(t0[6]),
-            "=&v"(t0[7]), "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]),
-            "=&v"(t1[6]), "=&v"(t1[7])
-          : "v"(a0), "v"(a1)
-          : "memory");
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const u32x4 w0 = {t0[2 * kk][0], t0[2 * kk][1], t0[2 * kk + 1][0], t0[2 * kk + 1][1]};
-      const u32x4 w1 = {t1[2 * kk][0], t1[2 * kk][1], t1[2 * kk + 1][0], t1[2 * kk + 1][1]};
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[kk], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[kk], o1, 0, 0, 0);
+      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1);
+    };
+    for (int t = 0; t < nt; t += 2) {
+      step(t, sA0, sA1, sB0, sB1);
+      if (t + 1 < nt) step(t + 1, sB0, sB1, sA0, sA1);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
 
   if (!wave_active) return;
   // ---- epilogue: combine the two half-waves' row sums, normalise, fused residual, 8-byte stores
   {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r.l), __float_as_uint(r.l), false, false);
+    r.l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   if (qrow >= p.Sq) return;
-  const float inv = p.out_scale / l_run;
-  const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * hh;
+  const float inv = p.out_scale / r.l;
+  const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * ln.hh;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (dt ? o1[4 * g + e] : o0[4 * g + e]) * inv;
+      for (int e = 0; e < 4; ++e) v[e] = (dt ? r.o1[4 * g + e] : r.o0[4 * g + e]) * inv;
       const long long off = obase + dt * 32 + 8 * g;
       if (p.resid) {
         const u32x2 rr = *(const u32x2*)(p.resid + off);
@@ -295,13 +429,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
   }
 }
 
-template <int NW>
+template <int NW, bool PIPE>
 int launch_attn(hipStream_t s, AttnP p) {
   p.n_qtiles = (p.Sq + NW * 32 - 1) / (NW * 32);
   const dim3 grid(p.n_qtiles * p.B * p.H), block(NW * 64);
-  const size_t lds = 2 * STAGE;
-  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true>), grid, block, lds, s, p);
-  else MRAG_LAUNCH((attn_fwd_kernel<NW, false>), grid, block, lds, s, p);
+  const size_t lds = 2 * NS * TILE_BYTES;
+  {
+    const void* kf = p.mask ? (const void*)attn_fwd_kernel<NW, true, PIPE> : (const void*)attn_fwd_kernel<NW, false, PIPE>;
+    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE>), grid, block, lds, s, p);
+  else MRAG_LAUNCH((attn_fwd_kernel<NW, false, PIPE>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -328,7 +467,11 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   p.qscale = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.out_scale = a->out_scale;
   hipStream_t s = (hipStream_t)stream;
-  if (a->Sq > 128) return launch_attn<8>(s, p);
-  if (a->Sq > 32) return launch_attn<2>(s, p);
-  return launch_attn<1>(s, p);
+  // The intra-wave software-pipelined variant (PIPE) measures SLOWER than the staggered-barrier loop on MI355X with
+  // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
+  bool pipe = false;
+  if (const char* e = getenv("MRAG_ATTN_PIPE")) pipe = e[0] == '1';
+  if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
+  if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
+  return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);
 }

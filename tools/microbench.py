@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the BASELINE shapes (developer tool; bench.py is the judged entry point).
+usage: python tools/microbench.py [attn] [gemm] [topk] [norm]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from motionrag_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def attn():
+    B, H, S = 2, 48, 17776
+    qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
+    out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
+    dt = timeit(lambda: ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out))
+    fl = 4.0 * B * H * S * S * 64
+    print(f"attn joint S={S}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s  ({fl/dt/2.5e15*100:.1f}% of 2.5 PF)")
+    kv = torch.randn(B, 25, 2, H, 64, device=DEV).to(torch.bfloat16)
+    dt = timeit(lambda: ops.attention(qkv[:, :, 0], kv[:, :, 0], kv[:, :, 1], out=out, resid=out, out_scale=1.0))
+    by = 3.0 * B * S * H * 64 * 2
+    print(f"attn motion (25 keys, fused residual): {dt*1e6:.1f} us  {by/dt/1e9:.0f} GB/s algorithmic (read Q, read+write O)")
+
+
+def gemm():
+    M = 2 * 17776
+    for name, N, K, epi in (("qkv", 9216, 3072, ops.EPI_NONE), ("to_out/to_q_ip", 3072, 3072, ops.EPI_NONE), ("ff1 gelu", 12288, 3072, ops.EPI_GELU_TANH),
+                            ("ff2", 3072, 12288, ops.EPI_NONE)):
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+        b = torch.randn(N, device=DEV).to(torch.bfloat16)
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        dt = timeit(lambda: ops.linear(x, w, b, out=out, epilogue=epi))
+        fl = 2.0 * M * N * K
+        print(f"gemm {name:16s} M={M} N={N} K={K}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s ({fl/dt/2.5e15*100:.1f}%)")
+
+
+def topk():
+    for N, Q in ((10000, 1), (10000, 256), (1000000, 1), (1000000, 64)):
+        db = torch.randn(N, 768, device=DEV)
+        q = torch.randn(Q, 768, device=DEV)
+        dt = timeit(lambda: ops.topk(db, q, 12), iters=5)
+        print(f"topk N={N} Q={Q}: {dt*1e6:.1f} us  db stream {N*768*4/dt/1e9:.0f} GB/s  ({Q/dt:.0f} queries/s)")
+
+
+def norm():
+    B, S, D = 2, 17776, 3072
+    x = torch.randn(B, S, D, device=DEV).to(torch.bfloat16)
+    w = torch.ones(D, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty_like(x)
+    dt = timeit(lambda: ops.layernorm(x, w, w, 1e-5, out=y))
+    print(f"layernorm [{B*S},{D}]: {dt*1e6:.1f} us  {2*x.numel()*2/dt/1e9:.0f} GB/s")
+    qkv = torch.randn(B, S, 3 * 48 * 64, device=DEV).to(torch.bfloat16)
+    g = torch.ones(64, device=DEV, dtype=torch.bfloat16)
+    cs = torch.randn(S - 226, 64, device=DEV)
+    dt = timeit(lambda: ops.qknorm_rope_(qkv, 48, g, g, g, g, cs, cs, 226, q_premul=0.18))
+    print(f"qknorm_rope: {dt*1e6:.1f} us  {2*(qkv.numel()*2//3)*2/dt/1e9:.0f} GB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
+    for w in which:
+        globals()[w]()

@@ -232,7 +232,9 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
   }
 }
 
-template <int NW, bool HAS_MASK, bool PIPE>
+// SHORTKV: key sets of at most one tile (motion tokens, text, temporal frames) -- same code, no barrier stagger; a separate
+// instantiation so that profiles list the HBM-bound small-KV launches apart from the MFMA-bound long-sequence ones.
+template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
   constexpr int PPW = NW >= 8 ? 1 : 8 / NW;  // 1 KiB DMA pieces per wave per K (or V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
     // NW/2..NW-1, the SIMD partners of the early half) runs HALF A TILE BEHIND: it takes barrier #j in the middle of its
     // softmax(j-1), so while one wave of a SIMD is in its MFMA phase (QK^T / PV) its partner is in its exp/convert phase,
     // instead of both queueing on the same pipe right after a common barrier.
-    const bool late = NW >= 8 && wave >= NW / 2;
+    const bool late = NW >= 8 && !SHORTKV && wave >= NW / 2;
 #pragma unroll
     for (int i = 0; i < D; ++i) { issue_k(i, i); issue_v(i, i); }
     if (late) { wait_pair(); issue_k(D % NS, D); issue_v(D % NS, D); }   // barrier #0
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
       softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1);
     }
-    if (!late && NW >= 8) __builtin_amdgcn_s_barrier();   // barrier #nt pairs with the late half's last rendezvous
+    if (!late && NW >= 8 && !SHORTKV) __builtin_amdgcn_s_barrier();   // barrier #nt pairs with the late half's last rendezvous
   } else {
     // software-pipelined: iteration t issues QK^T(t+1) (matrix pipe) ahead of softmax(t) (vector pipe) and PV(t).
     // It reads K(t+1), V(t) and issues the pair [K(t+D+1), V(t+D)] into the stages of K(t), V(t-1) (read in iteration t-1).
@@ -429,18 +431,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
   }
 }
 
-template <int NW, bool PIPE>
+template <int NW, bool PIPE, bool SHORTKV = false>
 int launch_attn(hipStream_t s, AttnP p) {
   p.n_qtiles = (p.Sq + NW * 32 - 1) / (NW * 32);
   const dim3 grid(p.n_qtiles * p.B * p.H), block(NW * 64);
   const size_t lds = 2 * NS * TILE_BYTES;
   {
-    const void* kf = p.mask ? (const void*)attn_fwd_kernel<NW, true, PIPE> : (const void*)attn_fwd_kernel<NW, false, PIPE>;
+    const void* kf = p.mask ? (const void*)attn_fwd_kernel<NW, true, PIPE, SHORTKV> : (const void*)attn_fwd_kernel<NW, false, PIPE, SHORTKV>;
     const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE>), grid, block, lds, s, p);
-  else MRAG_LAUNCH((attn_fwd_kernel<NW, false, PIPE>), grid, block, lds, s, p);
+  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE, SHORTKV>), grid, block, lds, s, p);
+  else MRAG_LAUNCH((attn_fwd_kernel<NW, false, PIPE, SHORTKV>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -471,6 +473,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
   bool pipe = false;
   if (const char* e = getenv("MRAG_ATTN_PIPE")) pipe = e[0] == '1';
+  if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);
   if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
   if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
   return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);

@@ -14,6 +14,7 @@
 //   * 1-D grid with a bijective XCD remap so tiles that share an A row-panel sit on one L2.
 #include "common.h"
 #include "../../include/mrag_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -21,7 +22,7 @@ struct GemmP {
   const bf16_t* A; const bf16_t* W; const bf16_t* bias; bf16_t* C; const bf16_t* resid;
   const bf16_t* gate0; const bf16_t* gate1;
   long long M, N, K, lda, ldw, ldc, ldr, rows_per_batch, split, gate_stride;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group_m;
 };
 
 template <int EPI>
@@ -46,8 +47,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   const int wm = wave / WN, wn = wave % WN;
 
   const int nwg = p.tiles_m * p.tiles_n;
+  // logical tile order: groups of GROUP_M m-tiles walked n-major, so the ~32 workgroups resident on one XCD (a contiguous
+  // run of the logical order after the XCD remap) form a GROUP_M x 8 block that shares GROUP_M A-panels and 8 W-panels
+  // per K-step through that XCD's L2 (instead of 1 A-panel and 32 W-panels)
   const int wg = xcd_remap(blockIdx.x, nwg);
-  const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+  const int gw = p.group_m * p.tiles_n;
+  const int first_m = (wg / gw) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  const int tile_m = first_m + (wg % gw) % gsz, tile_n = (wg % gw) / gsz;
   const long long bm0 = (long long)tile_m * BM, bn0 = (long long)tile_n * BN;
 
   // ---- per-lane DMA source pointers (k = 0), one per piece this wave stages
@@ -91,24 +98,81 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   };
 
   issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt landed for every wave; everyone finished reading the other stage
-    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
-    const char* st = smem + (kt & 1) * STAGE_BYTES;
+  if constexpr (TM == 8 && TN == 4 && WM == 2 && WN == 4) {
+    // ---- 256x256 tile: all 12 fragments of a 32-deep k-step are requested by ONE asm statement and released to the MFMAs by
+    // COUNTED s_waitcnt lgkmcnt(N) (LDS reads return in order), the second k-step's 12 reads are issued while the first
+    // k-step's MFMAs run -> the LDS latency is paid once per K-tile instead of eight times (hipcc's own schedule: read
+    // pair -> lgkmcnt(0) -> 8 MFMAs).  At most 15 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile kt landed for every wave; everyone finished reading the other stage
+      const unsigned st = (unsigned)(size_t)(smem + (kt & 1) * STAGE_BYTES);
+      const unsigned c0 = ((frag_q + 0) ^ swz) * 16, c1 = ((frag_q + 4) ^ swz) * 16;
+      const unsigned aA0 = st + a_off + c0, aA1 = st + a_off + c1;
+      const unsigned aW0 = st + (w_off - BM * 128) + c0, aW1 = st + (w_off - BM * 128) + c1;
+      u32x4 w0[4], a0[8], w1[4], a1[8];
+#define MRAG_READ12(W, A, AW, AA)                                                                                   \
+      asm volatile(                                                                                                  \
+          "ds_read_b128 %0, %12 offset:32768\n\tds_read_b128 %1, %12 offset:34816\n\t"                               \
+          "ds_read_b128 %2, %12 offset:36864\n\tds_read_b128 %3, %12 offset:38912\n\t"                               \
+          "ds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:2048\n\t"                                             \
+          "ds_read_b128 %6, %13 offset:4096\n\tds_read_b128 %7, %13 offset:6144\n\t"                                 \
+          "ds_read_b128 %8, %13 offset:8192\n\tds_read_b128 %9, %13 offset:10240\n\t"                                \
+          "ds_read_b128 %10, %13 offset:12288\n\tds_read_b128 %11, %13 offset:14336"                                  \
+          : "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3]), "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3]),    \
+            "=&v"(A[4]), "=&v"(A[5]), "=&v"(A[6]), "=&v"(A[7])                                                       \
+          : "v"(AW), "v"(AA)                                                                                         \
+          : "memory")
+#define MRAG_WAIT_W(N, W, X) \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(X) :: "memory")
+#define MRAG_WAIT_A(N, X) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X) :: "memory")
+#define MRAG_ROW(I, W, X)                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[I][j] =                                                                 \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[j]), __builtin_bit_cast(bf16x8, X), acc[I][j], 0, 0, 0)
+      MRAG_READ12(w0, a0, aW0, aA0);
+      if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);   // DMA of the next K-tile, behind the first fragment reads
+      MRAG_WAIT_W(7, w0, a0[0]); MRAG_ROW(0, w0, a0[0]);
+      MRAG_WAIT_A(6, a0[1]); MRAG_ROW(1, w0, a0[1]);
+      MRAG_WAIT_A(5, a0[2]); MRAG_ROW(2, w0, a0[2]);
+      MRAG_WAIT_A(4, a0[3]); MRAG_ROW(3, w0, a0[3]);
+      MRAG_WAIT_A(3, a0[4]); MRAG_ROW(4, w0, a0[4]);
+      MRAG_READ12(w1, a1, aW1, aA1);                  // 3 + 12 = 15 outstanding
+      MRAG_WAIT_A(14, a0[5]); MRAG_ROW(5, w0, a0[5]);
+      MRAG_WAIT_A(13, a0[6]); MRAG_ROW(6, w0, a0[6]);
+      MRAG_WAIT_A(12, a0[7]); MRAG_ROW(7, w0, a0[7]);
+      MRAG_WAIT_W(7, w1, a1[0]); MRAG_ROW(0, w1, a1[0]);
+      MRAG_WAIT_A(6, a1[1]); MRAG_ROW(1, w1, a1[1]);
+      MRAG_WAIT_A(5, a1[2]); MRAG_ROW(2, w1, a1[2]);
+      MRAG_WAIT_A(4, a1[3]); MRAG_ROW(3, w1, a1[3]);
+      MRAG_WAIT_A(3, a1[4]); MRAG_ROW(4, w1, a1[4]);
+      MRAG_WAIT_A(2, a1[5]); MRAG_ROW(5, w1, a1[5]);
+      MRAG_WAIT_A(1, a1[6]); MRAG_ROW(6, w1, a1[6]);
+      MRAG_WAIT_A(0, a1[7]); MRAG_ROW(7, w1, a1[7]);
+#undef MRAG_READ12
+#undef MRAG_WAIT_W
+#undef MRAG_WAIT_A
+#undef MRAG_ROW
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile kt landed for every wave; everyone finished reading the other stage
+      if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+      const char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((frag_q + 4 * ks) ^ swz) * 16;
-      bf16x8 wf[TN], af[TM];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((frag_q + 4 * ks) ^ swz) * 16;
+        bf16x8 wf[TN], af[TM];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 16 * 128 + coff);
+        for (int j = 0; j < TN; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 16 * 128 + coff);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 16 * 128 + coff);
+        for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 16 * 128 + coff);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
@@ -158,6 +222,8 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   GemmP p = p0;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
+  p.group_m = 4;
+  if (const char* e = getenv("MRAG_GEMM_GROUP_M")) p.group_m = atoi(e) > 0 ? atoi(e) : 4;   // tuning knob
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   const size_t lds = 2 * (BM + BN) * 64 * 2;
 #define MRAG_GEMM_CASE(E)                                                                              \

@@ -179,6 +179,12 @@ def main():
         S = 226 + lat_frames * 1350
         d = 3072
         step_flops = 2 * args.layers * (24 * S * d * d + 4 * S * S * d + 2 * S * d * d + 4 * S * 25 * d + 4 * 25 * 1024 * d)
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r1_attn_traffic.json")   # rocprofv3 PMC pass of the same kernel + shape (tools/pmc_traffic.sh)
+        if args.layers == 42 and args.frames == 49 and os.path.exists(tp):
+            with open(tp) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch_corrected"])
+            traffic_src = "profiles/r1_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)"
         out = {
             "metric": "denoise_step_frames_per_sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -193,7 +199,8 @@ def main():
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
             "roofline": {"kernel": "attn_fwd_kernel<8,false> (joint text+video flash attention, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": None,
+                         "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches": len(durs), "avg_launch_ms": round(avg * 1e3, 4) if durs else None,
                          "algorithmic_tflop_per_launch": round(flops / 1e12, 3)},
         }

@@ -195,6 +195,43 @@ int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n
                   int32_t k, int32_t metric,
                   int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes);
 
+/* ------------------------------------------------------------------------ */
+/* Spatio-temporal UNet denoisers (DynamiCrafter lvdm, SVD): channels-last   */
+/* rows [(n, y, x), C] bf16, n = b*t frames.                                  */
+/* ------------------------------------------------------------------------ */
+/* nn.GroupNorm(G, C) over (HW x C/G) per (n, group) [+ per-(n,c) embedding   */
+/* pre-add: `h + emb_out` of ResBlock._forward, openaimodel3d.py:216-229]     */
+/* [+ SiLU].  lvdm/basics.py:81-88; openaimodel3d.py:152-181,258-268;         */
+/* lvdm/modules/attention.py:286,357.  workspace: fp32 partial sums.          */
+typedef struct mrag_groupnorm_args {
+  const void* x; void* y;          /* [N, HW, C] bf16                           */
+  const void* gamma; const void* beta;   /* [C] bf16 or NULL                    */
+  const void* emb;                 /* [N, C] bf16 (row stride emb_stride) or NULL */
+  void* workspace;                 /* mrag_groupnorm_workspace_bytes(N, C, chunks) */
+  int64_t N, HW, C, emb_stride;
+  int32_t G, chunks, silu;
+  float eps;
+} mrag_groupnorm_args;
+int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks);
+int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* args);
+/* row gather in front of the implicit-GEMM 3x3 convolution (pad 1, stride 1|2,
+ * optional nearest x2 upsample of the source: openaimodel3d.py:52-107):
+ * dst[(n,yo,xo), (ky,kx,c)] -> [N*Ho*Wo, Kpad], columns >= 9C zero.            */
+int mrag_im2col3x3_bf16(void* stream, const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t stride, int32_t upsample, int32_t Kpad);
+/* row gather for nn.Conv3d((3,1,1), padding (1,0,0)), openaimodel3d.py:256-268:
+ * dst[(b,t,hw), (kt,c)] = src[b, t+kt-1, hw, c]                                */
+int mrag_unfold_t3_bf16(void* stream, const void* src, void* dst, int32_t B, int32_t T, int64_t HW, int32_t C);
+/* GEGLU (attention.py:448-455): y[r, j] = x[r, j] * gelu(x[r, inner + j])      */
+int mrag_geglu_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t inner);
+/* DDIMSampler.p_sample_ddim, v-parameterisation (samplers/ddim.py:203-298):
+ * v = v_u + s (v_c - v_u) with v_pred = [cond ; uncond] (cond FIRST, :219-237);
+ * eps = sa v + sb x; x0 = (sa x - sb v) * rescale; x <- sqrt_aprev x0 + dir eps
+ * + sigma noise.  x, noise fp32 [n] (noise pre-generated on the host, NULL = 0) */
+int mrag_ddim_v_step_f32(void* stream, const void* v_pred, float* x, const float* noise, int64_t n, float guidance,
+                         float sqrt_alpha_t, float sqrt_one_minus_alpha_t, float rescale, float sqrt_alpha_prev,
+                         float dir_coef, float sigma);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmrag_hip.so")
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "norm.hip", "pointwise.hip", "topk.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "norm.hip", "pointwise.hip", "topk.hip", "unet_ops.hip"]
 ABI_VERSION = 1
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"]}
@@ -26,6 +26,8 @@ SYMBOLS = [
     "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_attn_fwd_bf16", "mrag_layernorm_bf16",
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
+    "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
+    "mrag_ddim_v_step_f32",
 ]
 
 
@@ -73,6 +75,14 @@ class QkNormRopeArgs(Structure):
         ("cos", c_void_p), ("sin", c_void_p),
         ("B", c_int32), ("S", c_int32), ("H", c_int32), ("text_len", c_int32),
         ("eps", c_float), ("q_premul", c_float),
+    ]
+
+
+class GroupNormArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("emb", c_void_p), ("workspace", c_void_p),
+        ("N", c_int64), ("HW", c_int64), ("C", c_int64), ("emb_stride", c_int64),
+        ("G", c_int32), ("chunks", c_int32), ("silu", c_int32), ("eps", c_float),
     ]
 
 
@@ -141,9 +151,16 @@ def lib() -> ctypes.CDLL:
     L.mrag_topk_workspace_bytes.restype = c_int64
     L.mrag_topk_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                 c_int32, c_void_p, c_void_p, c_void_p, c_int64]
+    L.mrag_groupnorm_workspace_bytes.argtypes = [c_int64, c_int64, c_int32]
+    L.mrag_groupnorm_workspace_bytes.restype = c_int64
+    L.mrag_groupnorm_bf16.argtypes = [c_void_p, POINTER(GroupNormArgs)]
+    L.mrag_im2col3x3_bf16.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int32] * 7
+    L.mrag_unfold_t3_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32]
+    L.mrag_geglu_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64]
+    L.mrag_ddim_v_step_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 7
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("mrag_target_arch", "mrag_topk_workspace_bytes"):
+        if name not in ("mrag_target_arch", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes"):
             fn.restype = c_int32
     _lib = L
     return L

@@ -1,0 +1,288 @@
+// unet_ops.hip -- HBM-bound kernels of the spatio-temporal UNet denoisers (DynamiCrafter / SVD) for gfx950.
+// Activations are channels-last rows [(n, y, x), C] bf16 (n = b*t frames), so every linear / attention / conv of the UNet
+// is a row-major GEMM or a row gather in front of one.
+//
+//   mrag_groupnorm_bf16   nn.GroupNorm(32, C) [+ per-(n, c) embedding pre-add] [+ SiLU]
+//                         (lvdm/basics.py:81-88 GroupNorm32; openaimodel3d.py:152-181 ResBlock in/out layers, :258-268
+//                          TemporalConvBlock; attention.py:286,357 transformer norms)
+//   mrag_im2col3x3_bf16   row gather for nn.Conv2d 3x3 (stride 1 / 2, pad 1; optional nearest x2 upsample in front:
+//                         openaimodel3d.py:52-107 Downsample / Upsample, :152-181 ResBlock convs) -> implicit GEMM
+//   mrag_unfold_t3_bf16   row gather for nn.Conv3d (3,1,1), pad (1,0,0) (openaimodel3d.py:256-268)
+//   mrag_geglu_bf16       x * gelu(gate) (attention.py:448-455)
+//   mrag_ddim_v_step_f32  CFG + v-prediction DDIM update with dynamic rescale and eta noise (samplers/ddim.py:236-296)
+#include "common.h"
+#include "../../include/mrag_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(r[i] << 16);
+    f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm
+// pass 1: per-(n, chunk, channel) partial sum / sum of squares in fp32.  A workgroup owns one (n, chunk of pixels); a thread
+// owns one 8-channel vector column and strides over the chunk's pixels (coalesced 16-byte loads along C).
+struct GnP {
+  const bf16_t* x; bf16_t* y; const bf16_t* gamma; const bf16_t* beta; const bf16_t* emb; float* part;
+  long long N, HW, C, emb_stride;
+  int G, chunks, silu;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int c_off = blockIdx.z * 2048;                                  // channel segment of at most 2048 channels
+  const int C8 = (int)(((p.C - c_off) < 2048 ? (p.C - c_off) : 2048) / 8);
+  const long long px_per_chunk = (p.HW + p.chunks - 1) / p.chunks;
+  const long long px0 = chunk * px_per_chunk;
+  long long px1 = px0 + px_per_chunk;
+  if (px1 > p.HW) px1 = p.HW;
+  // threads are laid out [rows_per_pass][C8]; rows_per_pass = 256 / C8 (>= 1; C8 <= 256 enforced by the host)
+  const int rpp = 256 / C8;
+  const int col = threadIdx.x % C8, rsub = threadIdx.x / C8;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  if (rsub < rpp) {
+    const bf16_t* base = p.x + ((long long)n * p.HW) * p.C + c_off + col * 8;
+    for (long long px = px0 + rsub; px < px1; px += rpp) {
+      float v[8];
+      unpack8(*(const u32x4*)(base + px * p.C), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+  }
+  // reduce the rpp row-groups through LDS, then one thread per channel vector writes the partial
+  __shared__ float red[256][17];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][8 + e] = q[e]; }
+  __syncthreads();
+  if (threadIdx.x < C8) {
+    float ts[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ts[e] = 0.f;
+    for (int r = 0; r < rpp; ++r)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ts[e] += red[r * C8 + threadIdx.x][e];
+    float* out = p.part + (((long long)n * p.chunks + chunk) * p.C + c_off + threadIdx.x * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { out[2 * e] = ts[e]; out[2 * e + 1] = ts[8 + e]; }
+  }
+}
+
+// pass 2: fold the partials into per-channel scale / shift (in LDS), then stream y = act((x + emb) * a_c + b_c)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* a_c = (float*)smem;          // [C]
+  float* b_c = a_c + p.C;             // [C]
+  float* gsum = b_c + p.C;            // [G][2]
+  const int n = blockIdx.y;
+  const int cpg = (int)(p.C / p.G);
+  // per-channel totals (the per-(n, c) embedding folded in analytically), parked in a_c / b_c, then summed per group in a
+  // fixed order (bit-reproducible)
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < p.chunks; ++k) {
+      const float* pr = p.part + (((long long)n * p.chunks + k) * p.C + c) * 2;
+      s += pr[0]; q += pr[1];
+    }
+    if (p.emb) {
+      const float e = bf2f(p.emb[(long long)n * p.emb_stride + c]);
+      q += 2.f * e * s + (float)p.HW * e * e;   // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
+      s += (float)p.HW * e;
+    }
+    a_c[c] = s; b_c[c] = q;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < p.G; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += a_c[c]; q += b_c[c]; }
+    gsum[2 * g] = s; gsum[2 * g + 1] = q;
+  }
+  __syncthreads();
+  const float cnt = (float)p.HW * (float)cpg;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    const int g = c / cpg;
+    const float mean = gsum[2 * g] / cnt;
+    const float var = fmaxf(gsum[2 * g + 1] / cnt - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
+    const float ga = p.gamma ? bf2f(p.gamma[c]) : 1.f, be = p.beta ? bf2f(p.beta[c]) : 0.f;
+    const float e = p.emb ? bf2f(p.emb[(long long)n * p.emb_stride + c]) : 0.f;
+    a_c[c] = ga * rstd;
+    b_c[c] = be + (e - mean) * ga * rstd;
+  }
+  __syncthreads();
+  const long long C8 = p.C / 8;
+  const long long vecs = p.HW * C8;
+  const bf16_t* xb = p.x + (long long)n * p.HW * p.C;
+  bf16_t* yb = p.y + (long long)n * p.HW * p.C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (long long)gridDim.x * 256) {
+    const int c0 = (int)(i % C8) * 8;
+    float v[8];
+    unpack8(*(const u32x4*)(xb + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float o = v[e] * a_c[c0 + e] + b_c[c0 + e];
+      v[e] = p.silu ? silu_f(o) : o;
+    }
+    *(u32x4*)(yb + i * 8) = pack8(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- conv row gathers
+// dst[(n, yo, xo), (ky, kx, c)] = src[n, yo*stride + ky - 1, xo*stride + kx - 1, c]   (zero outside; src read at (y/2, x/2)
+// of the stored tensor when `up` (nearest x2 upsample fused in front)); columns [9C, Kpad) are zero.
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* src, bf16_t* dst, int N, int H, int W, int C, int stride, int up, int Kpad) {
+  const int Hi = up ? 2 * H : H, Wi = up ? 2 * W : W;   // logical input extent
+  const int Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
+  const int K8 = Kpad / 8, C8 = C / 8;
+  const long long total = (long long)N * Ho * Wo * K8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int kv = (int)(i % K8);
+    const long long row = i / K8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (kv < 9 * C8) {
+      const int tap = kv / C8, cv = kv - tap * C8;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int xo = (int)(row % Wo);
+      const long long r2 = row / Wo;
+      const int yo = (int)(r2 % Ho), n = (int)(r2 / Ho);
+      const int yi = yo * stride + ky - 1, xi = xo * stride + kx - 1;
+      if (yi >= 0 && yi < Hi && xi >= 0 && xi < Wi) {
+        const int ys = up ? yi >> 1 : yi, xs = up ? xi >> 1 : xi;
+        v = *(const u32x4*)(src + (((long long)n * H + ys) * W + xs) * C + cv * 8);
+      }
+    }
+    *(u32x4*)(dst + row * Kpad + kv * 8) = v;
+  }
+}
+
+// dst[(b, t, hw), (kt, c)] = src[b, t + kt - 1, hw, c]  (zero for t + kt - 1 outside [0, T))
+__global__ __launch_bounds__(256) void unfold_t3_kernel(const bf16_t* src, bf16_t* dst, int B, int T, long long HW, int C) {
+  const int C8 = C / 8;
+  const long long total = (long long)B * T * HW * 3 * C8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int kv = (int)(i % (3 * C8));
+    const long long row = i / (3 * C8);
+    const int kt = kv / C8, cv = kv - kt * C8;
+    const long long hw = row % HW;
+    const long long bt = row / HW;
+    const int t = (int)(bt % T) + kt - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t >= 0 && t < T) v = *(const u32x4*)(src + (((bt / T) * T + t) * HW + hw) * C + cv * 8);
+    *(u32x4*)(dst + row * (3LL * C) + kv * 8) = v;
+  }
+}
+
+// y[r, j] = x[r, j] * gelu_erf(x[r, inner + j])
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* x, bf16_t* y, long long rows, long long inner8) {
+  const long long total = rows * inner8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / inner8, j = i - r * inner8;
+    float a[8], g[8];
+    unpack8(*(const u32x4*)(x + (r * 2 * inner8 + j) * 8), a);
+    unpack8(*(const u32x4*)(x + (r * 2 * inner8 + inner8 + j) * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= gelu_erf_f(g[e]);
+    *(u32x4*)(y + i * 8) = pack8(a);
+  }
+}
+
+// samplers/ddim.py:236-296 (v-parameterisation):  v = v_u + s (v_c - v_u)   [cond FIRST in the batch, :219-237]
+//   eps = sa v + sb x ; x0 = (sa x - sb v) * rescale ; x <- sqrt(a_prev) x0 + dir eps + sigma noise
+__global__ __launch_bounds__(256) void ddim_v_kernel(const bf16_t* v_pred, float* x, const float* noise, long long n, float s, float sa, float sb,
+                                                     float rescale, float sqrt_aprev, float dir, float sigma) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float vc = bf2f(v_pred[i]), vu = bf2f(v_pred[n + i]);
+    const float v = vu + s * (vc - vu);
+    const float xx = x[i];
+    const float eps = sa * v + sb * xx;
+    const float x0 = (sa * xx - sb * v) * rescale;
+    x[i] = sqrt_aprev * x0 + dir * eps + (noise ? sigma * noise[i] : 0.f);
+  }
+}
+
+inline unsigned grid_for(long long items) {
+  long long b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks) {
+  if (N <= 0 || C <= 0 || chunks <= 0) return 0;
+  return N * chunks * C * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
+  if (!a || !a->x || !a->y || !a->workspace) return MRAG_EINVAL;
+  if (a->N <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->chunks <= 0) return MRAG_EINVAL;
+  if (a->C % 8 != 0 || a->C % a->G != 0) return MRAG_EINVAL;
+  if (a->C > 8192 || a->N > 65535 || a->chunks > 1024) return MRAG_ENOTSUP;
+  if (((uintptr_t)a->x | (uintptr_t)a->y) & 15) return MRAG_EINVAL;
+  GnP p{};
+  p.x = (const bf16_t*)a->x; p.y = (bf16_t*)a->y; p.gamma = (const bf16_t*)a->gamma; p.beta = (const bf16_t*)a->beta;
+  p.emb = (const bf16_t*)a->emb; p.part = (float*)a->workspace;
+  p.N = a->N; p.HW = a->HW; p.C = a->C; p.emb_stride = a->emb_stride; p.G = a->G; p.chunks = a->chunks; p.silu = a->silu; p.eps = a->eps;
+  hipStream_t s = (hipStream_t)stream;
+  MRAG_LAUNCH(gn_stats_kernel, dim3(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048)), dim3(256), 0, s, p);
+  MRAG_LAUNCH_CHECK();
+  const size_t lds = (size_t)(2 * a->C + 2 * a->G) * sizeof(float);
+  long long bx = (a->HW * (a->C / 8) + 255) / 256;
+  if (bx > 64) bx = 64;
+  MRAG_LAUNCH(gn_apply_kernel, dim3((unsigned)bx, (unsigned)a->N), dim3(256), lds, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_im2col3x3_bf16(void* stream, const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride,
+                                   int32_t upsample, int32_t Kpad) {
+  if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MRAG_EINVAL;
+  if (C % 8 != 0 || Kpad % 8 != 0 || Kpad < 9 * C || (stride != 1 && stride != 2)) return MRAG_EINVAL;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MRAG_EINVAL;
+  const int Hi = upsample ? 2 * H : H, Wi = upsample ? 2 * W : W;
+  const long long total = (long long)N * ((Hi - 1) / stride + 1) * ((Wi - 1) / stride + 1) * (Kpad / 8);
+  MRAG_LAUNCH(im2col3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, N, H, W, C, stride,
+              upsample ? 1 : 0, Kpad);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_unfold_t3_bf16(void* stream, const void* src, void* dst, int32_t B, int32_t T, int64_t HW, int32_t C) {
+  if (!src || !dst || B <= 0 || T <= 0 || HW <= 0 || C <= 0 || C % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MRAG_EINVAL;
+  const long long total = (long long)B * T * HW * 3 * (C / 8);
+  MRAG_LAUNCH(unfold_t3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, T, (long long)HW, C);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_geglu_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t inner) {
+  if (!x || !y || rows <= 0 || inner <= 0 || inner % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return MRAG_EINVAL;
+  MRAG_LAUNCH(geglu_kernel, dim3(grid_for(rows * inner / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)rows,
+              (long long)(inner / 8));
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_ddim_v_step_f32(void* stream, const void* v_pred, float* x, const float* noise, int64_t n, float guidance, float sqrt_alpha_t,
+                                    float sqrt_one_minus_alpha_t, float rescale, float sqrt_alpha_prev, float dir_coef, float sigma) {
+  if (!v_pred || !x || n <= 0) return MRAG_EINVAL;
+  MRAG_LAUNCH(ddim_v_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, x, noise, (long long)n, guidance,
+              sqrt_alpha_t, sqrt_one_minus_alpha_t, rescale, sqrt_alpha_prev, dir_coef, sigma);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}

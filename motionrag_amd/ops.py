@@ -272,3 +272,82 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
     check(L.mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
                           _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws_bytes), "mrag_topk_f32")
     return rows, dist
+
+
+# ---------------------------------------------------------------------------------------------- UNet ops (channels-last rows)
+def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int, eps: float, *, silu: bool = False,
+              emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.GroupNorm over x [N, HW, C] (channels-last) [+ per-(n, c) `emb` added before the statistics] [+ SiLU]."""
+    from ._lib import GroupNormArgs
+    _dev(x, name="x")
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("groupnorm: contiguous [N, HW, C] required")
+    N, HW, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    chunks = max(1, min(64, HW // 64))
+    L = _lib.lib()
+    ws = torch.empty(L.mrag_groupnorm_workspace_bytes(N, C, chunks), dtype=torch.uint8, device=x.device)
+    a = GroupNormArgs()
+    a.x, a.y, a.gamma, a.beta, a.workspace = _p(x), _p(out), _p(gamma), _p(beta), _p(ws)
+    a.N, a.HW, a.C, a.G, a.chunks, a.silu, a.eps = N, HW, C, groups, chunks, 1 if silu else 0, eps
+    if emb is not None:
+        _dev(emb, name="emb")
+        if emb.shape != (N, C) or emb.stride(1) != 1:
+            raise ValueError("emb must be [N, C] with contiguous channels")
+        a.emb, a.emb_stride = _p(emb), emb.stride(0)
+    check(L.mrag_groupnorm_bf16(_stream(), ctypes.byref(a)), "mrag_groupnorm_bf16")
+    return out
+
+
+def _kpad(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+def im2col3x3(x: torch.Tensor, stride: int = 1, upsample: bool = False) -> torch.Tensor:
+    """x [N, H, W, C] -> rows [N*Ho*Wo, Kpad] for the 3x3 / pad-1 convolution GEMM (Kpad = 9C rounded up to 64)."""
+    _dev(x, name="x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("im2col3x3: contiguous [N, H, W, C] required")
+    N, H, W, C = x.shape
+    Hi, Wi = (2 * H, 2 * W) if upsample else (H, W)
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    kp = _kpad(9 * C)
+    out = torch.empty(N * Ho * Wo, kp, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mrag_im2col3x3_bf16(_stream(), _p(x), _p(out), N, H, W, C, stride, 1 if upsample else 0, kp), "mrag_im2col3x3_bf16")
+    return out
+
+
+def unfold_t3(x: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """x [(b t), HW, C] -> rows [(b t hw), 3C] for the (3,1,1) temporal convolution GEMM."""
+    _dev(x, name="x")
+    if x.dim() != 3 or not x.is_contiguous() or x.shape[0] != B * T:
+        raise ValueError("unfold_t3: contiguous [(b t), HW, C] required")
+    _, HW, C = x.shape
+    out = torch.empty(B * T * HW, 3 * C, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mrag_unfold_t3_bf16(_stream(), _p(x), _p(out), B, T, HW, C), "mrag_unfold_t3_bf16")
+    return out
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, name="x")
+    if not x.is_contiguous():
+        raise ValueError("geglu: contiguous input required")
+    inner = x.shape[-1] // 2
+    out = torch.empty(*x.shape[:-1], inner, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mrag_geglu_bf16(_stream(), _p(x), _p(out), x.numel() // (2 * inner), inner), "mrag_geglu_bf16")
+    return out
+
+
+def ddim_v_step_(v_pred: torch.Tensor, x: torch.Tensor, noise: Optional[torch.Tensor], guidance: float, sqrt_alpha_t: float,
+                 sqrt_one_minus_alpha_t: float, rescale: float, sqrt_alpha_prev: float, dir_coef: float, sigma: float) -> torch.Tensor:
+    """DynamiCrafter DDIM update in place on fp32 latents x; v_pred bf16 [2, *x.shape] with the conditional half FIRST."""
+    _dev(v_pred, name="v_pred"); _dev(x, torch.float32, "x")
+    if noise is not None:
+        _dev(noise, torch.float32, "noise")
+    n = x.numel()
+    if v_pred.numel() != 2 * n or not v_pred.is_contiguous() or not x.is_contiguous():
+        raise ValueError("ddim_v_step_: v_pred must be [2, *x.shape], contiguous")
+    check(_lib.lib().mrag_ddim_v_step_f32(_stream(), _p(v_pred), _p(x), _p(noise), n, guidance, sqrt_alpha_t, sqrt_one_minus_alpha_t, rescale,
+                                          sqrt_alpha_prev, dir_coef, sigma), "mrag_ddim_v_step_f32")
+    return x

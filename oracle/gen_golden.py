@@ -202,9 +202,136 @@ def main():
     blob.update({f"sa.{k}": v.numpy() for k, v in sa.state_dict().items()})
     np.savez(os.path.join(OUT, "dc_cross_attention.npz"), x=xq.numpy(), prompt=ctx["prompt"].numpy(), image=ctx["image"].numpy(),
              action=ctx["action"].numpy(), y_cross=y_cross.numpy(), y_self=y_self.numpy(), **blob)
+    # ---- G8-G12 DynamiCrafter UNet blocks, reduced-width UNetModel, schedule tables, DDIM steps ----
+    gen_dynamicrafter(attn_mod)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
+
+
+def seeded_state(module, seed: int, std: float = 0.08):
+    """overwrite EVERY parameter (zero-initialised ones included: SURVEY App. D.6) from a seeded generator, in sorted key order;
+    norm scales get 1 + noise.  tests regenerate the same values from (keys, shapes, seed)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    new = {}
+    for k in sorted(sd):
+        v = torch.randn(sd[k].shape, generator=g) * std
+        if k.endswith("weight") and sd[k].dim() == 1:
+            v = v + 1.0
+        new[k] = v
+    module.load_state_dict(new, strict=True)
+    SEEDED_META[seed] = {"std": std, "keys": sorted(sd), "shapes": [list(sd[k].shape) for k in sorted(sd)]}
+    return new
+
+
+SEEDED_META = {}
+
+
+def gen_dynamicrafter(attn_mod):
+    import importlib
+    net = importlib.import_module("dcroot.lvdm.modules.networks.openaimodel3d")
+    ud = importlib.import_module("dcroot.lvdm.models.utils_diffusion")
+    ddim_mod = importlib.import_module("dcroot.lvdm.models.samplers.ddim")
+    gi = torch.Generator().manual_seed(201)
+    r = lambda *s: torch.randn(*s, generator=gi)
+    C, cd = 64, 96
+    ctx = {"prompt": r(4, 7, cd), "image": r(4, 5, cd), "action": r(4, 25, cd)}
+    blob = {}
+
+    # G8 transformers (in_channels 64 -> 1 head x 64)
+    st = attn_mod.SpatialTransformer(C, 1, 64, depth=1, context_dim=cd, use_linear=True, use_checkpoint=False, image_cross_attention=True,
+                                     action_cross_attention=True).eval()
+    seeded_state(st, 202)
+    x4 = r(4, C, 6, 5)
+    tt = attn_mod.TemporalTransformer(C, 2, 64, depth=1, context_dim=cd, use_linear=True, use_checkpoint=False, only_self_att=True,
+                                      relative_position=False, temporal_length=4).eval()      # inner 128 != 64, like init_attn
+    seeded_state(tt, 203)
+    x5 = r(2, C, 4, 3, 5)
+    with torch.no_grad():
+        blob.update(st_x=x4.numpy(), st_y=st(x4, ctx).numpy(), tt_x=x5.numpy(), tt_y=tt(x5).numpy())
+    blob.update({f"ctx_{k}": v.numpy() for k, v in ctx.items()})
+
+    # G9 ResBlock (+ temporal conv, skip 1x1), Downsample, Upsample
+    rb = net.ResBlock(C, 128, 0.0, out_channels=96, dims=2, use_temporal_conv=True).eval()
+    seeded_state(rb, 204)
+    rb2 = net.ResBlock(C, 128, 0.0, out_channels=C, dims=2, use_temporal_conv=False).eval()
+    seeded_state(rb2, 205)
+    dn, up = net.Downsample(C, True, dims=2, out_channels=C).eval(), net.Upsample(C, True, dims=2, out_channels=C).eval()
+    seeded_state(dn, 206); seeded_state(up, 207)
+    xr, emb = r(4, C, 6, 5), r(4, 128)
+    with torch.no_grad():
+        blob.update(rb_x=xr.numpy(), rb_emb=emb.numpy(), rb_y=rb(xr, emb, batch_size=2).numpy(), rb2_y=rb2(xr, emb, batch_size=2).numpy(),
+                    dn_y=dn(xr).numpy(), up_y=up(xr).numpy())
+    import json
+    blob["meta"] = np.array(json.dumps({name: dict(seed=seed, **SEEDED_META[seed]) for name, seed in
+                                        (("st", 202), ("tt", 203), ("rb", 204), ("rb2", 205), ("dn", 206), ("up", 207))}))
+    np.savez(os.path.join(OUT, "dc_blocks.npz"), **blob)
+
+    # G10 reduced-width UNetModel (every zero-init layer re-randomised)
+    unet = net.UNetModel(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=(1, 2), num_res_blocks=1, channel_mult=(1, 2),
+                         num_head_channels=64, transformer_depth=1, context_dim=64, use_linear=True, use_checkpoint=False, temporal_conv=True,
+                         temporal_attention=True, temporal_self_att_only=True, use_relative_position=False, temporal_length=4,
+                         addition_attention=True, image_cross_attention=True, action_cross_attention=True, default_fs=10, fs_condition=True).eval()
+    sd = seeded_state(unet, 208, std=0.05)
+    gi = torch.Generator().manual_seed(209)
+    x = torch.randn(2, 8, 4, 8, 8, generator=gi)
+    ctx = {"image": torch.randn(2, 4 * 3, 64, generator=gi), "prompt": torch.randn(2, 7, 64, generator=gi), "action": torch.randn(2, 25, 64, generator=gi)}
+    ts, fs = torch.tensor([481, 34]), torch.tensor([15, 15])
+    with torch.no_grad():
+        y = unet(x, ts, context=ctx, fs=fs)
+    keys = sorted(sd)
+    np.savez(os.path.join(OUT, "dc_unet.npz"), seed=208, std=0.05, keys=np.array(keys), shapes=np.array([list(sd[k].shape) + [0] * (5 - sd[k].dim()) for k in keys]),
+             ndims=np.array([sd[k].dim() for k in keys]), input_seed=209, timesteps=ts.numpy(), fs=fs.numpy(), y=y.numpy())
+
+    # G11 schedule tables
+    betas = ud.rescale_zero_terminal_snr(ud.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012))
+    ac = np.cumprod(1.0 - betas)
+    t30, t50 = ud.make_ddim_timesteps("uniform", 30, 1000, verbose=False), ud.make_ddim_timesteps("uniform", 50, 1000, verbose=False)
+    sig, al, alp = ud.make_ddim_sampling_parameters(torch.tensor(ac, dtype=torch.float32), t30, 1.0, verbose=False)
+    temb = ud.timestep_embedding(torch.tensor([0, 1, 481, 999]), 64)
+
+    # G12 three stochastic DDIM steps (eta = 1, CFG 2.0, v-param, dynamic rescale) against a duck-typed model
+    class Duck:
+        num_timesteps, parameterization, use_dynamic_rescale, device = 1000, "v", True, torch.device("cpu")
+
+        def __init__(self):
+            self.alphas_cumprod_np = ac
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.sqrt_alphas_cumprod = torch.tensor(np.sqrt(ac), dtype=torch.float32)
+            self.sqrt_one_minus_alphas_cumprod = torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+            self.scale_arr = torch.tensor(np.concatenate((np.linspace(1.0, 0.3, 400), np.full(1000, 0.3))), dtype=torch.float32)
+
+        def apply_model(self, x, t, c, **kw):
+            return 0.5 * x + c["shift"] * torch.cos(t.float() / 100.0).view(-1, 1, 1, 1, 1)
+
+        def predict_start_from_z_and_v(self, x, t, v):
+            return self.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * x - self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * v
+
+        def predict_eps_from_z_and_v(self, x, t, v):
+            return self.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * v + self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * x
+
+    ddim_mod.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)      # the reference forces .to("cuda")
+    smp = ddim_mod.DDIMSampler(Duck())
+    smp.make_schedule(30, ddim_eta=1.0, verbose=False)
+    gi = torch.Generator().manual_seed(210)
+    xT = torch.randn(2, 4, 4, 8, 8, generator=gi)
+    c, uc = {"shift": torch.randn(2, 1, 1, 1, 1, generator=gi)}, {"shift": torch.randn(2, 1, 1, 1, 1, generator=gi)}
+    xs, noises, x = [], [], xT
+    steps = np.flip(smp.ddim_timesteps)
+    for i in range(3):
+        index = len(steps) - i - 1
+        torch.manual_seed(300 + i)
+        noises.append(torch.randn(x.shape).numpy())
+        torch.manual_seed(300 + i)
+        tsx = torch.full((2,), int(steps[i]), dtype=torch.long)
+        x, _ = smp.p_sample_ddim(x, c, tsx, index=index, unconditional_guidance_scale=2.0, unconditional_conditioning=uc)
+        xs.append(x.numpy())
+    np.savez(os.path.join(OUT, "dc_schedule.npz"), alphas_cumprod=ac, t30=t30, t50=t50, sigmas=sig.numpy(), alphas=al.numpy(), alphas_prev=alp.numpy(),
+             temb=temb.numpy(), xT=xT.numpy(), c_shift=c["shift"].numpy(), uc_shift=uc["shift"].numpy(), noises=np.stack(noises), xs=np.stack(xs),
+             scale_arr=smp.model.scale_arr.numpy())
 
 
 if __name__ == "__main__":

@@ -187,3 +187,85 @@ def test_topk_oracle_ties_and_short_results():
     assert rows.tolist() == [[0, 1, 2, 4]] and dist.tolist() == [[0.0, 0.0, 0.0, 0.0]]     # ties by ascending row
     rows, dist = topk_ref.topk(db, q, 8, "l2", group=np.zeros(5, np.int32) + np.array([0, 0, 0, 1, 1], np.int32), exclude=np.array([0], np.int32))
     assert rows.tolist() == [[4, 3, -1, -1, -1, -1, -1, -1]] and np.isinf(dist[0, 2:]).all()
+
+
+# ---------------------------------------------------------------------------------------------- DynamiCrafter UNet (G8-G12)
+def _dc_blocks(golden_dir):
+    import json
+    from oracle.seeded import seeded_sd
+    g = _load(golden_dir, "dc_blocks.npz")
+    meta = json.loads(str(g["meta"]))
+    sds = {n: seeded_sd(m["keys"], m["shapes"], m["seed"], m["std"]) for n, m in meta.items()}
+    return g, sds
+
+
+def test_dc_transformers_match_reference(golden_dir):
+    g, sds = _dc_blocks(golden_dir)
+    ctx = {k: torch.from_numpy(g[f"ctx_{k}"]) for k in ("prompt", "image", "action")}
+    y = dynamicrafter_ref.spatial_transformer(sds["st"], torch.from_numpy(g["st_x"]), ctx, heads=1)
+    np.testing.assert_allclose(y.numpy(), g["st_y"], rtol=1e-4, atol=2e-5)
+    y = dynamicrafter_ref.temporal_transformer(sds["tt"], torch.from_numpy(g["tt_x"]), heads=2)
+    np.testing.assert_allclose(y.numpy(), g["tt_y"], rtol=1e-4, atol=2e-5)
+
+
+def test_dc_resblock_and_resample_match_reference(golden_dir):
+    g, sds = _dc_blocks(golden_dir)
+    x, emb = torch.from_numpy(g["rb_x"]), torch.from_numpy(g["rb_emb"])
+    np.testing.assert_allclose(dynamicrafter_ref.res_block(sds["rb"], x, emb, batch_size=2).numpy(), g["rb_y"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dynamicrafter_ref.res_block(sds["rb2"], x, emb, batch_size=2).numpy(), g["rb2_y"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dynamicrafter_ref.downsample(sds["dn"], x).numpy(), g["dn_y"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dynamicrafter_ref.upsample(sds["up"], x).numpy(), g["up_y"], rtol=1e-4, atol=2e-5)
+
+
+def dc_unet_fixture(golden_dir):
+    from oracle.seeded import seeded_sd
+    g = _load(golden_dir, "dc_unet.npz")
+    shapes = [s[:n].tolist() for s, n in zip(g["shapes"], g["ndims"])]
+    sd = seeded_sd([str(k) for k in g["keys"]], shapes, int(g["seed"]), float(g["std"]))
+    gi = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randn(2, 8, 4, 8, 8, generator=gi)
+    ctx = {"image": torch.randn(2, 12, 64, generator=gi), "prompt": torch.randn(2, 7, 64, generator=gi), "action": torch.randn(2, 25, 64, generator=gi)}
+    spec = dynamicrafter_ref.UNetSpec(model_channels=64, attention_resolutions=(1, 2), num_res_blocks=1, channel_mult=(1, 2), context_dim=64,
+                                      temporal_length=4)
+    return g, sd, spec, x, ctx
+
+
+def test_dc_unet_matches_reference(golden_dir):
+    g, sd, spec, x, ctx = dc_unet_fixture(golden_dir)
+    y = dynamicrafter_ref.unet_forward(sd, spec, x, torch.from_numpy(g["timesteps"]), ctx, torch.from_numpy(g["fs"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=2e-4, atol=5e-5)
+
+
+def test_dc_schedule_and_ddim_steps_match_reference(golden_dir):
+    g = _load(golden_dir, "dc_schedule.npz")
+    ac = dynamicrafter_ref.dc_schedule()
+    np.testing.assert_allclose(ac, g["alphas_cumprod"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(dynamicrafter_ref.dc_ddim_timesteps(30), g["t30"])      # 31 entries
+    np.testing.assert_array_equal(dynamicrafter_ref.dc_ddim_timesteps(50), g["t50"])
+    assert len(g["t30"]) == 31 and g["t30"][-1] == 991
+    sig, al, alp = dynamicrafter_ref.dc_ddim_params(ac, g["t30"], 1.0)
+    np.testing.assert_allclose(sig.numpy(), g["sigmas"], rtol=1e-6); np.testing.assert_allclose(al.numpy(), g["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(alp.numpy(), g["alphas_prev"], rtol=1e-6)
+    np.testing.assert_allclose(dynamicrafter_ref.timestep_embedding(torch.tensor([0, 1, 481, 999]), 64).numpy(), g["temb"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(dynamicrafter_ref.dc_scale_arr(), g["scale_arr"])
+    # three eta = 1 steps with the recorded noise
+    ac32 = torch.tensor(ac, dtype=torch.float32)
+    scale = torch.from_numpy(g["scale_arr"])
+    ts = g["t30"]
+    sc_t = scale[ts]
+    sc_prev = torch.cat([sc_t[0:1], sc_t[:-1]])
+    x = torch.from_numpy(g["xT"])
+    c, uc = torch.from_numpy(g["c_shift"]), torch.from_numpy(g["uc_shift"])
+    for i in range(3):
+        index = len(ts) - 1 - i
+        t = int(ts[index])
+        f = math_cos(t)
+        vc, vu = 0.5 * x + c * f, 0.5 * x + uc * f
+        x, _ = dynamicrafter_ref.dc_ddim_step(vc, vu, x, torch.from_numpy(g["noises"][i]), 2.0, ac32, t, sig[index], al[index], alp[index],
+                                              sc_t[index], sc_prev[index])
+        np.testing.assert_allclose(x.numpy(), g["xs"][i], rtol=1e-4, atol=1e-5)
+
+
+def math_cos(t):
+    import math
+    return math.cos(t / 100.0)

@@ -55,6 +55,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise ValueError(f"weight {tuple(weight.shape)} does not match K={K}")
+    if K % 64 != 0:   # the kernel streams whole 64-deep K-tiles: zero-pad odd reduction dims (memory only; no shipped shape needs it)
+        pad = 64 - K % 64
+        x2 = torch.nn.functional.pad(x2, (0, pad))
+        weight = torch.nn.functional.pad(weight, (0, pad))
+        K += pad
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
     o2 = _rows(out)

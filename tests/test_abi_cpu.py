@@ -115,3 +115,41 @@ def test_rag_table_io_and_filter_parsing(tmp_path):
     assert rag._WHERE_RE.match('video != "a b/c.mp4"').group(2) == "a b/c.mp4"
     assert rag._WHERE_RE.match("video != 'x'").group(2) == "x"
     assert rag._WHERE_RE.match("start_sec > 3") is None
+
+
+def test_dynamicrafter_state_dict_keys_match_reference_golden():
+    """the UNet mirrors load the reference's checkpoints: key sets (and shapes) equal those dumped from the reference classes"""
+    import json
+    from motionrag_amd import dynamicrafter as dc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dc_blocks.npz"))
+    meta = json.loads(str(g["meta"]))
+    C, cd = 64, 96
+    mods = {
+        "st": dc.SpatialTransformer(C, 1, 64, depth=1, context_dim=cd, use_linear=True, image_cross_attention=True, action_cross_attention=True),
+        "tt": dc.TemporalTransformer(C, 2, 64, depth=1, context_dim=cd, use_linear=True, temporal_length=4),
+        "rb": dc.ResBlock(C, 128, 0.0, out_channels=96, use_temporal_conv=True), "rb2": dc.ResBlock(C, 128, 0.0, out_channels=C),
+        "dn": dc.Downsample(C, True, out_channels=C), "up": dc.Upsample(C, True, out_channels=C)}
+    for name, m in mods.items():
+        sd = m.state_dict()
+        assert sorted(sd) == meta[name]["keys"], name
+        assert [list(sd[k].shape) for k in sorted(sd)] == meta[name]["shapes"], name
+    u = np.load(os.path.join(ROOT, "tests", "golden", "dc_unet.npz"))
+    unet = dc.UNetModel(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=(1, 2), num_res_blocks=1, channel_mult=(1, 2),
+                        num_head_channels=64, transformer_depth=1, context_dim=64, use_linear=True, temporal_conv=True, temporal_attention=True,
+                        temporal_self_att_only=True, use_relative_position=False, temporal_length=4, addition_attention=True,
+                        image_cross_attention=True, action_cross_attention=True, default_fs=10, fs_condition=True)
+    sd = unet.state_dict()
+    assert sorted(sd) == [str(k) for k in u["keys"]]
+    assert [list(sd[k].shape) for k in sorted(sd)] == [s[:n].tolist() for s, n in zip(u["shapes"], u["ndims"])]
+
+
+def test_dc_sampler_tables_match_reference_golden():
+    from motionrag_amd.dynamicrafter import DDIMSampler, make_alphas_cumprod
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dc_schedule.npz"))
+    np.testing.assert_allclose(make_alphas_cumprod(), g["alphas_cumprod"], rtol=1e-12, atol=1e-15)
+    s = DDIMSampler()
+    np.testing.assert_array_equal(s.make_schedule(30, 1.0), g["t30"])
+    np.testing.assert_allclose(s.ddim_sigmas, g["sigmas"], rtol=1e-6); np.testing.assert_allclose(s.ddim_alphas, g["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(s.ddim_alphas_prev, g["alphas_prev"], rtol=1e-6)
+    np.testing.assert_array_equal(s.scale_arr, g["scale_arr"])
+    np.testing.assert_array_equal(s.make_schedule(50, 0.0), g["t50"])

@@ -81,9 +81,17 @@ def test_gemm_epilogues(hip, epi, M, N, K):
 
 def test_gemm_rejects_bad_arguments(hip):
     from motionrag_amd import ops, _lib
+    import ctypes
     x, w = torch.zeros(8, 72, dtype=torch.bfloat16, device=DEV), torch.zeros(16, 72, dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(_lib.HipError, match="ENOTSUP"):
-        ops.linear(x, w)                         # K % 64 != 0
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C = x.data_ptr(), w.data_ptr(), torch.empty(8, 16, dtype=torch.bfloat16, device=DEV).data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = 8, 16, 72, 72, 72, 16
+    assert hip.mrag_gemm_bf16(None, ctypes.byref(a)) == -2          # the C ABI refuses K % 64 != 0 (MRAG_ENOTSUP) ...
+    g = torch.Generator().manual_seed(0)
+    xr, wr = bf(torch.randn(8, 72, generator=g)), bf(torch.randn(16, 72, generator=g))
+    close(ops.linear(xr.to(DEV), wr.to(DEV)), xr.float() @ wr.float().t(), scale=5.0)   # ... the host wrapper zero-pads the reduction dim
+    a.K, a.M = 64, 0
+    assert hip.mrag_gemm_bf16(None, ctypes.byref(a)) == -1          # MRAG_EINVAL
     with pytest.raises(ops.HipOnly):
         ops.linear(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(16, 64, dtype=torch.bfloat16))
 

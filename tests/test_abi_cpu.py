@@ -153,3 +153,18 @@ def test_dc_sampler_tables_match_reference_golden():
     np.testing.assert_allclose(s.ddim_alphas_prev, g["alphas_prev"], rtol=1e-6)
     np.testing.assert_array_equal(s.scale_arr, g["scale_arr"])
     np.testing.assert_array_equal(s.make_schedule(50, 0.0), g["t50"])
+
+
+def test_tuple_tensor_semantics():
+    """svd/pipelines/pipeline.py:25-57: both members move / repeat together, indexing / shape / dtype see the first"""
+    from motionrag_amd.svd import TupleTensor
+    a, b = torch.arange(6.0).view(2, 1, 3), torch.ones(2, 25, 4)
+    tt = TupleTensor([a, b])
+    assert isinstance(tt, tuple) and tt.shape == a.shape and tt.dtype == a.dtype and tt.size(2) == 3
+    assert torch.equal(tt[1], a[1]) and torch.equal(tt[None, :].reshape(1, 2, 1, 3)[:, 0], a[None, 0])
+    r = tt.repeat_interleave(3, dim=0)
+    assert isinstance(r, TupleTensor) and r.shape == (6, 1, 3) and r.to_tuple()[1].shape == (6, 25, 4)
+    h = tt.to(torch.float16)
+    assert h.dtype == torch.float16 and h.to_tuple()[1].dtype == torch.float16
+    e, ip = tt                      # how attn_processor.py:34-37 unpacks it
+    assert e is a and ip is b

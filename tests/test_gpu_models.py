@@ -216,3 +216,23 @@ def test_rag_database_text_search(hip, tmp_path):
     assert len(batch) == 40 and all(len(b) == 12 for b in batch) and all(b[0]["video"] != f"v{i // 2}.mp4" for i, b in enumerate(batch))
     with pytest.raises(NotImplementedError):
         db.text_search(text=q, where="start_sec > 3")
+
+
+def test_svd_processor_accepts_tuple_tensor(hip):
+    """the (image_emb, action_emb) pair travels as a TupleTensor through `.to` / `.repeat_interleave` (what diffusers' UNet does to
+    encoder_hidden_states) and is unpacked by the processor exactly like a plain tuple"""
+    from motionrag_amd.attn_processor import APAdapterAttnProcessor2_0, Attention
+    from motionrag_amd.svd import TupleTensor
+    g = torch.Generator().manual_seed(23)
+    C, H, cd, F = 320, 5, 1024, 3
+    attn = Attention(C, cross_attention_dim=cd, heads=H, dim_head=64, bias=False, out_bias=True)
+    attn.set_processor(APAdapterAttnProcessor2_0(C, cd))
+    for p in attn.parameters():
+        torch.nn.init.normal_(p, std=0.05, generator=g)
+    attn = attn.to(DEV, torch.bfloat16)
+    hidden = torch.randn(2 * F, 36, C, generator=g).to(DEV, torch.bfloat16)
+    img, act = torch.randn(2, 1, cd, generator=g), torch.randn(2, 25, cd, generator=g)
+    tt = TupleTensor([img, act]).to(DEV, torch.bfloat16).repeat_interleave(F, dim=0)          # [2F, 1, cd], [2F, 25, cd]
+    got = attn(hidden, tt)
+    want = attn(hidden, (img.to(DEV, torch.bfloat16).repeat_interleave(F, dim=0), act.to(DEV, torch.bfloat16)))   # r = F broadcast inside
+    close_exactish(got, want, rtol=1e-6, atol_frac=1e-6)

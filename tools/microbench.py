@@ -72,6 +72,38 @@ def norm():
     print(f"qknorm_rope: {dt*1e6:.1f} us  {2*(qkv.numel()*2//3)*2/dt/1e9:.0f} GB/s")
 
 
+
+
+def unet():
+    """DynamiCrafter-1024 UNet + CAMA tokens, one CFG denoise step at 16x576x1024 (x [2, 8, 16, 72, 128]), random-init weights"""
+    from motionrag_amd import dynamicrafter as dc
+    torch.manual_seed(0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(DEV):
+        net = dc.UNetModel(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1), num_res_blocks=2,
+                           channel_mult=(1, 2, 4, 4), num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
+                           temporal_conv=True, temporal_attention=True, temporal_self_att_only=True, use_relative_position=False,
+                           temporal_length=16, addition_attention=True, image_cross_attention=True, action_cross_attention=True,
+                           default_fs=10, fs_condition=True)
+    torch.set_default_dtype(old)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+            elif n.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02)
+    x = torch.randn(2, 8, 16, 72, 128, device=DEV).to(torch.bfloat16)
+    ctx = {"prompt": torch.randn(2, 77, 1024, device=DEV).to(torch.bfloat16), "image": torch.randn(2, 16 * 16, 1024, device=DEV).to(torch.bfloat16),
+           "action": torch.randn(2, 25, 1024, device=DEV).to(torch.bfloat16)}
+    ts = torch.tensor([481.0, 481.0], device=DEV)
+    fs = torch.tensor([15, 15], device=DEV)
+    dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=3, warm=1)
+    print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {105.7/dt:.0f} TFLOP/s of 105.7 TFLOP algorithmic  -> {16/dt:.1f} frames/s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

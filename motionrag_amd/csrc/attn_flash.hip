@@ -29,6 +29,22 @@
 #include "../../include/mrag_hip.h"
 #include <stdlib.h>
 
+#ifdef MRAG_ATTN_STAMPS
+// diagnostic build only (tools/build_diag.sh): per-phase s_memtime sums of the long-sequence loop; never compiled into the product
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)); }
+#define MRAG_STAMP(T)                                                                  \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#endif
+
+#ifndef MRAG_ATTN_WPS
+#define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
+#endif
+
 namespace {
 
 struct AttnP {
@@ -41,7 +57,7 @@ struct AttnP {
 constexpr float kThr = 5.0f;          // deferred-rescale threshold in log2 units (P <= 32)
 constexpr int KVB = 64;               // keys per tile
 constexpr int TILE_BYTES = KVB * 128; // one K (or V) tile
-constexpr int NS = 5;                 // LDS ring stages per operand (DMA runs D = NS-2 tiles ahead)
+constexpr int NS = MRAG_ATTN_WPS >= 4 ? 4 : 5;   // LDS ring stages per operand (DMA runs D = NS-2 tiles ahead); 2 x 64 KB fit two workgroups per CU
 constexpr int V_BASE = NS * TILE_BYTES;  // LDS: K stages 0..NS-1, then V stages 0..NS-1
 
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float s) {
@@ -82,6 +98,30 @@ struct NoHook {
 template <typename Between = NoHook>
 __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const bf16x8 (&qf)[4], const f32x16& negm, f32x16& s0, f32x16& s1,
                                         Between between = Between()) {
+#if MRAG_ATTN_WPS >= 4
+  // register-lean form (4 waves per SIMD hide the LDS latency): one 32-key block at a time
+  const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
+  const unsigned b0 = base + ((0 + ln.hh) ^ ln.k_swz) * 16, b1 = base + ((2 + ln.hh) ^ ln.k_swz) * 16;
+  const unsigned b2 = base + ((4 + ln.hh) ^ ln.k_swz) * 16, b3 = base + ((6 + ln.hh) ^ ln.k_swz) * 16;
+  u32x4 kf[4];
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+               : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");
+  between();
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C
+  const float nm = negm[0];   // register-lean form: the running max is one VGPR and is subtracted after the chain
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
+  asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\tds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
+#else
   u32x4 k0f[4], k1f[4];
   const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
   const unsigned a0 = base + ((0 + ln.hh) ^ ln.k_swz) * 16, a1 = base + ((2 + ln.hh) ^ ln.k_swz) * 16;
@@ -110,12 +150,37 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
     s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0f[ks]), qf[ks], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1f[ks]), qf[ks], s1, 0, 0, 0);
   }
+#endif
 }
 
 // O^T += V^T . P^T (8 MFMAs).  The 16 transposed reads go through ONE asm statement: hipcc cannot see that the
 // ds_read_tr16 builtin does not alias the in-flight LDS-DMA of later tiles and would drain it (s_waitcnt vmcnt(0))
 // in the middle of the tile.  EXEC is all ones here (wave-uniform control flow only).
-__device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
+__device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1, f32x16& lacc) {
+#if MRAG_ATTN_WPS >= 4
+  {
+    const unsigned c0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0), c1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      u32x2 u0[4], u1[4];
+      const unsigned d0 = c0 + half * 4096, d1 = c1 + half * 4096;
+      asm volatile("ds_read_b64_tr_b16 %0, %8 offset:0\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                   "ds_read_b64_tr_b16 %4, %9 offset:0\n\tds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
+                   "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
+                   "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                   : "v"(d0), "v"(d1) : "memory");
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const u32x4 w0 = {u0[2 * k2][0], u0[2 * k2][1], u0[2 * k2 + 1][0], u0[2 * k2 + 1][1]};
+        const u32x4 w1 = {u1[2 * k2][0], u1[2 * k2][1], u1[2 * k2 + 1][0], u1[2 * k2 + 1][1]};
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
+      }
+    }
+  }
+#else
   u32x2 t0[8], t1[8];
   const unsigned a0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0);
   const unsigned a1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
@@ -147,12 +212,17 @@ __device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const b
     const u32x4 w1 = {t1[2 * kk][0], t1[2 * kk][1], t1[2 * kk + 1][0], t1[2 * kk + 1][1]};
     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[kk], o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[kk], o1, 0, 0, 0);
+    // row sums on the (under-used) matrix pipe instead of 32 v_add per tile on the (saturated) vector pipe: A = all-ones
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[kk], lacc, 0, 0, 0);
   }
+#endif
 }
 
 struct Run {
   f32x16 o0, o1, negm;
-  float m, l;
+  f32x16 lacc;   // row sums, accumulated by the matrix pipe: lacc = ones . P^T (every register of a lane holds l of its query)
+  float m;
 };
 
 // softmax bookkeeping of one tile: masks, tile max, deferred rescale, P = exp2(S'), row sum, bf16 B fragments.
@@ -160,13 +230,17 @@ struct Run {
 template <bool HAS_MASK, bool HAS_NEXT, typename Mid = NoHook>
 __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int t, int nt, int qrow_c, f32x16& s0, f32x16& s1, f32x16& n0,
                                              f32x16& n1, Run& r, bf16x8 (&pb)[4], Mid mid = Mid()) {
-  const int kbase_idx = t * KVB + 4 * ln.hh;
+  // key held by register i of block kb: tile_start + kb*32 + (i&3) + 8*(i>>2) + 4*hh; the last tile of a long sequence starts at
+  // Skv-64 (slid back), keys before t*64 were already consumed by the previous tile
+  const int tile_start = p.Skv >= KVB ? (t * KVB < p.Skv - KVB ? t * KVB : p.Skv - KVB) : 0;
+  const int kbase_idx = tile_start + 4 * ln.hh;
   if (t == nt - 1 && (p.Skv & (KVB - 1))) {
+    const int lo = t * KVB;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
-      if (key >= p.Skv) s0[i] = -INFINITY;
-      if (key + 32 >= p.Skv) s1[i] = -INFINITY;
+      if (key < lo || key >= p.Skv) s0[i] = -INFINITY;
+      if (key + 32 < lo || key + 32 >= p.Skv) s1[i] = -INFINITY;
     }
   }
   if constexpr (HAS_MASK) {
@@ -197,28 +271,44 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
     const float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
     if (!first) {
       const float alpha = __builtin_amdgcn_exp2f(-delta);
-      r.l *= alpha;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { r.o0[i] *= alpha; r.o1[i] *= alpha; }
+#if MRAG_ATTN_WPS >= 4
+      r.lacc[0] *= alpha;
+#else
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r.lacc[i] *= alpha;
+#endif
     }
     r.m += delta;
+#if MRAG_ATTN_WPS >= 4
+    r.negm[0] = -r.m;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+#else
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; r.negm[i] = -r.m; }
+#endif
     if constexpr (HAS_NEXT) {  // the prefetched S' of tile t+1 was formed against the old max
 #pragma unroll
       for (int i = 0; i < 16; ++i) { n0[i] -= delta; n1[i] -= delta; }
     }
   }
   mid();  // staggered waves rendezvous here (between the max / rescale head and the exp body)
+#if MRAG_ATTN_WPS >= 4
   float la = 0.f, lb = 0.f;
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     s0[i] = __builtin_amdgcn_exp2f(s0[i]);
     s1[i] = __builtin_amdgcn_exp2f(s1[i]);
-    la += s0[i];
-    lb += s1[i];
+#if MRAG_ATTN_WPS >= 4
+    la += s0[i]; lb += s1[i];
+#endif
   }
-  r.l += la + lb;
+#if MRAG_ATTN_WPS >= 4
+  r.lacc[0] += la + lb;   // lane-local half of the row sum; the two half-waves are combined in the epilogue
+#endif
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     u32x4 w0, w1;
@@ -235,7 +325,7 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
 // SHORTKV: key sets of at most one tile (motion tokens, text, temporal frames) -- same code, no barrier stagger; a separate
 // instantiation so that profiles list the HBM-bound small-KV launches apart from the MFMA-bound long-sequence ones.
 template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATTN_WPS : 1) void attn_fwd_kernel(const AttnP p) {
   constexpr int PPW = NW >= 8 ? 1 : 8 / NW;  // 1 KiB DMA pieces per wave per K (or V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -285,35 +375,40 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
     k_loff[i] = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;
     v_loff[i] = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8) * 2u;
   }
+  // A partial last tile is SLID BACK to keys [Skv-64, Skv) (its already-seen keys are masked in softmax_tile), and prefetches past
+  // the end re-read that tile: every DMA of a >= 64-key sequence is a full in-range tile -> scalar tile base + loop-invariant
+  // per-lane offset, no per-lane clamping (no 64-bit lane arithmetic, nothing to spill).  Shorter key sets clamp rows instead.
+  const int last_start = p.Skv - KVB;
+  const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_k = [&](int stage, int t) {
-    if ((t + 1) * KVB <= p.Skv) {   // whole tile in range (wave-uniform): scalar tile base + invariant lane offset
-      const char* tile = (const char*)kbase + (long long)t * KVB * p.k_ss * 2;
+    if (last_start >= 0) {
+      const int start = t * KVB < last_start ? t * KVB : last_start;
+      const char* tile = (const char*)kbase + (long long)start * p.k_ss * 2;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) glds16(tile + k_loff[i], smem + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
+      for (int i = 0; i < PPW; ++i) glds16_sbase(tile, k_loff[i], lds0 + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
     } else {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
         const int piece = (wave + i * NW) & 7;
         const int kit = piece * 8 + prow;
-        long long key = (long long)t * KVB + kit;
-        key = key < p.Skv ? key : p.Skv - 1;  // tail keys re-read a valid row; their scores are masked
-        glds16(kbase + key * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8, smem + stage * TILE_BYTES + piece * 1024);
+        const int key = kit < p.Skv ? kit : p.Skv - 1;  // rows past the end re-read a valid row; their scores are masked
+        glds16(kbase + (long long)key * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8, smem + stage * TILE_BYTES + piece * 1024);
       }
     }
   };
   auto issue_v = [&](int stage, int t) {
-    if ((t + 1) * KVB <= p.Skv) {
-      const char* tile = (const char*)vbase + (long long)t * KVB * p.v_ss * 2;
+    if (last_start >= 0) {
+      const int start = t * KVB < last_start ? t * KVB : last_start;
+      const char* tile = (const char*)vbase + (long long)start * p.v_ss * 2;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) glds16(tile + v_loff[i], smem + V_BASE + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
+      for (int i = 0; i < PPW; ++i) glds16_sbase(tile, v_loff[i], lds0 + V_BASE + stage * TILE_BYTES + ((wave + i * NW) & 7) * 1024);
     } else {
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
         const int piece = (wave + i * NW) & 7;
         const int kit = piece * 8 + prow;
-        long long key = (long long)t * KVB + kit;
-        key = key < p.Skv ? key : p.Skv - 1;
-        glds16(vbase + key * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8, smem + V_BASE + stage * TILE_BYTES + piece * 1024);
+        const int key = kit < p.Skv ? kit : p.Skv - 1;
+        glds16(vbase + (long long)key * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8, smem + V_BASE + stage * TILE_BYTES + piece * 1024);
       }
     }
   };
@@ -331,18 +426,36 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
 
   Run r;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { r.o0[i] = 0.f; r.o1[i] = 0.f; r.negm[i] = 0.f; }
-  r.m = 0.f; r.l = 0.f;
+  for (int i = 0; i < 16; ++i) { r.o0[i] = 0.f; r.o1[i] = 0.f; r.negm[i] = 0.f; r.lacc[i] = 0.f; }
+  r.m = 0.f;
 
   // ---- main loop.  K and V each own a ring of NS stages; the DMA runs D = NS-1 tiles ahead of the compute and is
   // retired by a COUNTED vmcnt (every wave issues exactly 2*PPW DMA instructions per tile pair, tiles past the end
   // re-read clamped rows so the count never changes) + a raw s_barrier: __syncthreads() would drain the queue.
   const int nt = (p.Skv + KVB - 1) / KVB;
+#ifndef MRAG_ATTN_STAGGER
+  constexpr int D = NS - 1;   // without the half-tile stagger the stage refilled after barrier #t is the one read in iteration t-1
+#else
   constexpr int D = NS - 2;
+#endif
+#ifdef MRAG_ATTN_STAMPS
+  unsigned long long vm_wait = 0, bar_wait = 0;
+#endif
   auto wait_pair = [&]() {   // all but the (D-1) youngest tile pairs of this wave have landed; then rendezvous
+#ifdef MRAG_ATTN_STAMPS
+    unsigned long long w0, w1, w2;
+    MRAG_STAMP(w0);
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (D - 1)) : "memory");
+#ifdef MRAG_ATTN_STAMPS
+    MRAG_STAMP(w1);
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef MRAG_ATTN_STAMPS
+    MRAG_STAMP(w2);
+    vm_wait += w1 - w0; bar_wait += w2 - w1;
+#endif
   };
   if constexpr (!PIPE) {
     // iteration t reads K(t), V(t) from stage t % NS.  Barrier #j guarantees tile j has landed for every wave; after it each
@@ -350,26 +463,61 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
     // NW/2..NW-1, the SIMD partners of the early half) runs HALF A TILE BEHIND: it takes barrier #j in the middle of its
     // softmax(j-1), so while one wave of a SIMD is in its MFMA phase (QK^T / PV) its partner is in its exp/convert phase,
     // instead of both queueing on the same pipe right after a common barrier.
+#ifndef MRAG_ATTN_STAGGER   // measured: with two independent workgroups per CU the half-tile stagger LOSES 9 % (A/B, one device)
+    const bool late = false;
+#else
     const bool late = NW >= 8 && !SHORTKV && wave >= NW / 2;
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) { issue_k(i, i); issue_v(i, i); }
     if (late) { wait_pair(); issue_k(D % NS, D); issue_v(D % NS, D); }   // barrier #0
+#ifdef MRAG_ATTN_STAMPS
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, ta, tb, tc, td, te, tg;
+#endif
     for (int t = 0; t < nt; ++t) {
+#ifdef MRAG_ATTN_STAMPS
+      MRAG_STAMP(ta);
+#endif
       if (!late) wait_pair();   // barrier #t
+#ifdef MRAG_ATTN_STAMPS
+      MRAG_STAMP(tb);
+#endif
       auto early_issue = [&]() {
         if (!late) { issue_k((t + D) % NS, t + D); issue_v((t + D) % NS, t + D); }
       };
       auto mid = [&]() {
+#ifdef MRAG_ATTN_STAMPS
+        MRAG_STAMP(td);
+#endif
         if (late) { wait_pair(); issue_k((t + 1 + D) % NS, t + 1 + D); issue_v((t + 1 + D) % NS, t + 1 + D); }   // barrier #(t+1)
+#ifdef MRAG_ATTN_STAMPS
+        MRAG_STAMP(te);
+#endif
       };
       if (!wave_active) { early_issue(); mid(); continue; }
       f32x16 s0, s1;
       bf16x8 pb[4];
       qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
+#ifdef MRAG_ATTN_STAMPS
+      MRAG_STAMP(tc);
+#endif
       softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
-      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1);
+      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
+#ifdef MRAG_ATTN_STAMPS
+      MRAG_STAMP(tg);
+      acc_t[0] += tb - ta; acc_t[1] += tc - tb; acc_t[2] += td - tc; acc_t[3] += te - td; acc_t[4] += tg - te; acc_t[5] += tg - ta;
+#endif
     }
-    if (!late && NW >= 8 && !SHORTKV) __builtin_amdgcn_s_barrier();   // barrier #nt pairs with the late half's last rendezvous
+#ifdef MRAG_ATTN_STAMPS
+    if (g_stamp_buf && lane == 0 && blockIdx.x < 2048) {
+      for (int k = 0; k < 6; ++k) g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + k] = acc_t[k];
+      g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + 6] = nt;
+      g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + 7] = (vm_wait << 32) | (bar_wait & 0xffffffffull);
+    }
+#endif
+#ifdef MRAG_ATTN_STAGGER
+    if (!late && NW >= 8 && !SHORTKV) __builtin_amdgcn_s_barrier();
+#endif   // barrier #nt pairs with the late half's last rendezvous
   } else {
     // software-pipelined: iteration t issues QK^T(t+1) (matrix pipe) ahead of softmax(t) (vector pipe) and PV(t).
     // It reads K(t+1), V(t) and issues the pair [K(t+D+1), V(t+D)] into the stages of K(t), V(t-1) (read in iteration t-1).
@@ -392,7 +540,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
       } else {
         softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, c0, c1, c0, c1, r, pb);
       }
-      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1);
+      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
     };
     for (int t = 0; t < nt; t += 2) {
       step(t, sA0, sA1, sB0, sB1);
@@ -402,13 +550,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
 
   if (!wave_active) return;
-  // ---- epilogue: combine the two half-waves' row sums, normalise, fused residual, 8-byte stores
-  {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r.l), __float_as_uint(r.l), false, false);
-    r.l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-  }
+  // ---- epilogue: normalise by the MFMA-accumulated row sum (already complete over both half-waves' keys), fused residual
   if (qrow >= p.Sq) return;
-  const float inv = p.out_scale / r.l;
+#if MRAG_ATTN_WPS >= 4
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r.lacc[0]), __float_as_uint(r.lacc[0]), false, false);
+    r.lacc[0] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+#endif
+  const float inv = p.out_scale / r.lacc[0];
   const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * ln.hh;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
@@ -474,6 +624,9 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   bool pipe = false;
   if (const char* e = getenv("MRAG_ATTN_PIPE")) pipe = e[0] == '1';
   if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);
+  int nw_big = 8;
+  if (const char* e = getenv("MRAG_ATTN_NW")) nw_big = atoi(e);   // tuning knob (tools/microbench.py)
+  if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
   if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
   if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
   return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);

@@ -44,6 +44,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
 }
 
+// same copy with the SCALAR-base form: source = sbase (wave-uniform, SGPR pair) + voff (32-bit per-lane byte offset).  Keeps
+// loop-invariant lane offsets in ONE VGPR each instead of 64-bit VGPR pointers that hipcc recomputes / spills per tile (its spill
+// reloads come with s_waitcnt vmcnt(0), which would drain the DMA ring).  The statement is invisible to hipcc's vmcnt bookkeeping:
+// the caller retires it with its own counted s_waitcnt.  M0 (LDS destination base) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
 // bijective XCD-aware remap of a 1-D grid: blocks with equal (id % 8) share an
 // XCD's L2, so give each XCD one contiguous chunk of the logical tile space.
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -1,0 +1,10 @@
+# developer tool: build a library variant for interleaved A/B runs:  tools/build_variant.sh <name> [extra hipcc flags for attn_flash.hip / gemm]
+cd "$(dirname "$0")/.."
+NAME=$1; shift
+OBJ=/tmp/mrag_variant_$NAME; mkdir -p $OBJ
+for f in api gemm_bf16 attn_flash norm pointwise topk unet_ops; do
+  EXTRA=""; [ $f = attn_flash ] && EXTRA="-fno-slp-vectorize"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment $EXTRA "$@" -c motionrag_amd/csrc/$f.hip -o $OBJ/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lib_$NAME.so $OBJ/*.o && echo built tools/lib_$NAME.so

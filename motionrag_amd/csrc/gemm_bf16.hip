@@ -16,13 +16,27 @@
 #include "../../include/mrag_hip.h"
 #include <stdlib.h>
 
+#ifdef MRAG_GEMM_STAMPS
+// diagnostic build only (tools/build_diag.sh): per-phase s_memtime sums of the 256x256 main loop; never compiled into the product
+__device__ unsigned long long* g_gemm_stamp_buf = nullptr;
+extern "C" int mrag_debug_set_gemm_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp_buf), &p, sizeof(p)); }
+#define MRAG_GSTAMP(T)                                                                 \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define MRAG_GSTAMP(T) do {} while (0)
+#endif
+
 namespace {
 
 struct GemmP {
   const bf16_t* A; const bf16_t* W; const bf16_t* bias; bf16_t* C; const bf16_t* resid;
   const bf16_t* gate0; const bf16_t* gate1;
   long long M, N, K, lda, ldw, ldc, ldr, rows_per_batch, split, gate_stride;
-  int tiles_m, tiles_n, group_m;
+  int tiles_m, tiles_n, group_m, staged;
 };
 
 template <int EPI>
@@ -103,9 +117,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     // COUNTED s_waitcnt lgkmcnt(N) (LDS reads return in order), the second k-step's 12 reads are issued while the first
     // k-step's MFMAs run -> the LDS latency is paid once per K-tile instead of eight times (hipcc's own schedule: read
     // pair -> lgkmcnt(0) -> 8 MFMAs).  At most 15 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
+#ifdef MRAG_GEMM_STAMPS
+    unsigned long long g_acc[4] = {0, 0, 0, 0}, g0, g1, g2, g3, g4;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+      MRAG_GSTAMP(g0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MRAG_GSTAMP(g1);
       __syncthreads();  // tile kt landed for every wave; everyone finished reading the other stage
+      MRAG_GSTAMP(g2);
       const unsigned st = (unsigned)(size_t)(smem + (kt & 1) * STAGE_BYTES);
       const unsigned c0 = ((frag_q + 0) ^ swz) * 16, c1 = ((frag_q + 4) ^ swz) * 16;
       const unsigned aA0 = st + a_off + c0, aA1 = st + a_off + c1;
@@ -130,17 +150,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[I][j] =                                                                 \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[j]), __builtin_bit_cast(bf16x8, X), acc[I][j], 0, 0, 0)
       MRAG_READ12(w0, a0, aW0, aA0);
-      if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);   // DMA of the next K-tile, behind the first fragment reads
-      MRAG_WAIT_W(7, w0, a0[0]); MRAG_ROW(0, w0, a0[0]);
-      MRAG_WAIT_A(6, a0[1]); MRAG_ROW(1, w0, a0[1]);
-      MRAG_WAIT_A(5, a0[2]); MRAG_ROW(2, w0, a0[2]);
-      MRAG_WAIT_A(4, a0[3]); MRAG_ROW(3, w0, a0[3]);
+      // the 8 LDS-DMA pieces of the next K-tile are issued ONE PER ROW GROUP, between the MFMAs: a burst of 8 right after the
+      // barrier costs ~100 cycles each (measured with s_memtime stamps: 900 cycles before the first MFMA), all of it exposed
+      const bool more = kt + 1 < nk;
+      char* nbase = smem + ((kt + 1) & 1) * STAGE_BYTES;
+#define MRAG_PIECE(I) if (more) glds16(gsrc[I] + (long long)(kt + 1) * BK, nbase + (wave + (I) * NW) * 1024)
+      MRAG_WAIT_W(7, w0, a0[0]);
+      MRAG_GSTAMP(g3);
+      MRAG_ROW(0, w0, a0[0]); MRAG_PIECE(0);
+      MRAG_WAIT_A(6, a0[1]); MRAG_ROW(1, w0, a0[1]); MRAG_PIECE(1);
+      MRAG_WAIT_A(5, a0[2]); MRAG_ROW(2, w0, a0[2]); MRAG_PIECE(2);
+      MRAG_WAIT_A(4, a0[3]); MRAG_ROW(3, w0, a0[3]); MRAG_PIECE(3);
       MRAG_WAIT_A(3, a0[4]); MRAG_ROW(4, w0, a0[4]);
       MRAG_READ12(w1, a1, aW1, aA1);                  // 3 + 12 = 15 outstanding
-      MRAG_WAIT_A(14, a0[5]); MRAG_ROW(5, w0, a0[5]);
-      MRAG_WAIT_A(13, a0[6]); MRAG_ROW(6, w0, a0[6]);
-      MRAG_WAIT_A(12, a0[7]); MRAG_ROW(7, w0, a0[7]);
-      MRAG_WAIT_W(7, w1, a1[0]); MRAG_ROW(0, w1, a1[0]);
+      MRAG_WAIT_A(14, a0[5]); MRAG_ROW(5, w0, a0[5]); MRAG_PIECE(4);
+      MRAG_WAIT_A(13, a0[6]); MRAG_ROW(6, w0, a0[6]); MRAG_PIECE(5);
+      MRAG_WAIT_A(12, a0[7]); MRAG_ROW(7, w0, a0[7]); MRAG_PIECE(6);
+      MRAG_WAIT_W(7, w1, a1[0]); MRAG_ROW(0, w1, a1[0]); MRAG_PIECE(7);
       MRAG_WAIT_A(6, a1[1]); MRAG_ROW(1, w1, a1[1]);
       MRAG_WAIT_A(5, a1[2]); MRAG_ROW(2, w1, a1[2]);
       MRAG_WAIT_A(4, a1[3]); MRAG_ROW(3, w1, a1[3]);
@@ -148,11 +174,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       MRAG_WAIT_A(2, a1[5]); MRAG_ROW(5, w1, a1[5]);
       MRAG_WAIT_A(1, a1[6]); MRAG_ROW(6, w1, a1[6]);
       MRAG_WAIT_A(0, a1[7]); MRAG_ROW(7, w1, a1[7]);
+#undef MRAG_PIECE
+#ifdef MRAG_GEMM_STAMPS
+      MRAG_GSTAMP(g4);
+      g_acc[0] += g1 - g0; g_acc[1] += g2 - g1; g_acc[2] += g3 - g2; g_acc[3] += g4 - g3;
+#endif
 #undef MRAG_READ12
 #undef MRAG_WAIT_W
 #undef MRAG_WAIT_A
 #undef MRAG_ROW
     }
+#ifdef MRAG_GEMM_STAMPS
+    if (g_gemm_stamp_buf && lane == 0 && blockIdx.x < 1024) {
+      for (int k = 0; k < 4; ++k) g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + k] = g_acc[k];
+      g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + 4] = nk;
+    }
+#endif
   } else {
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,6 +214,82 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   }
 
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n0 + (lane >> 4) * 4 + {0..3}
+  constexpr bool STAGED = (TM == 8 && TN == 4 && WM == 2 && WN == 4);
+  if (STAGED && p.staged) {
+    // The accumulator layout gives 8-byte pieces of 16 different rows per store instruction (32-byte row segments): the store
+    // tail was ~24 % of a K = 3072 workgroup.  Stage the wave's 128 x 64 bf16 tile through LDS (row pitch 144 B) and write
+    // whole 128-byte row segments with 16-byte lanes; bias / activation / gate are applied in the accumulator layout, the
+    // residual add in the row layout (same rounding points as the reference's bf16 tensors: gate * out, then + residual).
+    constexpr int ROWB = 144;
+    char* wbase = smem + wave * (128 * ROWB);
+    __syncthreads();   // every wave is done with the operand stages that these per-wave regions overlay
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
+      const bf16_t* gate = nullptr;
+      if constexpr (EPI == MRAG_EPI_GATE_RESID) {
+        const long long mc = m < p.M ? m : p.M - 1;
+        const long long b = mc / p.rows_per_batch, pos = mc - b * p.rows_per_batch;
+        gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        long long n = bn0 + wn * TN * 16 + j * 16 + frag_q * 4;
+        n = n < p.N ? n : p.N - 4;   // clamped columns are never stored
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (p.bias) {
+          const u32x2 bb = *(const u32x2*)(p.bias + n);
+          v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+          v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+        if constexpr (EPI == MRAG_EPI_GATE_RESID) {
+          const u32x2 gg = *(const u32x2*)(gate + n);
+          v[0] *= __uint_as_float(gg[0] << 16); v[1] *= __uint_as_float(gg[0] & 0xffff0000u);
+          v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
+        }
+        u32x2 out;
+        out[0] = pack_bf2(v[0], v[1]);
+        out[1] = pack_bf2(v[2], v[3]);
+        *(u32x2*)(wbase + (i * 16 + frag_row) * ROWB + (j * 16 + frag_q * 4) * 2) = out;
+      }
+    }
+    // row layout: lane -> row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7): one instruction = 8 x 128 contiguous bytes
+    const int rsub = lane >> 3, chunk = lane & 7;
+    const long long n = bn0 + wn * TN * 16 + chunk * 8;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+      const int row = g * 8 + rsub;
+      const long long m = bm0 + wm * TM * 16 + row;
+      u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
+      if (m < p.M && n + 8 <= p.N) {
+        if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
+          const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(rr[e] << 16);
+            const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u);
+            val[e] = pack_bf2(lo, hi);
+          }
+        }
+        *(u32x4*)(p.C + m * p.ldc + n) = val;
+      } else if (m < p.M && n + 4 <= p.N) {   // N % 8 == 4 tail
+        u32x2 half = {val[0], val[1]};
+        if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
+          const u32x2 rr = *(const u32x2*)(p.resid + m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float lo = __uint_as_float(half[e] << 16) + __uint_as_float(rr[e] << 16);
+            const float hi = __uint_as_float(half[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u);
+            half[e] = pack_bf2(lo, hi);
+          }
+        }
+        *(u32x2*)(p.C + m * p.ldc + n) = half;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
@@ -225,7 +338,11 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   p.group_m = 4;
   if (const char* e = getenv("MRAG_GEMM_GROUP_M")) p.group_m = atoi(e) > 0 ? atoi(e) : 4;   // tuning knob
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
-  const size_t lds = 2 * (BM + BN) * 64 * 2;
+  // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
+  p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
+  if (getenv("MRAG_GEMM_NO_STAGED")) p.staged = 0;   // tuning knob
+  const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
+  const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
 #define MRAG_GEMM_CASE(E)                                                                              \
   case E: {                                                                                            \
     auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E>;                                                    \
@@ -272,6 +389,9 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // big problems: 256x256 tiles, 8 waves (1 workgroup per CU); small ones: 128x128, 4 waves,
   // so that a few hundred rows still spread over the 256 CUs.
   const long long t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  if (const char* e = getenv("MRAG_GEMM_CFG")) {   // tuning knob (tools/microbench.py)
+    if (e[0] == '1' && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
+  }
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);
 }

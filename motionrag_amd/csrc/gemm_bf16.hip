@@ -29,6 +29,14 @@ extern "C" int mrag_debug_set_gemm_stamp_buffer(void* p) { return (int)hipMemcpy
 #else
 #define MRAG_GSTAMP(T) do {} while (0)
 #endif
+#ifndef MRAG_GEMM_TRACE
+#define MRAG_GEMM_TRACE 0
+#endif
+#ifdef MRAG_GEMM_SAMEK   // diagnostic only: every K-tile re-reads tile 0 (always L2-resident) to separate memory latency from sync cost
+#define MRAG_DIAG_KSTEP 0
+#else
+#define MRAG_DIAG_KSTEP BK
+#endif
 
 namespace {
 
@@ -58,6 +66,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MRAG_GEMM_STAMPS
+  unsigned long long g_entry, g_loop0 = 0, g_loop1 = 0, g_exit;
+  MRAG_GSTAMP(g_entry);
+#endif
   const int wm = wave / WN, wn = wave % WN;
 
   const int nwg = p.tiles_m * p.tiles_n;
@@ -117,20 +129,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     // COUNTED s_waitcnt lgkmcnt(N) (LDS reads return in order), the second k-step's 12 reads are issued while the first
     // k-step's MFMAs run -> the LDS latency is paid once per K-tile instead of eight times (hipcc's own schedule: read
     // pair -> lgkmcnt(0) -> 8 MFMAs).  At most 15 LDS reads are outstanding (lgkmcnt is a 4-bit counter).
+    //
+    // Software pipeline across the per-tile barrier: the fragments of k-step (t, 0) are already in registers when tile t's MFMAs
+    // start, the reads of (t, 1) fly under the 32 MFMAs of (t, 0), and the ONE barrier per K-tile sits between the two k-steps:
+    // behind it every wave has finished reading stage t (so the DMA of tile t+2 may overwrite it) and tile t+1 has landed (so
+    // the reads of (t+1, 0) are issued right there, under the MFMAs of (t, 1)).  No fragment latency is exposed at the tile
+    // boundary (measured before: ~350 cycles of first-fragment wait + ~500 of barrier per 2048-cycle MFMA body).
 #ifdef MRAG_GEMM_STAMPS
-    unsigned long long g_acc[4] = {0, 0, 0, 0}, g0, g1, g2, g3, g4;
+    unsigned long long g_acc[5] = {0, 0, 0, 0, 0}, g0, g1, g2, g3, g4, g5;
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
-      MRAG_GSTAMP(g0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      MRAG_GSTAMP(g1);
-      __syncthreads();  // tile kt landed for every wave; everyone finished reading the other stage
-      MRAG_GSTAMP(g2);
-      const unsigned st = (unsigned)(size_t)(smem + (kt & 1) * STAGE_BYTES);
-      const unsigned c0 = ((frag_q + 0) ^ swz) * 16, c1 = ((frag_q + 4) ^ swz) * 16;
-      const unsigned aA0 = st + a_off + c0, aA1 = st + a_off + c1;
-      const unsigned aW0 = st + (w_off - BM * 128) + c0, aW1 = st + (w_off - BM * 128) + c1;
-      u32x4 w0[4], a0[8], w1[4], a1[8];
 #define MRAG_READ12(W, A, AW, AA)                                                                                   \
       asm volatile(                                                                                                  \
           "ds_read_b128 %0, %12 offset:32768\n\tds_read_b128 %1, %12 offset:34816\n\t"                               \
@@ -143,51 +150,91 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
             "=&v"(A[4]), "=&v"(A[5]), "=&v"(A[6]), "=&v"(A[7])                                                       \
           : "v"(AW), "v"(AA)                                                                                         \
           : "memory")
-#define MRAG_WAIT_W(N, W, X) \
-      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(X) :: "memory")
-#define MRAG_WAIT_A(N, X) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X) :: "memory")
+#define MRAG_WAIT12(N, W, A)                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                        \
+                   : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]),   \
+                     "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7])                                                  \
+                   :: "memory")
 #define MRAG_ROW(I, W, X)                                                                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[I][j] =                                                                 \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W[j]), __builtin_bit_cast(bf16x8, X), acc[I][j], 0, 0, 0)
-      MRAG_READ12(w0, a0, aW0, aA0);
-      // the 8 LDS-DMA pieces of the next K-tile are issued ONE PER ROW GROUP, between the MFMAs: a burst of 8 right after the
-      // barrier costs ~100 cycles each (measured with s_memtime stamps: 900 cycles before the first MFMA), all of it exposed
-      const bool more = kt + 1 < nk;
-      char* nbase = smem + ((kt + 1) & 1) * STAGE_BYTES;
-#define MRAG_PIECE(I) if (more) glds16(gsrc[I] + (long long)(kt + 1) * BK, nbase + (wave + (I) * NW) * 1024)
-      MRAG_WAIT_W(7, w0, a0[0]);
+    const unsigned smem_u = (unsigned)(size_t)smem;
+    const unsigned c0 = ((frag_q + 0) ^ swz) * 16, c1 = ((frag_q + 4) ^ swz) * 16;
+    const unsigned offA = a_off, offW = w_off - BM * 128;   // the W reads carry offset:32768 (= BM * 128) in the instruction
+    u32x4 w0[4], a0[8], w1[4], a1[8];
+    if (nk > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PPW) : "memory");   // tile 0 landed everywhere, tile 1 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    MRAG_READ12(w0, a0, smem_u + offW + c0, smem_u + offA + c0);
+#ifdef MRAG_GEMM_STAMPS
+    MRAG_GSTAMP(g_loop0);
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+      MRAG_GSTAMP(g0);
+      const unsigned st = smem_u + (kt & 1) * STAGE_BYTES;
+      MRAG_WAIT12(0, w0, a0);            // the (t, 0) fragments (requested one k-step ago) are here
+      MRAG_GSTAMP(g1);
+      MRAG_ROW(0, w0, a0[0]);
+      MRAG_READ12(w1, a1, st + offW + c1, st + offA + c1);   // behind the first MFMAs: the 12 KB read burst of 8 waves takes up to ~380 cycles to issue
+      MRAG_ROW(1, w0, a0[1]); MRAG_ROW(2, w0, a0[2]); MRAG_ROW(3, w0, a0[3]);
+      MRAG_ROW(4, w0, a0[4]); MRAG_ROW(5, w0, a0[5]); MRAG_ROW(6, w0, a0[6]); MRAG_ROW(7, w0, a0[7]);
+      __builtin_amdgcn_sched_barrier(0);
+      MRAG_WAIT12(0, w1, a1);            // this wave is done reading stage t
+      MRAG_GSTAMP(g2);
+      const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+      if (more) {
+#ifdef MRAG_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MRAG_GSTAMP(g5);
+        g_acc[4] += g5 - g2;
+        asm volatile("s_barrier" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // tile t+1 landed for every wave; stage t is free
+#endif
+      }
       MRAG_GSTAMP(g3);
-      MRAG_ROW(0, w0, a0[0]); MRAG_PIECE(0);
-      MRAG_WAIT_A(6, a0[1]); MRAG_ROW(1, w0, a0[1]); MRAG_PIECE(1);
-      MRAG_WAIT_A(5, a0[2]); MRAG_ROW(2, w0, a0[2]); MRAG_PIECE(2);
-      MRAG_WAIT_A(4, a0[3]); MRAG_ROW(3, w0, a0[3]); MRAG_PIECE(3);
-      MRAG_WAIT_A(3, a0[4]); MRAG_ROW(4, w0, a0[4]);
-      MRAG_READ12(w1, a1, aW1, aA1);                  // 3 + 12 = 15 outstanding
-      MRAG_WAIT_A(14, a0[5]); MRAG_ROW(5, w0, a0[5]); MRAG_PIECE(4);
-      MRAG_WAIT_A(13, a0[6]); MRAG_ROW(6, w0, a0[6]); MRAG_PIECE(5);
-      MRAG_WAIT_A(12, a0[7]); MRAG_ROW(7, w0, a0[7]); MRAG_PIECE(6);
-      MRAG_WAIT_W(7, w1, a1[0]); MRAG_ROW(0, w1, a1[0]); MRAG_PIECE(7);
-      MRAG_WAIT_A(6, a1[1]); MRAG_ROW(1, w1, a1[1]);
-      MRAG_WAIT_A(5, a1[2]); MRAG_ROW(2, w1, a1[2]);
-      MRAG_WAIT_A(4, a1[3]); MRAG_ROW(3, w1, a1[3]);
-      MRAG_WAIT_A(3, a1[4]); MRAG_ROW(4, w1, a1[4]);
-      MRAG_WAIT_A(2, a1[5]); MRAG_ROW(5, w1, a1[5]);
-      MRAG_WAIT_A(1, a1[6]); MRAG_ROW(6, w1, a1[6]);
-      MRAG_WAIT_A(0, a1[7]); MRAG_ROW(7, w1, a1[7]);
+      // the 8 LDS-DMA pieces of tile t+2 go into stage t, ONE PER ROW GROUP between the MFMAs (a burst of 8 costs ~100 cycles
+      // each at issue, measured with s_memtime stamps)
+      char* nbase = smem + (kt & 1) * STAGE_BYTES;
+#define MRAG_PIECE(I) if (more2) glds16(gsrc[I] + (long long)(kt + 2) * MRAG_DIAG_KSTEP, nbase + (wave + (I) * NW) * 1024)
+      MRAG_ROW(0, w1, a1[0]);
+      if (more) {
+        const unsigned sn = smem_u + ((kt + 1) & 1) * STAGE_BYTES;
+        MRAG_READ12(w0, a0, sn + offW + c0, sn + offA + c0);
+      }
+      MRAG_PIECE(0);
+      MRAG_ROW(1, w1, a1[1]); MRAG_PIECE(1);
+      MRAG_ROW(2, w1, a1[2]); MRAG_PIECE(2);
+      MRAG_ROW(3, w1, a1[3]); MRAG_PIECE(3);
+      MRAG_ROW(4, w1, a1[4]); MRAG_PIECE(4);
+      MRAG_ROW(5, w1, a1[5]); MRAG_PIECE(5);
+      MRAG_ROW(6, w1, a1[6]); MRAG_PIECE(6);
+      MRAG_ROW(7, w1, a1[7]); MRAG_PIECE(7);
+      __builtin_amdgcn_sched_barrier(0);
 #undef MRAG_PIECE
 #ifdef MRAG_GEMM_STAMPS
       MRAG_GSTAMP(g4);
       g_acc[0] += g1 - g0; g_acc[1] += g2 - g1; g_acc[2] += g3 - g2; g_acc[3] += g4 - g3;
+      if (MRAG_GEMM_TRACE && g_gemm_stamp_buf && lane == 0 && blockIdx.x < 4 && kt >= 8 && kt < 12) {   // absolute timeline of 4 K-tiles, after the 64 Ki-word summary
+        unsigned long long* tr = g_gemm_stamp_buf + 65536 + (((long long)blockIdx.x * 8 + wave) * 4 + (kt - 8)) * 8;
+        tr[0] = g0; tr[1] = g1; tr[2] = g2; tr[3] = g5; tr[4] = g3; tr[5] = g4;
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        tr[6] = hwid;
+      }
 #endif
-#undef MRAG_READ12
-#undef MRAG_WAIT_W
-#undef MRAG_WAIT_A
-#undef MRAG_ROW
     }
+#undef MRAG_READ12
+#undef MRAG_WAIT12
+#undef MRAG_ROW
 #ifdef MRAG_GEMM_STAMPS
+    MRAG_GSTAMP(g_loop1);
     if (g_gemm_stamp_buf && lane == 0 && blockIdx.x < 1024) {
       for (int k = 0; k < 4; ++k) g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + k] = g_acc[k];
       g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + 4] = nk;
+      g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + 5] = g_acc[4];
     }
 #endif
   } else {
@@ -288,6 +335,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         *(u32x2*)(p.C + m * p.ldc + n) = half;
       }
     }
+#ifdef MRAG_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MRAG_GSTAMP(g_exit);
+    if (g_gemm_stamp_buf && lane == 0 && blockIdx.x < 1024) {
+      g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + 6] = g_loop0 - g_entry;
+      g_gemm_stamp_buf[((long long)blockIdx.x * 8 + wave) * 8 + 7] = g_exit - g_loop1;
+    }
+#endif
     return;
   }
 #pragma unroll

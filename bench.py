@@ -197,7 +197,7 @@ def main():
             "step_tflops_per_sec_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
             "cama_ms": round(cama_ms, 2), "cama_first_call_ms": round(cama_first_ms, 1),
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
-            "roofline": {"kernel": "attn_fwd_kernel<8,false> (joint text+video flash attention, 48 heads x 64, S=%d, B=2)" % S,
+            "roofline": {"kernel": "attn_fwd_kernel<8,false,false,false> (joint text+video flash attention, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

@@ -26,6 +26,6 @@ out = {"kernel": kern + ">", "shape": "B=2 H=48 S=17776 D=64", "launches": len(f
        "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
        "algorithmic_bytes_per_launch": 4 * 2 * 17776 * 3072 * 2,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 wide-stream correction)"}
-json.dump(out, open(f"profiles/{tag}_attn_traffic.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_attn_traffic.json", "w"), indent=1); json.dump(out, open(f"gpurun_out/traffic/{tag}_attn_traffic.json", "w"), indent=1)  # gpurun merges only gpurun_out/ back
 print(json.dumps(out))
 PY

@@ -165,6 +165,22 @@ int mrag_add_rows_bf16(void* stream, const void* x, const void* table, void* y,
                        int64_t rows, int64_t D, int64_t period);
 /* y = a + b elementwise bf16 */
 int mrag_add_bf16(void* stream, const void* a, const void* b, void* y, int64_t n);
+/* y[r, :] = x[r, :] + table[(r / div) % period, :] -- a per-frame / per-sample vector broadcast over a frame's pixels.
+ * SVD (third-party diffusers 0.32.2 TransformerSpatioTemporalModel, reached from src/projects/svd/module.py:38-47):
+ * `hidden_states_mix + emb[:, None, :]` (frame-index embedding) and TemporalResnetBlock's `+ temb` per frame;
+ * with div = 1 it reproduces the `time_context` row order of the temporal cross-attention (row % batch).           */
+int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period);
+/* out = a x + b y (fp32 inside, one rounding): diffusers AlphaBlender `alpha * x_spatial + (1 - alpha) * x_temporal`
+ * of SpatioTemporalResBlock / TransformerSpatioTemporalModel (SVD UNet sites the reference adapts at
+ * src/projects/svd/module.py:145-165).                                                                          */
+int mrag_axpby_bf16(void* stream, const void* x, const void* y, void* out, int64_t n, float a, float b);
+/* SVD classifier-free guidance with the per-frame scale linspace(min, max, F) + one Euler-discrete step on v-prediction
+ * (diffusers StableVideoDiffusionPipeline.__call__ as driven by src/projects/svd/pipelines/pipeline.py:147-160 and the
+ * in-tree c_skip / c_out / c_noise convention src/projects/svd/module.py:92-98):
+ *   latents <- c_x * latents + c_v * (v_u + g[f] (v_c - v_u)),  f = (i / frame_elems) % F
+ * v_pred [2, n] bf16 (uncond first), latents [n] bf16 in place, guidance [F] fp32 on the device.                   */
+int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n, const float* guidance, int32_t F,
+                             int64_t frame_elems, float c_x, float c_v);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,

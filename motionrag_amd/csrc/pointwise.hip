@@ -141,6 +141,46 @@ __global__ void cfg_ddim_kernel(const bf16_t* vp, bf16_t* x, long long n8, long 
   }
 }
 
+// y[r, :] = x[r, :] + table[(r / div) % period, :]  (per-frame / per-sample vectors broadcast over the pixels of a frame)
+__global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long div, long long period) {
+  const long long total = rows * D8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / D8, c = i - r * D8;
+    float u[8], v[8];
+    unpack8(*(const u32x4*)(x + i * 8), u);
+    unpack8(*(const u32x4*)(table + (((r / div) % period) * D8 + c) * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] += v[e];
+    *(u32x4*)(y + i * 8) = pack8(u);
+  }
+}
+
+// out = a x + b y in fp32, one rounding (AlphaBlender)
+__global__ void axpby_kernel(const bf16_t* x, const bf16_t* y, bf16_t* out, long long n8, float a, float b) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    unpack8(*(const u32x4*)(x + i * 8), u);
+    unpack8(*(const u32x4*)(y + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = a * u[e] + b * v[e];
+    *(u32x4*)(out + i * 8) = pack8(u);
+  }
+}
+
+// latents <- cx * latents + cv * (v_u + g[f] (v_c - v_u)), f = (i / frame_elems) % F
+__global__ void cfg_euler_kernel(const bf16_t* vp, bf16_t* x, long long n8, long long n, const float* g, int F, long long frame_elems, float cx, float cv) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float vu[8], vc[8], xx[8];
+    unpack8(*(const u32x4*)(vp + i * 8), vu);
+    unpack8(*(const u32x4*)(vp + n + i * 8), vc);
+    unpack8(*(const u32x4*)(x + i * 8), xx);
+    const float gf = g[((i * 8) / frame_elems) % F];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xx[e] = cx * xx[e] + cv * (vu[e] + gf * (vc[e] - vu[e]));
+    *(u32x4*)(x + i * 8) = pack8(xx);
+  }
+}
+
 }  // namespace
 
 extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
@@ -201,6 +241,33 @@ extern "C" int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* l
   if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
   MRAG_LAUNCH(cfg_ddim_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents,
                      (long long)(n / 8), (long long)n, guidance, sqrt_alpha_t, sqrt_beta_t, a_t, b_t);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period) {
+  if (!x || !table || !y || rows <= 0 || D <= 0 || div <= 0 || period <= 0 || D % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)table | (uintptr_t)y) & 15) return MRAG_EINVAL;
+  MRAG_LAUNCH(add_bcast_kernel, dim3(grid_for(rows * D / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)table, (bf16_t*)y,
+              (long long)rows, (long long)(D / 8), (long long)div, (long long)period);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_axpby_bf16(void* stream, const void* x, const void* y, void* out, int64_t n, float a, float b) {
+  if (!x || !y || !out || n <= 0 || n % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15) return MRAG_EINVAL;
+  MRAG_LAUNCH(axpby_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, (long long)(n / 8), a, b);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n, const float* guidance, int32_t F,
+                                        int64_t frame_elems, float c_x, float c_v) {
+  if (!v_pred || !latents || !guidance || n <= 0 || n % 8 != 0 || F <= 0 || frame_elems <= 0 || frame_elems % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
+  MRAG_LAUNCH(cfg_euler_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents, (long long)(n / 8),
+              (long long)n, guidance, (int)F, (long long)frame_elems, c_x, c_v);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -222,6 +222,43 @@ def add_rows(x: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] =
     return out
 
 
+def add_bcast(x: torch.Tensor, table: torch.Tensor, div: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, D] (any leading shape) + table[(row // div) % len(table)]: a per-frame vector broadcast over `div` pixel rows."""
+    _dev(x, name="x"); _dev(table, name="table")
+    if not x.is_contiguous() or not table.is_contiguous() or table.dim() != 2 or table.shape[1] != x.shape[-1]:
+        raise ValueError("add_bcast: x [..., D] and table [L, D], both contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    D = x.shape[-1]
+    check(_lib.lib().mrag_add_bcast_bf16(_stream(), _p(x), _p(table), _p(out), x.numel() // D, D, int(div), table.shape[0]), "mrag_add_bcast_bf16")
+    return out
+
+
+def axpby(x: torch.Tensor, y: torch.Tensor, a: float, b: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a * x + b * y (AlphaBlender)"""
+    _dev(x, name="x"); _dev(y, name="y")
+    if x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous():
+        raise ValueError("axpby: same-shape contiguous tensors")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().mrag_axpby_bf16(_stream(), _p(x), _p(y), _p(out), x.numel(), float(a), float(b)), "mrag_axpby_bf16")
+    return out
+
+
+def cfg_euler_step_(v_pred: torch.Tensor, latents: torch.Tensor, guidance: torch.Tensor, c_x: float, c_v: float) -> torch.Tensor:
+    """latents [B, F, C, H, W] <- c_x * latents + c_v * (v_u + g[f] (v_c - v_u)); v_pred [2, B, F, C, H, W] (uncond first), g fp32 [F]."""
+    _dev(v_pred, name="v_pred"); _dev(latents, name="latents"); _dev(guidance, torch.float32, "guidance")
+    if v_pred.shape[0] != 2 or v_pred.shape[1:] != latents.shape or not v_pred.is_contiguous() or not latents.is_contiguous() or latents.dim() != 5:
+        raise ValueError("cfg_euler_step_: v_pred [2, B, F, C, H, W], latents [B, F, C, H, W], contiguous")
+    F = latents.shape[1]
+    if guidance.numel() != F:
+        raise ValueError("cfg_euler_step_: one guidance scale per frame")
+    fe = latents.shape[2] * latents.shape[3] * latents.shape[4]
+    check(_lib.lib().mrag_cfg_euler_step_bf16(_stream(), _p(v_pred), _p(latents), latents.numel(), _p(guidance.contiguous()), F, fe, float(c_x), float(c_v)),
+          "mrag_cfg_euler_step_bf16")
+    return latents
+
+
 def patchify(src0: torch.Tensor, src1: Optional[torch.Tensor], B: int) -> torch.Tensor:
     """[Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> [B*F*(H/2)*(W/2), (C0+C1)*4]; batch b reads latent b % Bl."""
     _dev(src0, name="src0")

@@ -269,3 +269,56 @@ def test_dc_schedule_and_ddim_steps_match_reference(golden_dir):
 def math_cos(t):
     import math
     return math.cos(t / 100.0)
+
+
+# ------------------------------------------------------------------------------------------------ SVD (parity unpinned: self-consistency only)
+def svd_tiny(seed=0):
+    """reduced-width SVD UNet with the motion adapters installed: (model on CPU, state dict, config, inputs)"""
+    import torch
+    from motionrag_amd import svd, svd_unet
+    cfg = dict(in_channels=8, out_channels=4, block_out_channels=(64, 128), addition_time_embed_dim=64, projection_class_embeddings_input_dim=192,
+               layers_per_block=1, cross_attention_dim=64, num_attention_heads=(1, 2))
+    unet = svd_unet.UNetSpatioTemporalConditionModel(**cfg)
+    names = [n for n in unet.attn_processors if "temporal_transformer_blocks" not in n and n.endswith("attn2.processor")]
+    hidden = {n: dict(unet.named_modules())[n[: -len(".processor")]].to_q.in_features for n in names}
+    svd.set_attention_processors(unet, names, 64, hidden)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in unet.named_parameters():
+            if k.endswith("mix_factor"):
+                p.copy_(torch.randn(p.shape, generator=g))
+            elif p.dim() == 1:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g) if "norm" in k and k.endswith("weight") else 0.05 * torch.randn(p.shape, generator=g))
+            else:
+                fan = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (0.7 / fan ** 0.5))
+    unet = unet.to(torch.bfloat16)
+    B, Fr = 2, 4
+    inp = dict(sample=torch.randn(B, Fr, 8, 16, 16, generator=g), timestep=torch.tensor(1.3), image=torch.randn(B, 1, 64, generator=g),
+               action=torch.randn(B, 25, 64, generator=g), added_time_ids=torch.tensor([[6.0, 127.0, 0.02]] * B))
+    inp = {k: (v.to(torch.bfloat16).float() if k != "added_time_ids" and k != "timestep" else v) for k, v in inp.items()}
+    return unet, cfg, inp
+
+
+def test_svd_oracle_self_consistency():
+    import torch
+    from oracle import svd_ref
+    unet, cfg, inp = svd_tiny()
+    sd = unet.state_dict()
+    assert any(k.endswith("attn2.processor.to_q_ip.0.weight") for k in sd), "adapter weights must be state-dict keys (Motion-Adapter.ckpt layout)"
+    assert "down_blocks.0.resnets.0.temporal_res_block.conv1.weight" in sd and "mid_block.attentions.0.time_mixer.mix_factor" in sd
+    y = svd_ref.unet_forward(sd, cfg, inp["sample"], inp["timestep"], inp["image"], inp["added_time_ids"], inp["action"])
+    assert y.shape == (2, 4, 4, 16, 16) and torch.isfinite(y).all() and y.std() > 1e-3
+    y0 = svd_ref.unet_forward(sd, cfg, inp["sample"], inp["timestep"], inp["image"], inp["added_time_ids"], None)
+    assert (y - y0).abs().max() > 1e-4, "the motion tokens must reach the output"
+    # the Euler step in its linear form (what the kernel takes) equals the textbook form
+    sig = svd_ref.karras_sigmas(25)
+    assert abs(float(sig[0]) - 700.0) < 1e-9 and abs(float(sig[24]) - 0.002) < 1e-12 and float(sig[25]) == 0.0
+    g = torch.Generator().manual_seed(1)
+    x, vu, vc = (torch.randn(1, 4, 4, 8, 8, generator=g, dtype=torch.float64) for _ in range(3))
+    gs = torch.linspace(1.0, 3.0, 4, dtype=torch.float64)
+    for i in (0, 7, 24):
+        want = svd_ref.euler_cfg_step(vu, vc, x, float(sig[i]), float(sig[i + 1]), gs)
+        cx, cv = svd_ref.euler_coeffs(float(sig[i]), float(sig[i + 1]))
+        got = cx * x + cv * (vu + gs.view(1, -1, 1, 1, 1) * (vc - vu))
+        assert torch.allclose(got, want, rtol=1e-10, atol=1e-10)

@@ -104,6 +104,64 @@ def unet():
     print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {105.7/dt:.0f} TFLOP/s of 105.7 TFLOP algorithmic  -> {16/dt:.1f} frames/s")
 
 
+def count_flops(fn):
+    """algorithmic FLOPs of one call: 2 M N K of every GEMM (true K, before padding) + 4 B H Sq Skv 64 of every attention launch"""
+    tot = [0.0]
+    lin, att = ops.linear, ops.attention
+
+    def linear(x, w, *a, **k):
+        tot[0] += 2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * min(x.shape[-1], w.shape[1])
+        return lin(x, w, *a, **k)
+
+    def attention(q, k_, v, *a, **k):
+        tot[0] += 4.0 * q.shape[0] * q.shape[2] * q.shape[1] * k_.shape[1] * 64
+        return att(q, k_, v, *a, **k)
+
+    ops.linear, ops.attention = linear, attention
+    try:
+        fn()
+    finally:
+        ops.linear, ops.attention = lin, att
+    return tot[0]
+
+
+def svd():
+    """SVD img2vid UNet + motion adapters, one CFG denoise step at 14x576x1024 (sample [2, 14, 8, 72, 128]), random-init weights"""
+    from motionrag_amd import svd as svd_glue, svd_unet
+    torch.manual_seed(0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(DEV):
+        net = svd_unet.UNetSpatioTemporalConditionModel()
+        names = [n for n in net.attn_processors if "temporal_transformer_blocks" not in n and n.endswith("attn2.processor")]
+        hidden = {n: dict(net.named_modules())[n[: -len(".processor")]].to_q.in_features for n in names}
+        svd_glue.set_attention_processors(net, names, 1024, hidden)
+    torch.set_default_dtype(old)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+            elif n.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02)
+    B, Fr = 2, 14
+    x = torch.randn(B, Fr, 8, 72, 128, device=DEV).to(torch.bfloat16)
+    ehs = svd_glue.TupleTensor([torch.randn(B, 1, 1024, device=DEV).to(torch.bfloat16), torch.randn(B, 25, 1024, device=DEV).to(torch.bfloat16)])
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B, device=DEV)
+    sch = svd_unet.EulerDiscreteScheduler(); sch.set_timesteps(25)
+    lat = torch.randn(1, Fr, 4, 72, 128, device=DEV).to(torch.bfloat16)
+    gs = torch.linspace(1.0, 3.0, Fr, device=DEV)
+
+    def step():
+        v = net(x, float(sch.timesteps[3]), ehs, ids).sample
+        sch.step_(v.view(2, 1, Fr, 4, 72, 128), lat, 3, gs)
+
+    fl = count_flops(step)
+    dt = timeit(step, iters=3, warm=1)
+    print(f"SVD UNet CFG step (14x576x1024, {len(names)} adapter sites): {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP algorithmic  -> {Fr/dt:.1f} frames/s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

@@ -52,7 +52,9 @@ enum mrag_epilogue {
   MRAG_EPI_GELU_ERF = 2,    /* C = gelu_erf(acc + bias)       (CAMA / Resampler FF)   */
   MRAG_EPI_RESID = 3,       /* C = resid + (acc + bias)                               */
   MRAG_EPI_GATE_RESID = 4,  /* C = resid + gate[b(m), n] * (acc + bias)  (AdaLN-zero) */
-  MRAG_EPI_SILU = 5         /* C = silu(acc + bias)            (timestep MLP)         */
+  MRAG_EPI_SILU = 5,        /* C = silu(acc + bias)            (timestep MLP)         */
+  MRAG_EPI_GEGLU = 6        /* C[M, N/2] = v * gelu_erf(g): W / bias rows interleaved in 16-row [value | gate] groups
+                             * (GEGLU of lvdm/modules/attention.py:448-455 and diffusers' FeedForward, N % 32 == 0)  */
 };
 
 typedef struct mrag_gemm_args {

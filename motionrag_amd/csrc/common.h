@@ -20,6 +20,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }   // value after a bf16 store + reload
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2;
 // one v_cvt_pk_bf16_f32: lo -> bits [15:0], hi -> bits [31:16]

@@ -345,6 +345,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 #endif
     return;
   }
+  if constexpr (EPI == MRAG_EPI_GEGLU) {
+    // W rows arrive interleaved in 16-row groups: [value 16m..16m+15 | gate 16m..16m+15], so the even 16-column MFMA tile
+    // holds the values and the odd one the gates of the SAME 16 outputs in the same lanes: C[m, j] = v * gelu_erf(g),
+    // C is [M, N/2].  Removes the [M, N] round trip and the separate GEGLU pass (6 % of an SVD / DynamiCrafter step).
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j += 2) {
+        const long long n = bn0 + wn * TN * 16 + j * 16 + frag_q * 4;   // value columns; gates at n + 16
+        if (n >= p.N) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+        if (p.bias) {
+          const u32x2 bv = *(const u32x2*)(p.bias + n), bg = *(const u32x2*)(p.bias + n + 16);
+          v[0] += __uint_as_float(bv[0] << 16); v[1] += __uint_as_float(bv[0] & 0xffff0000u);
+          v[2] += __uint_as_float(bv[1] << 16); v[3] += __uint_as_float(bv[1] & 0xffff0000u);
+          g[0] += __uint_as_float(bg[0] << 16); g[1] += __uint_as_float(bg[0] & 0xffff0000u);
+          g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
+        }
+        // the reference rounds both halves of proj(x) to bf16 before the product (nn.Linear output dtype)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+        u32x2 out;
+        out[0] = pack_bf2(v[0], v[1]);
+        out[1] = pack_bf2(v[2], v[3]);
+        const long long no = ((bn0 + wn * TN * 16 + j * 16) >> 1) + frag_q * 4;
+        *(u32x2*)(p.C + m * p.ldc + no) = out;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
@@ -395,7 +428,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
-  if (getenv("MRAG_GEMM_NO_STAGED")) p.staged = 0;   // tuning knob
+  if (getenv("MRAG_GEMM_NO_STAGED") || epi == MRAG_EPI_GEGLU) p.staged = 0;   // tuning knob; GEGLU writes [M, N/2] from the accumulator layout
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
 #define MRAG_GEMM_CASE(E)                                                                              \
@@ -413,6 +446,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
     MRAG_GEMM_CASE(MRAG_EPI_RESID)
     MRAG_GEMM_CASE(MRAG_EPI_GATE_RESID)
     MRAG_GEMM_CASE(MRAG_EPI_SILU)
+    MRAG_GEMM_CASE(MRAG_EPI_GEGLU)
     default: return MRAG_EINVAL;
   }
 #undef MRAG_GEMM_CASE
@@ -426,6 +460,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   if (!a || !a->A || !a->W || !a->C) return MRAG_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return MRAG_EINVAL;
   if (a->K % 64 != 0 || a->N % 4 != 0) return MRAG_ENOTSUP;
+  if (a->epilogue == MRAG_EPI_GEGLU && a->N % 32 != 0) return MRAG_ENOTSUP;
   if (a->lda % 8 != 0 || a->ldw % 8 != 0 || a->ldc % 4 != 0) return MRAG_EINVAL;
   if (((uintptr_t)a->A | (uintptr_t)a->W) & 15) return MRAG_EINVAL;
   if ((uintptr_t)a->C & 7) return MRAG_EINVAL;

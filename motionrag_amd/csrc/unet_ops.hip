@@ -80,47 +80,63 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
   }
 }
 
-// pass 2: fold the partials into per-channel scale / shift (in LDS), then stream y = act((x + emb) * a_c + b_c)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* a_c = (float*)smem;          // [C]
-  float* b_c = a_c + p.C;             // [C]
-  float* gsum = b_c + p.C;            // [G][2]
-  const int n = blockIdx.y;
+// pass 2 (tiny): one workgroup per (group, n) folds the chunk partials of its channels in a FIXED order (bit-reproducible),
+// adds the analytic contribution of the per-(n, c) embedding, and writes per-channel scale / shift a_c, b_c to the workspace.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const GnP p, float* ab) {
+  __shared__ float red_s[256], red_q[256];
+  __shared__ float ch_s[256], ch_q[256];
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int cpg = (int)(p.C / p.G);
-  // per-channel totals (the per-(n, c) embedding folded in analytically), parked in a_c / b_c, then summed per group in a
-  // fixed order (bit-reproducible)
-  for (int c = threadIdx.x; c < p.C; c += 256) {
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = g * cpg + cl;
     float s = 0.f, q = 0.f;
-    for (int k = 0; k < p.chunks; ++k) {
+    for (int k = t; k < p.chunks; k += 256) {
       const float* pr = p.part + (((long long)n * p.chunks + k) * p.C + c) * 2;
       s += pr[0]; q += pr[1];
     }
-    if (p.emb) {
-      const float e = bf2f(p.emb[(long long)n * p.emb_stride + c]);
-      q += 2.f * e * s + (float)p.HW * e * e;   // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
-      s += (float)p.HW * e;
+    red_s[t] = s; red_q[t] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) { red_s[t] += red_s[t + w]; red_q[t] += red_q[t + w]; }
+      __syncthreads();
     }
-    a_c[c] = s; b_c[c] = q;
+    if (t == 0) {
+      s = red_s[0]; q = red_q[0];
+      if (p.emb) {
+        const float e = bf2f(p.emb[(long long)n * p.emb_stride + c]);
+        q += 2.f * e * s + (float)p.HW * e * e;   // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
+        s += (float)p.HW * e;
+      }
+      ch_s[cl] = s; ch_q[cl] = q;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < p.G; g += 256) {
+  if (t == 0) {
     float s = 0.f, q = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += a_c[c]; q += b_c[c]; }
-    gsum[2 * g] = s; gsum[2 * g + 1] = q;
+    for (int cl = 0; cl < cpg; ++cl) { s += ch_s[cl]; q += ch_q[cl]; }
+    red_s[0] = s; red_q[0] = q;
   }
   __syncthreads();
   const float cnt = (float)p.HW * (float)cpg;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    const int g = c / cpg;
-    const float mean = gsum[2 * g] / cnt;
-    const float var = fmaxf(gsum[2 * g + 1] / cnt - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + p.eps);
+  const float mean = red_s[0] / cnt;
+  const float var = fmaxf(red_q[0] / cnt - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + p.eps);
+  for (int cl = t; cl < cpg; cl += 256) {
+    const int c = g * cpg + cl;
     const float ga = p.gamma ? bf2f(p.gamma[c]) : 1.f, be = p.beta ? bf2f(p.beta[c]) : 0.f;
     const float e = p.emb ? bf2f(p.emb[(long long)n * p.emb_stride + c]) : 0.f;
-    a_c[c] = ga * rstd;
-    b_c[c] = be + (e - mean) * ga * rstd;
+    ab[((long long)n * p.C + c) * 2] = ga * rstd;
+    ab[((long long)n * p.C + c) * 2 + 1] = be + (e - mean) * ga * rstd;
   }
+}
+
+// pass 3: stream y = act(x * a_c + b_c) with the per-channel pairs parked in LDS; enough workgroups to fill the chip even
+// when N is 1 or 2 (GroupNorm over (t, h, w) of the temporal blocks)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p, const float* ab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* abl = (float2*)smem;          // [C]
+  const int n = blockIdx.y;
+  for (int c = threadIdx.x; c < p.C; c += 256) abl[c] = ((const float2*)ab)[(long long)n * p.C + c];
   __syncthreads();
   const long long C8 = p.C / 8;
   const long long vecs = p.HW * C8;
@@ -132,7 +148,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p) {
     unpack8(*(const u32x4*)(xb + i * 8), v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float o = v[e] * a_c[c0 + e] + b_c[c0 + e];
+      const float2 w = abl[c0 + e];
+      const float o = v[e] * w.x + w.y;
       v[e] = p.silu ? silu_f(o) : o;
     }
     *(u32x4*)(yb + i * 8) = pack8(v);
@@ -223,7 +240,7 @@ inline unsigned grid_for(long long items) {
 
 extern "C" int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks) {
   if (N <= 0 || C <= 0 || chunks <= 0) return 0;
-  return N * chunks * C * 2 * (int64_t)sizeof(float);
+  return (N * chunks * C * 2 + N * C * 2) * (int64_t)sizeof(float);   // chunk partials + per-(n, c) scale / shift
 }
 
 extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
@@ -239,10 +256,16 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   hipStream_t s = (hipStream_t)stream;
   MRAG_LAUNCH(gn_stats_kernel, dim3(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048)), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
-  const size_t lds = (size_t)(2 * a->C + 2 * a->G) * sizeof(float);
-  long long bx = (a->HW * (a->C / 8) + 255) / 256;
-  if (bx > 64) bx = 64;
-  MRAG_LAUNCH(gn_apply_kernel, dim3((unsigned)bx, (unsigned)a->N), dim3(256), lds, s, p);
+  if (a->C / a->G > 256) return MRAG_ENOTSUP;
+  float* ab = p.part + a->N * a->chunks * a->C * 2;
+  MRAG_LAUNCH(gn_fold_kernel, dim3((unsigned)a->G, (unsigned)a->N), dim3(256), 0, s, p, ab);
+  MRAG_LAUNCH_CHECK();
+  const size_t lds = (size_t)a->C * 2 * sizeof(float);
+  long long bx = (a->HW * (a->C / 8) + 1023) / 1024;          // >= 4 vectors per thread
+  const long long cap = 4096 / a->N > 16 ? 4096 / a->N : 16;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  MRAG_LAUNCH(gn_apply_kernel, dim3((unsigned)bx, (unsigned)a->N), dim3(256), lds, s, p, (const float*)ab);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import AttnArgs, GemmArgs, LnArgs, QkNormRopeArgs, check
 
-EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU = range(6)
+EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU, EPI_GEGLU = range(7)
 LOG2E = 1.4426950408889634
 
 
@@ -61,7 +61,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         weight = torch.nn.functional.pad(weight, (0, pad))
         K += pad
     if out is None:
-        out = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(*x.shape[:-1], N // 2 if epilogue == EPI_GEGLU else N, dtype=torch.bfloat16, device=x.device)
     o2 = _rows(out)
     a = GemmArgs()
     a.A, a.W, a.bias, a.C = _p(x2), _p(weight), _p(bias), _p(o2)
@@ -76,6 +76,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         a.rows_per_batch, a.split, a.gate_stride = rows_per_batch, split, gate_stride
     check(_lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a)), "mrag_gemm_bf16")
     return out
+
+
+def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """re-order the rows of a GEGLU projection ([value rows | gate rows], `chunk(2)` order) into the 16-row [value | gate] groups
+    that `linear(..., epilogue=EPI_GEGLU)` expects.  Memory plumbing, done once per weight."""
+    n2 = weight.shape[0]
+    inner = n2 // 2
+    if n2 % 32 != 0:
+        raise ValueError("GEGLU inner width must be a multiple of 16")
+    idx = torch.arange(inner, device=weight.device).view(-1, 16)
+    perm = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+    return weight.detach()[perm].contiguous(), (bias.detach()[perm].contiguous() if bias is not None else None)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optional[torch.Tensor] = None,
@@ -327,7 +339,7 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     N, HW, C = x.shape
     if out is None:
         out = torch.empty_like(x)
-    chunks = max(1, min(64, HW // 64))
+    chunks = max(1, min(1024, HW // 32, max(64, -(-2048 // N))))        # >= ~2048 statistics workgroups even when N is 1 or 2
     L = _lib.lib()
     ws = torch.empty(L.mrag_groupnorm_workspace_bytes(N, C, chunks), dtype=torch.uint8, device=x.device)
     a = GroupNormArgs()

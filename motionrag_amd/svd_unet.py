@@ -159,7 +159,9 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim if dim_out is None else dim_out)])
 
     def forward(self, x, resid=None):
-        h = ops.geglu(ops.linear(x, self.net[0].proj.weight, self.net[0].proj.bias))
+        pj = self.net[0].proj
+        w, b = _CACHE.get(("geglu", id(pj)), pj.weight, lambda: ops.geglu_interleave(pj.weight, pj.bias))
+        h = ops.linear(x, w, b, epilogue=ops.EPI_GEGLU)                             # value * gelu(gate) in the GEMM epilogue
         if resid is not None:
             return ops.linear(h, self.net[2].weight, self.net[2].bias, epilogue=ops.EPI_RESID, resid=resid)
         return ops.linear(h, self.net[2].weight, self.net[2].bias)

@@ -332,3 +332,21 @@ def test_topk_baseline_size(hip):
     np.testing.assert_array_equal(rows, want_r)
     np.testing.assert_array_equal(dist, want_d.astype(np.float32))
     assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
+
+
+@pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128)])
+def test_gemm_geglu_epilogue(hip, M, inner, K):
+    """C = v * gelu_erf(g) with [v | g] = x W^T + b (lvdm attention.py:448-455 / diffusers GEGLU), both tile configurations"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M + inner)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inner, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = (torch.randn(2 * inner, generator=g) * 0.2).to(torch.bfloat16)
+    y = (x.float() @ w.float().T + b.float()).to(torch.bfloat16).float()
+    want = y[:, :inner] * torch.nn.functional.gelu(y[:, inner:])
+    wi, bi = ops.geglu_interleave(w.to(DEV), b.to(DEV))
+    got = ops.linear(x.to(DEV), wi, bi, epilogue=ops.EPI_GEGLU)
+    assert got.shape == (M, inner)
+    close(got, want, scale=want.abs().mean().item())
+    close(ops.linear(x.to(DEV), wi, None, epilogue=ops.EPI_GEGLU), (lambda z: z[:, :inner] * torch.nn.functional.gelu(z[:, inner:]))((x.float() @ w.float().T).to(torch.bfloat16).float()),
+          scale=want.abs().mean().item())

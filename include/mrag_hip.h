@@ -237,6 +237,23 @@ int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* args);
  * dst[(n,yo,xo), (ky,kx,c)] -> [N*Ho*Wo, Kpad], columns >= 9C zero.            */
 int mrag_im2col3x3_bf16(void* stream, const void* src, void* dst, int32_t N, int32_t H, int32_t W, int32_t C,
                         int32_t stride, int32_t upsample, int32_t Kpad);
+/* Implicit-GEMM convolutions on channels-last activations (no materialised im2col): the MFMA GEMM's LDS-DMA gathers the
+ * tap-shifted pixel rows itself, zero rows outside the image / clip.  Cin % 64 == 0.
+ *   MRAG_CONV_3X3: nn.Conv2d(Cin, Cout, 3, stride 1|2, padding 1) [+ nearest x2 upsample in front]
+ *                  (ResBlock / Downsample / Upsample, lvdm/modules/networks/openaimodel3d.py:52-107,211-237; diffusers
+ *                  ResnetBlock2D / Downsample2D / Upsample2D of the SVD UNet): x [N, H, Wd, Cin] -> y [N, Ho, Wo, Cout];
+ *                  W [Cout, (ky, kx, cin)].
+ *   MRAG_CONV_T3:  nn.Conv3d(Cin, Cout, (3,1,1), padding (1,0,0)) (TemporalConvBlock, openaimodel3d.py:240-281; diffusers
+ *                  TemporalResnetBlock): x [(N = B) * (H = T), Wd = HW, Cin] -> y same rows x Cout; W [Cout, (kt, cin)].
+ * epilogue: MRAG_EPI_NONE or MRAG_EPI_RESID (resid has the shape of y).                                                 */
+enum { MRAG_CONV_3X3 = 1, MRAG_CONV_T3 = 2 };
+typedef struct mrag_conv_args {
+  const void* x; const void* W; const void* bias; void* y; const void* resid;
+  int32_t N, H, Wd, Cin, Cout;
+  int32_t stride, upsample;        /* MRAG_CONV_3X3 only */
+  int32_t mode, epilogue;
+} mrag_conv_args;
+int mrag_conv_bf16(void* stream, const mrag_conv_args* args);
 /* row gather for nn.Conv3d((3,1,1), padding (1,0,0)), openaimodel3d.py:256-268:
  * dst[(b,t,hw), (kt,c)] = src[b, t+kt-1, hw, c]                                */
 int mrag_unfold_t3_bf16(void* stream, const void* src, void* dst, int32_t B, int32_t T, int64_t HW, int32_t C);

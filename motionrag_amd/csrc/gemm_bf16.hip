@@ -45,7 +45,13 @@ struct GemmP {
   const bf16_t* gate0; const bf16_t* gate1;
   long long M, N, K, lda, ldw, ldc, ldr, rows_per_batch, split, gate_stride;
   int tiles_m, tiles_n, group_m, staged;
+  // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
+  int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T;
+  long long cv_C, cv_HW;
 };
+
+// zero source for the taps that fall outside the image / clip (never written)
+__device__ __attribute__((aligned(128))) bf16_t g_zero_row[64];
 
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
@@ -55,7 +61,7 @@ __device__ __forceinline__ float epi_act(float v) {
   else return v;
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI, int CONV = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
@@ -85,6 +91,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 
   // ---- per-lane DMA source pointers (k = 0), one per piece this wave stages
   const bf16_t* gsrc[PPW];
+  constexpr int APW = BM / 8 / NW;          // a wave's first APW pieces are A rows (piece = wave + i * NW < BM / 8)
+  static_assert((BM / 8) % NW == 0, "A pieces split evenly over the waves");
+  int cv_y[APW], cv_x[APW];                 // conv modes: per A piece
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int piece = wave + i * NW;  // pieces [0, BM/8) are A rows, the rest W rows
@@ -93,7 +102,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     if (piece < BM / 8) {
       long long row = bm0 + r;
       row = row < p.M ? row : p.M - 1;  // clamp: tail rows re-read a valid row, stores are masked
-      gsrc[i] = p.A + row * p.lda + chunk * 8;
+      if constexpr (CONV == 1) {         // row = (n, yo, xo) of the output image: keep (n base, yo*stride - 1, xo*stride - 1)
+        const int xo = (int)(row % p.cv_Wo);
+        const long long r2 = row / p.cv_Wo;
+        const int yo = (int)(r2 % p.cv_Ho);
+        const long long n = r2 / p.cv_Ho;
+        gsrc[i] = p.A + n * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
+        cv_y[i] = yo * p.cv_stride - 1;
+        cv_x[i] = xo * p.cv_stride - 1;
+      } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row pointer and t
+        gsrc[i] = p.A + row * p.cv_C + chunk * 8;
+        cv_y[i] = (int)((row / p.cv_HW) % p.cv_T);
+      } else {
+        gsrc[i] = p.A + row * p.lda + chunk * 8;
+      }
     } else {
       long long row = bn0 + (r - BM);
       row = row < p.N ? row : p.N - 1;
@@ -114,12 +136,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 
   const int nk = (int)(p.K / BK);
 
+  // DMA source of piece i for K-tile kt.  Plain GEMM: the row pointer advanced by kt * 64.  Convolutions: K-tile kt is channel
+  // block (kt % ctiles) of tap (kt / ctiles); the lane's row is the tap-shifted pixel (or frame), or the zero row outside.
+  auto src = [&](int i, int kt) -> const bf16_t* {
+    if constexpr (CONV == 0) {
+      return gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP;
+    } else {
+      if (i >= APW) return gsrc[i] + (long long)kt * BK;       // weight rows [Cout, taps * Cin] are plain
+      const int tap = kt / p.cv_ctiles, c0 = (kt - tap * p.cv_ctiles) * 64;
+      if constexpr (CONV == 1) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
+        const bool ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
+        const long long off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C + c0;
+        return ok ? gsrc[i] + off : g_zero_row + (lane & 7) * 8;
+      } else {
+        const int t = cv_y[i] + tap - 1;
+        const bool ok = (unsigned)t < (unsigned)p.cv_T;
+        return ok ? gsrc[i] + (long long)(tap - 1) * p.cv_HW * p.cv_C + c0 : g_zero_row + (lane & 7) * 8;
+      }
+    }
+  };
   auto issue = [&](int stage, int kt) {
     char* base = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NW;
-      glds16(gsrc[i] + (long long)kt * BK, base + piece * 1024);  // wave-uniform base (+ lane*16 by HW)
+      glds16(src(i, kt), base + piece * 1024);  // wave-uniform base (+ lane*16 by HW)
     }
   };
 
@@ -199,7 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       // the 8 LDS-DMA pieces of tile t+2 go into stage t, ONE PER ROW GROUP between the MFMAs (a burst of 8 costs ~100 cycles
       // each at issue, measured with s_memtime stamps)
       char* nbase = smem + (kt & 1) * STAGE_BYTES;
-#define MRAG_PIECE(I) if (more2) glds16(gsrc[I] + (long long)(kt + 2) * MRAG_DIAG_KSTEP, nbase + (wave + (I) * NW) * 1024)
+#define MRAG_PIECE(I) if (more2) glds16(src(I, kt + 2), nbase + (wave + (I) * NW) * 1024)
       MRAG_ROW(0, w1, a1[0]);
       if (more) {
         const unsigned sn = smem_u + ((kt + 1) & 1) * STAGE_BYTES;
@@ -345,7 +388,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 #endif
     return;
   }
-  if constexpr (EPI == MRAG_EPI_GEGLU) {
+  if constexpr (EPI == MRAG_EPI_GEGLU && TN % 2 != 0) {
+    return;   // never dispatched: the value / gate pairing needs an even number of 16-column tiles per wave
+  } else if constexpr (EPI == MRAG_EPI_GEGLU) {
     // W rows arrive interleaved in 16-row groups: [value 16m..16m+15 | gate 16m..16m+15], so the even 16-column MFMA tile
     // holds the values and the odd one the gates of the SAME 16 outputs in the same lanes: C[m, j] = v * gelu_erf(g),
     // C is [M, N/2].  Removes the [M, N] round trip and the separate GEGLU pass (6 % of an SVD / DynamiCrafter step).
@@ -417,7 +462,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+// UNet widths are multiples of 320: N = 320 / 640 / 960 wastes 38 / 17 / 6 % of a 256-wide tile grid, nothing of a 320-wide one
+inline bool wide_n_pays(long long N) {
+  if (getenv("MRAG_GEMM_NO_WIDE")) return false;   // tuning knob
+  const long long w256 = (N + 255) / 256 * 256, w320 = (N + 319) / 320 * 320;
+  return w320 * 100 < w256 * 90;                   // at least 10 % fewer padded columns
+}
+
+template <int WM, int WN, int TM, int TN, int CONV = 0>
 int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   GemmP p = p0;
@@ -433,21 +485,29 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
 #define MRAG_GEMM_CASE(E)                                                                              \
   case E: {                                                                                            \
-    auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E>;                                                    \
+    auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, CONV>;                                              \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                   \
     break;                                                                                             \
   }
-  switch (epi) {
-    MRAG_GEMM_CASE(MRAG_EPI_NONE)
-    MRAG_GEMM_CASE(MRAG_EPI_GELU_TANH)
-    MRAG_GEMM_CASE(MRAG_EPI_GELU_ERF)
-    MRAG_GEMM_CASE(MRAG_EPI_RESID)
-    MRAG_GEMM_CASE(MRAG_EPI_GATE_RESID)
-    MRAG_GEMM_CASE(MRAG_EPI_SILU)
-    MRAG_GEMM_CASE(MRAG_EPI_GEGLU)
-    default: return MRAG_EINVAL;
+  if constexpr (CONV != 0) {   // convolutions carry bias / residual only
+    switch (epi) {
+      MRAG_GEMM_CASE(MRAG_EPI_NONE)
+      MRAG_GEMM_CASE(MRAG_EPI_RESID)
+      default: return MRAG_EINVAL;
+    }
+  } else {
+    switch (epi) {
+      MRAG_GEMM_CASE(MRAG_EPI_NONE)
+      MRAG_GEMM_CASE(MRAG_EPI_GELU_TANH)
+      MRAG_GEMM_CASE(MRAG_EPI_GELU_ERF)
+      MRAG_GEMM_CASE(MRAG_EPI_RESID)
+      MRAG_GEMM_CASE(MRAG_EPI_GATE_RESID)
+      MRAG_GEMM_CASE(MRAG_EPI_SILU)
+      MRAG_GEMM_CASE(MRAG_EPI_GEGLU)
+      default: return MRAG_EINVAL;
+    }
   }
 #undef MRAG_GEMM_CASE
   MRAG_LAUNCH_CHECK();
@@ -482,6 +542,40 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   if (const char* e = getenv("MRAG_GEMM_CFG")) {   // tuning knob (tools/microbench.py)
     if (e[0] == '1' && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
   }
+  if (t256 >= 192 && wide_n_pays(a->N) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, a->epilogue);   // 256x320 tile
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);
+}
+
+extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
+  if (!a || !a->x || !a->W || !a->y) return MRAG_EINVAL;
+  if (a->N <= 0 || a->H <= 0 || a->Wd <= 0 || a->Cin <= 0 || a->Cout <= 0) return MRAG_EINVAL;
+  if (a->Cin % 64 != 0 || a->Cout % 4 != 0) return MRAG_ENOTSUP;   // one K-tile = 64 channels of one tap
+  if (a->mode != MRAG_CONV_3X3 && a->mode != MRAG_CONV_T3) return MRAG_EINVAL;
+  if (a->epilogue != MRAG_EPI_NONE && a->epilogue != MRAG_EPI_RESID) return MRAG_EINVAL;
+  if (((uintptr_t)a->x | (uintptr_t)a->W) & 15) return MRAG_EINVAL;
+  if ((uintptr_t)a->y & 7) return MRAG_EINVAL;
+  if (a->epilogue == MRAG_EPI_RESID && (!a->resid || ((uintptr_t)a->resid & 7))) return MRAG_EINVAL;
+  GemmP p{};
+  p.A = (const bf16_t*)a->x; p.W = (const bf16_t*)a->W; p.bias = (const bf16_t*)a->bias; p.C = (bf16_t*)a->y; p.resid = (const bf16_t*)a->resid;
+  p.N = a->Cout; p.ldc = a->Cout; p.ldr = a->Cout; p.cv_C = a->Cin; p.cv_ctiles = a->Cin / 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->mode == MRAG_CONV_3X3) {
+    if ((a->stride != 1 && a->stride != 2) || (a->upsample != 0 && a->upsample != 1)) return MRAG_EINVAL;
+    p.cv_H = a->H; p.cv_W = a->Wd; p.cv_up = a->upsample; p.cv_stride = a->stride;
+    p.cv_Hi = a->upsample ? 2 * a->H : a->H; p.cv_Wi = a->upsample ? 2 * a->Wd : a->Wd;
+    p.cv_Ho = (p.cv_Hi - 1) / a->stride + 1; p.cv_Wo = (p.cv_Wi - 1) / a->stride + 1;
+    p.M = (long long)a->N * p.cv_Ho * p.cv_Wo; p.K = 9LL * a->Cin; p.ldw = p.K;
+    const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
+    if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 1>(s, p, a->epilogue);
+    return launch_cfg<2, 2, 4, 4, 1>(s, p, a->epilogue);
+  }
+  // (3,1,1) temporal convolution over x [(N = B) x (H = T), Wd = HW, Cin]
+  p.cv_T = a->H; p.cv_HW = a->Wd;
+  p.M = (long long)a->N * a->H * a->Wd; p.K = 3LL * a->Cin; p.ldw = p.K;
+  const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 2>(s, p, a->epilogue);
+  if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 2>(s, p, a->epilogue);
+  return launch_cfg<2, 2, 4, 4, 2>(s, p, a->epilogue);
 }

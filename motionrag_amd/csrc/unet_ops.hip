@@ -86,34 +86,33 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const GnP p, float* ab) {
   __shared__ float red_s[256], red_q[256];
   __shared__ float ch_s[256], ch_q[256];
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
-  const int cpg = (int)(p.C / p.G);
-  for (int cl = 0; cl < cpg; ++cl) {
+  const int cpg = (int)(p.C / p.G);          // <= 256 (host check)
+  const int ksl = 256 / cpg;                 // k-slices: thread t sums channel (t % cpg) over chunks k = t / cpg, + ksl, ...
+  const int cl = t % cpg, ks = t / cpg;
+  float s = 0.f, q = 0.f;
+  if (ks < ksl) {
     const int c = g * cpg + cl;
-    float s = 0.f, q = 0.f;
-    for (int k = t; k < p.chunks; k += 256) {
+    for (int k = ks; k < p.chunks; k += ksl) {
       const float* pr = p.part + (((long long)n * p.chunks + k) * p.C + c) * 2;
       s += pr[0]; q += pr[1];
     }
-    red_s[t] = s; red_q[t] = q;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (t < w) { red_s[t] += red_s[t + w]; red_q[t] += red_q[t + w]; }
-      __syncthreads();
-    }
-    if (t == 0) {
-      s = red_s[0]; q = red_q[0];
-      if (p.emb) {
-        const float e = bf2f(p.emb[(long long)n * p.emb_stride + c]);
-        q += 2.f * e * s + (float)p.HW * e * e;   // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
-        s += (float)p.HW * e;
-      }
-      ch_s[cl] = s; ch_q[cl] = q;
-    }
-    __syncthreads();
   }
+  red_s[t] = s; red_q[t] = q;
+  __syncthreads();
+  if (t < cpg) {                             // fixed order over the slices, then the analytic embedding terms
+    s = 0.f; q = 0.f;
+    for (int k = 0; k < ksl; ++k) { s += red_s[k * cpg + t]; q += red_q[k * cpg + t]; }
+    if (p.emb) {
+      const float e = bf2f(p.emb[(long long)n * p.emb_stride + g * cpg + t]);
+      q += 2.f * e * s + (float)p.HW * e * e;   // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
+      s += (float)p.HW * e;
+    }
+    ch_s[t] = s; ch_q[t] = q;
+  }
+  __syncthreads();
   if (t == 0) {
-    float s = 0.f, q = 0.f;
-    for (int cl = 0; cl < cpg; ++cl) { s += ch_s[cl]; q += ch_q[cl]; }
+    s = 0.f; q = 0.f;
+    for (int c = 0; c < cpg; ++c) { s += ch_s[c]; q += ch_q[c]; }
     red_s[0] = s; red_q[0] = q;
   }
   __syncthreads();
@@ -121,8 +120,8 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(const GnP p, float* ab) {
   const float mean = red_s[0] / cnt;
   const float var = fmaxf(red_q[0] / cnt - mean * mean, 0.f);
   const float rstd = rsqrtf(var + p.eps);
-  for (int cl = t; cl < cpg; cl += 256) {
-    const int c = g * cpg + cl;
+  if (t < cpg) {
+    const int c = g * cpg + t;
     const float ga = p.gamma ? bf2f(p.gamma[c]) : 1.f, be = p.beta ? bf2f(p.beta[c]) : 0.f;
     const float e = p.emb ? bf2f(p.emb[(long long)n * p.emb_stride + c]) : 0.f;
     ab[((long long)n * p.C + c) * 2] = ga * rstd;

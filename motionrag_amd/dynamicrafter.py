@@ -63,6 +63,9 @@ def conv3x3(x: torch.Tensor, conv: nn.Conv2d, *, stride: int = 1, upsample: bool
         return w.contiguous()
 
     wk = _CACHE.get(("c3", id(conv)), conv.weight, build)
+    if C % 64 == 0:                                                                 # implicit GEMM: the GEMM's DMA gathers the taps itself
+        return ops.conv_implicit(x.contiguous(), wk, conv.bias, ops.CONV_3X3, stride=stride, upsample=upsample,
+                                 resid=resid.contiguous() if resid is not None else None)
     rows = ops.im2col3x3(x, stride=stride, upsample=upsample)
     Hi, Wi = (2 * H, 2 * W) if upsample else (H, W)
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
@@ -78,6 +81,8 @@ def conv_t3(x: torch.Tensor, conv: nn.Conv3d, B: int, T: int, *, resid: Optional
     C = x.shape[-1]
     cout = conv.weight.shape[0]
     wk = _CACHE.get(("t3", id(conv)), conv.weight, lambda: conv.weight.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, 3 * C).contiguous())
+    if C % 64 == 0:
+        return ops.conv_implicit(x.contiguous(), wk, conv.bias, ops.CONV_T3, frames=T, resid=resid.contiguous() if resid is not None else None)
     rows = ops.unfold_t3(x, B, T)
     if resid is not None:
         return ops.linear(rows, wk, conv.bias, epilogue=ops.EPI_RESID, resid=resid.reshape(-1, cout)).view(x.shape[0], x.shape[1], cout)

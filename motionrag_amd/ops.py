@@ -354,6 +354,48 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     return out
 
 
+CONV_3X3, CONV_T3 = 1, 2
+
+
+def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor], mode: int, *, stride: int = 1, upsample: bool = False,
+                  frames: int = 0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """implicit-GEMM convolution (no materialised im2col), Cin % 64 == 0.
+    CONV_3X3: x [N, H, W, Cin] -> [N, Ho, Wo, Cout], wk [Cout, 9 Cin] in (ky, kx, cin) order.
+    CONV_T3:  x [(b t), HW, Cin] with `frames` = t -> same rows x Cout, wk [Cout, 3 Cin] in (kt, cin) order."""
+    from ._lib import ConvArgs
+    _dev(x, name="x"); _dev(wk, name="weight")
+    if not x.is_contiguous() or not wk.is_contiguous():
+        raise ValueError("conv_implicit: contiguous activation and weight required")
+    a = ConvArgs()
+    cout = wk.shape[0]
+    if mode == CONV_3X3:
+        N, H, W, C = x.shape
+        Hi, Wi = (2 * H, 2 * W) if upsample else (H, W)
+        out = torch.empty(N, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1, cout, dtype=torch.bfloat16, device=x.device)
+        a.N, a.H, a.Wd, a.stride, a.upsample = N, H, W, stride, 1 if upsample else 0
+        taps = 9
+    else:
+        NT, HW, C = x.shape
+        if frames <= 0 or NT % frames:
+            raise ValueError("conv_implicit: frames must divide the leading dim")
+        out = torch.empty(NT, HW, cout, dtype=torch.bfloat16, device=x.device)
+        a.N, a.H, a.Wd = NT // frames, frames, HW
+        taps = 3
+    if wk.shape[1] != taps * C:
+        raise ValueError(f"weight {tuple(wk.shape)} does not match {taps} taps x {C} channels")
+    if x.numel() >= 2 ** 31:
+        raise ValueError("conv_implicit: activation too large for 32-bit tap offsets")
+    a.x, a.W, a.bias, a.y = _p(x), _p(wk), _p(bias), _p(out)
+    a.Cin, a.Cout, a.mode, a.epilogue = C, cout, mode, EPI_NONE
+    if resid is not None:
+        _dev(resid, name="resid")
+        if resid.numel() != out.numel() or not resid.is_contiguous():
+            raise ValueError("conv_implicit: resid must be contiguous with the output's shape")
+        a.resid, a.epilogue = _p(resid), EPI_RESID
+    check(_lib.lib().mrag_conv_bf16(_stream(), ctypes.byref(a)), "mrag_conv_bf16")
+    return out
+
+
 def _kpad(k: int) -> int:
     return (k + 63) // 64 * 64
 

@@ -31,7 +31,7 @@ def test_struct_layouts_match_the_header():
     from motionrag_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "mrag_hip.h")).read()
     for cname, st in (("mrag_gemm_args", _lib.GemmArgs), ("mrag_attn_args", _lib.AttnArgs), ("mrag_ln_args", _lib.LnArgs),
-                      ("mrag_qknorm_rope_args", _lib.QkNormRopeArgs)):
+                      ("mrag_qknorm_rope_args", _lib.QkNormRopeArgs), ("mrag_groupnorm_args", _lib.GroupNormArgs), ("mrag_conv_args", _lib.ConvArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

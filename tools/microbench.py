@@ -50,6 +50,27 @@ def gemm():
         print(f"gemm {name:16s} M={M} N={N} K={K}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s ({fl/dt/2.5e15*100:.1f}%)")
 
 
+def gemm320():
+    """UNet level-0 shapes (28 frames x 72 x 128 rows, widths that are multiples of 320)"""
+    M = 28 * 9216
+    for name, N, K, epi in (("proj/to_out", 320, 320, ops.EPI_NONE), ("ff2", 320, 1280, ops.EPI_RESID), ("qkv", 960, 320, ops.EPI_NONE),
+                            ("level-1 to_out", 640, 640, ops.EPI_NONE)):
+        Mm = M if N != 640 else M // 4
+        x = torch.randn(Mm, K, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+        b = torch.randn(N, device=DEV).to(torch.bfloat16)
+        out = torch.empty(Mm, N, device=DEV, dtype=torch.bfloat16)
+        r = torch.randn(Mm, N, device=DEV).to(torch.bfloat16) if epi == ops.EPI_RESID else None
+        dt = timeit(lambda: ops.linear(x, w, b, out=out, epilogue=epi, resid=r), iters=30, warm=5)
+        fl = 2.0 * Mm * N * K
+        print(f"gemm {name:16s} M={Mm} N={N} K={K}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s  ({(Mm*K+Mm*N*(2 if r is not None else 1))*2/dt/1e9:.0f} GB/s of activations)")
+    x = torch.randn(28, 72, 128, 320, device=DEV).to(torch.bfloat16)
+    wk = (torch.randn(320, 9 * 320, device=DEV) * 0.02).to(torch.bfloat16)
+    b = torch.randn(320, device=DEV).to(torch.bfloat16)
+    dt = timeit(lambda: ops.conv_implicit(x, wk, b, ops.CONV_3X3), iters=30, warm=5)
+    print(f"conv3x3 320->320 on [28,72,128]: {dt*1e3:.3f} ms  {2.0*M*320*2880/dt/1e12:.1f} TFLOP/s")
+
+
 def topk():
     for N, Q in ((10000, 1), (10000, 256), (1000000, 1), (1000000, 64)):
         db = torch.randn(N, 768, device=DEV)
@@ -117,11 +138,18 @@ def count_flops(fn):
         tot[0] += 4.0 * q.shape[0] * q.shape[2] * q.shape[1] * k_.shape[1] * 64
         return att(q, k_, v, *a, **k)
 
-    ops.linear, ops.attention = linear, attention
+    cimp = ops.conv_implicit
+
+    def conv_implicit(x, wk, *a, **k):
+        y = cimp(x, wk, *a, **k)
+        tot[0] += 2.0 * (y.numel() // y.shape[-1]) * wk.shape[0] * wk.shape[1]
+        return y
+
+    ops.linear, ops.attention, ops.conv_implicit = linear, attention, conv_implicit
     try:
         fn()
     finally:
-        ops.linear, ops.attention = lin, att
+        ops.linear, ops.attention, ops.conv_implicit = lin, att, cimp
     return tot[0]
 
 

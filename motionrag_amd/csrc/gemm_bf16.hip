@@ -541,6 +541,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   const long long t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   if (const char* e = getenv("MRAG_GEMM_CFG")) {   // tuning knob (tools/microbench.py)
     if (e[0] == '1' && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
+    if (e[0] == '2') return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);                  // 128x128, 4 waves, 2 workgroups per CU
   }
   if (t256 >= 192 && wide_n_pays(a->N) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, a->epilogue);   // 256x320 tile
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, a->epilogue);

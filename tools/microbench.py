@@ -54,12 +54,12 @@ def gemm320():
     """UNet level-0 shapes (28 frames x 72 x 128 rows, widths that are multiples of 320)"""
     M = 28 * 9216
     for name, N, K, epi in (("proj/to_out", 320, 320, ops.EPI_NONE), ("ff2", 320, 1280, ops.EPI_RESID), ("qkv", 960, 320, ops.EPI_NONE),
-                            ("level-1 to_out", 640, 640, ops.EPI_NONE)):
+                            ("level-1 to_out", 640, 640, ops.EPI_NONE), ("geglu proj", 2560, 320, ops.EPI_GEGLU)):
         Mm = M if N != 640 else M // 4
         x = torch.randn(Mm, K, device=DEV).to(torch.bfloat16)
         w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
         b = torch.randn(N, device=DEV).to(torch.bfloat16)
-        out = torch.empty(Mm, N, device=DEV, dtype=torch.bfloat16)
+        out = torch.empty(Mm, N // 2 if epi == ops.EPI_GEGLU else N, device=DEV, dtype=torch.bfloat16)
         r = torch.randn(Mm, N, device=DEV).to(torch.bfloat16) if epi == ops.EPI_RESID else None
         dt = timeit(lambda: ops.linear(x, w, b, out=out, epilogue=epi, resid=r), iters=30, warm=5)
         fl = 2.0 * Mm * N * K

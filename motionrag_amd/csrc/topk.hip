@@ -4,11 +4,11 @@
 // src/data/rag.py:54; caller src/data/datamodule.py:231-236).  HBM-bound: the [N, D] fp32 database is
 // streamed once per tile of 16 queries.
 //
-//   * lane = database row: every distance is ONE sequential fp32 fmaf chain over d = 0..D-1, so the
-//     result is bit-identical to oracle/topk_oracle.c (and independent of grid shape);
-//   * a 256-row x 32-float chunk of the database is staged in LDS with coalesced 16-byte loads
-//     (row stride 36 floats -> conflict-free ds_read_b128 with lane = row), the 16 query vectors
-//     sit in LDS and are read as wave-wide broadcasts;
+//   * 16 lanes share a database row: lane s owns one of 16 interleaved fp32 fmaf chains (16-byte loads, the 16 lanes read
+//     256 contiguous bytes), a wavefront streams 4 rows per load instruction from HBM straight into registers with a
+//     one-step register prefetch; the 16 partial sums fold through a fixed butterfly -> bit-identical to
+//     oracle/topk_oracle.c mode 0 and independent of grid shape;
+//   * the query vectors (1, 4 or 16 per workgroup pass) sit in LDS and are read 16-lane-contiguous;
 //   * selection: each wavefront keeps, per query, a sorted top-64 spread over its 64 lanes.  A new
 //     64-row batch is bitonic-sorted with wave shuffles and merged (elementwise min against the
 //     reversed batch, then one bitonic merge); batches that cannot enter the current top-k are
@@ -21,11 +21,7 @@
 
 namespace {
 
-constexpr int QT = 16;         // queries per workgroup
 constexpr int ROWS = 256;      // rows per workgroup iteration (4 waves x 64 lanes)
-constexpr int DCH = 32;        // floats of D staged per chunk
-constexpr int LDT = 36;        // LDS row stride in floats (16-byte aligned, bank-conflict-free)
-constexpr int MAX_SLICES = 1024;
 
 struct Cand { float d; int r; };
 
@@ -80,24 +76,32 @@ struct TopkP {
   long long n_rows; int dim, nq, k, metric, slices, rows_per_slice;
 };
 
-template <int METRIC>
-__global__ __launch_bounds__(256) void topk_scan_kernel(const TopkP p) {
+// Distance of one (query, row) pair = 16 interleaved fp32 fmaf chains + a fixed 4-level pairwise tree (the definition
+// oracle/topk_oracle.c mode 0 restates):
+//   chain l (0..15) runs over k = 64 j + 4 l + c, j = 0.., c = 0..3, in that order;  d = tree(p[0..15]) with
+//   p[l] += p[l ^ 8], then ^4, ^2, ^1 (float addition is commutative, so every lane of the butterfly holds the same bits).
+// Mapping: 16 lanes share a row (lane s owns chain s: one 16-byte load per 64-float block -> the 16 lanes read 256
+// contiguous bytes), a wavefront streams 4 rows per load instruction straight from HBM into registers (no LDS staging of the
+// database), 16 such row-quads make the 64-row batch whose candidates sit one per lane for the bitonic selection.
+// The queries (QT per workgroup pass) live in LDS and are read as 16-lane-contiguous ds_read_b128.
+template <int METRIC, int QT, int JC>
+__global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const TopkP p) {   // <= 168 / 128 VGPRs: 3-4 waves per SIMD stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* qs = (float*)smem;                      // [QT][dim]
-  float* tile = qs + QT * p.dim;                 // [ROWS][LDT]
+  float* qs = (float*)smem;                      // [QT][dimp], dimp = dim rounded up to 64, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, s = lane & 15;
   const int q0 = blockIdx.y * QT;
   const int slice = blockIdx.x;
+  const int nj = (p.dim + 63) / 64, dimp = nj * 64;
 
-  // stage the query tile (zero-fill past nq)
-  for (int i = tid; i < QT * p.dim; i += 256) {
-    const int qi = i / p.dim;
-    qs[i] = (q0 + qi < p.nq) ? p.q[(long long)(q0 + qi) * p.dim + (i - qi * p.dim)] : 0.f;
+  for (int i = tid; i < QT * dimp; i += 256) {
+    const int qi = i / dimp, k = i - qi * dimp;
+    qs[i] = (q0 + qi < p.nq && k < p.dim) ? p.q[(long long)(q0 + qi) * p.dim + k] : 0.f;
   }
+  __syncthreads();
   int excl[QT];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) excl[qi] = (p.excl && q0 + qi < p.nq) ? p.excl[q0 + qi] : INT_MIN;
-
   Cand run[QT];
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) { run[qi].d = INFINITY; run[qi].r = INT_MAX; }
@@ -105,30 +109,36 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const TopkP p) {
   const long long row_begin = (long long)slice * p.rows_per_slice;
   long long row_end = row_begin + p.rows_per_slice;
   if (row_end > p.n_rows) row_end = p.n_rows;
+  const int nchunk = nj / JC;                    // JC divides nj (host picks JC)
+  const bool tail = (p.dim & 63) != 0;           // last 64-block is partial: lanes past the row end contribute exact zeros
 
-  for (long long r0 = row_begin; r0 < row_end; r0 += ROWS) {
-    float acc[QT];
+  for (long long r0 = row_begin + wave * 64; r0 < row_end; r0 += ROWS) {
+    // (quad t, chunk ch) stream
+    auto load = [&](int t, int ch, f32x4* dst) {
+      long long row = r0 + 4 * t + g;
+      if (row >= p.n_rows) row = p.n_rows - 1;
+      const float* base = p.db + row * p.dim + 4 * s;
 #pragma unroll
-    for (int qi = 0; qi < QT; ++qi) acc[qi] = 0.f;
-    for (int d0 = 0; d0 < p.dim; d0 += DCH) {
-      __syncthreads();  // previous chunk consumed (also orders the query staging on the first pass)
-      // coalesced stage: thread -> (row = tid/8 + 32 i, 16-byte column tid%8)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rr = (tid >> 3) + 32 * i;
-        long long grow = r0 + rr;
-        if (grow >= p.n_rows) grow = p.n_rows - 1;
-        const f32x4 v = *(const f32x4*)(p.db + grow * p.dim + d0 + (tid & 7) * 4);
-        *(f32x4*)(tile + rr * LDT + (tid & 7) * 4) = v;
+      for (int jj = 0; jj < JC; ++jj) {
+        const int j = ch * JC + jj;
+        if (tail && 64 * j + 4 * s >= p.dim) dst[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else dst[jj] = __builtin_nontemporal_load((const f32x4*)(base + 64 * j));
       }
-      __syncthreads();
-      const float* trow = tile + tid * LDT;
+    };
+    float dist[QT], acc[QT];
 #pragma unroll
-      for (int c = 0; c < DCH; c += 4) {
-        const f32x4 x = *(const f32x4*)(trow + c);
+    for (int qi = 0; qi < QT; ++qi) { dist[qi] = 0.f; acc[qi] = 0.f; }
+    int lt = 0, lch = 0;                          // next (quad, chunk) to request
+    auto advance = [&]() { if (++lch == nchunk) { lch = 0; ++lt; } };
+    int t = 0, ch = 0;                            // (quad, chunk) being consumed
+    auto consume = [&](const f32x4* xb) {
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj) {
+        const f32x4 x = xb[jj];
+        const float* qp = qs + (ch * JC + jj) * 64 + 4 * s;
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
-          const f32x4 qv = *(const f32x4*)(qs + qi * p.dim + d0 + c);  // wave-wide broadcast
+          const f32x4 qv = *(const f32x4*)(qp + qi * dimp);
           if constexpr (METRIC == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float df = qv[e] - x[e]; acc[qi] = __builtin_fmaf(df, df, acc[qi]); }
@@ -138,16 +148,55 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const TopkP p) {
           }
         }
       }
+      if (++ch == nchunk) {                       // row-quad t finished: fixed tree over the 16 chains, lane s keeps quad s
+        ch = 0;
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) {
+          float v = acc[qi];
+          v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+          if (t == s) dist[qi] = v;
+          acc[qi] = 0.f;
+        }
+        ++t;
+      }
+    };
+    const int nit = 16 * nchunk;
+    if constexpr (QT == 1) {
+      // single query: latency-bound -> 4-deep register ring, statically indexed (step loop unrolled by 4; nit % 4 == 0)
+      constexpr int PF = 4;
+      f32x4 ring[PF][JC];
+#pragma unroll
+      for (int u = 0; u < PF - 1; ++u) {
+        if (lt < 16) { load(lt, lch, ring[u]); advance(); }
+      }
+      for (int it = 0; it < nit; it += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          if (lt < 16) { load(lt, lch, ring[(u + PF - 1) % PF]); advance(); }
+          consume(ring[u]);
+        }
+      }
+    } else {
+      // query tiles: the 4 / 16 chains need the registers and the issue slots -> two steps ahead, rotated by moves
+      f32x4 cur[JC], n1[JC], n2[JC];
+      load(lt, lch, cur); advance();
+      if (lt < 16) { load(lt, lch, n1); advance(); }
+      for (int it = 0; it < nit; ++it) {
+        if (lt < 16) { load(lt, lch, n2); advance(); }
+        consume(cur);
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) { cur[jj] = n1[jj]; n1[jj] = n2[jj]; }
+      }
     }
-    const long long myrow = r0 + tid;
+    const long long myrow = r0 + 4 * s + g;      // the row whose distance this lane captured
     const bool valid = myrow < row_end;
     const int grp = (valid && p.group) ? p.group[myrow] : INT_MIN + 1;
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
       Cand c;
-      const float dist = METRIC == 0 ? acc[qi] : 1.0f - acc[qi];
+      const float d = METRIC == 0 ? dist[qi] : 1.0f - dist[qi];
       const bool ok = valid && !(p.group && grp == excl[qi]) && (q0 + qi < p.nq);
-      c.d = ok ? dist : INFINITY;
+      c.d = ok ? d : INFINITY;
       c.r = ok ? (int)myrow : INT_MAX;
       // skip the sort when nothing in this 64-row batch can enter the current top-k
       const Cand kth = cand_shfl(run[qi], p.k - 1);
@@ -164,17 +213,47 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const TopkP p) {
   }
 }
 
-// one workgroup (4 waves) per query: merge the per-wave partial lists
+// one workgroup (4 waves) per query: merge the per-wave partial lists (each sorted ascending, 64 entries).
+// Phase A bounds the answer: the k-th smallest of the lists' MINIMA is an upper bound of the final k-th distance, so only lists
+// whose minimum does not exceed it can contribute (about k of thousands).  Phase B merges just those.  The result is the
+// unique top-k under the total order (distance, row), whatever the merge order.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
   __shared__ Cand sh[4][64];
+  __shared__ Cand thr_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
   const int nparts = p.slices * 4;
-  Cand run; run.d = INFINITY; run.r = INT_MAX;
-  for (int part = wave; part < nparts; part += 4) {
-    const Cand c = p.ws[((long long)q * nparts + part) * 64 + lane];  // already sorted ascending
-    run = wave_merge_top(run, c, lane);
+  const Cand* lists = p.ws + (long long)q * nparts * 64;
+  Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
+  Cand best = inf;
+  for (int base = wave * 64; base < nparts; base += 256) {
+    const int part = base + lane;
+    Cand m = part < nparts ? lists[(long long)part * 64] : inf;
+    m = wave_sort(m, lane);
+    best = wave_merge_top(best, m, lane);
   }
+  sh[wave][lane] = best;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) best = wave_merge_top(best, sh[w][lane], lane);
+    if (lane == p.k - 1) thr_s = best;           // k-th smallest minimum
+  }
+  __syncthreads();
+  const Cand thr = thr_s;
+  Cand run = inf;
+  for (int base = wave * 64; base < nparts; base += 256) {
+    const int part = base + lane;
+    const Cand m = part < nparts ? lists[(long long)part * 64] : inf;
+    unsigned long long todo = __ballot(part < nparts && !cand_less(thr, m));   // min <= thr
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const Cand c = lists[(long long)(base + src) * 64 + lane];
+      run = wave_merge_top(run, c, lane);
+    }
+  }
+  __syncthreads();
   sh[wave][lane] = run;
   __syncthreads();
   if (wave == 0) {
@@ -188,8 +267,12 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
   }
 }
 
+inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
+
 void plan(long long n_rows, int nq, int* slices, int* rows_per_slice) {
+  const int QT = pick_qt(nq);
   const int ntq = (nq + QT - 1) / QT;
+  const int MAX_SLICES = 2048;
   long long tiles = (n_rows + ROWS - 1) / ROWS;
   long long s = MAX_SLICES / ntq;
   if (s < 1) s = 1;
@@ -215,7 +298,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   if (!db || !queries || !out_rows || !out_dist || !workspace) return MRAG_EINVAL;
   if (n_rows <= 0 || n_rows > INT_MAX - 1 || n_queries <= 0 || dim <= 0) return MRAG_EINVAL;
   if (k <= 0 || k > 64) return MRAG_ENOTSUP;
-  if (dim % DCH != 0 || dim > 1024) return MRAG_ENOTSUP;
+  if (dim % 4 != 0 || dim > 1024) return MRAG_ENOTSUP;
   if (metric != 0 && metric != 1) return MRAG_EINVAL;
   if (exclude && !group) return MRAG_EINVAL;
   if (((uintptr_t)db | (uintptr_t)queries) & 15) return MRAG_EINVAL;
@@ -226,11 +309,21 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   p.n_rows = n_rows; p.dim = dim; p.nq = n_queries; p.k = k; p.metric = metric;
   plan(n_rows, n_queries, &p.slices, &p.rows_per_slice);
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)(QT * dim + ROWS * LDT) * sizeof(float);
-  auto kfn = metric == 0 ? topk_scan_kernel<0> : topk_scan_kernel<1>;
-  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH(kfn, dim3(p.slices, (n_queries + QT - 1) / QT), dim3(256), lds, s, p);
+  const int QT = pick_qt(n_queries), nj = (dim + 63) / 64;
+  // blocks of 64 floats per register-ring step: 4 for the single query, 2 for query tiles (their chains need the registers)
+  const int JCsel = QT == 1 ? (nj % 4 == 0 ? 4 : 1) : (nj % 2 == 0 ? 2 : 1);
+  const size_t lds = (size_t)QT * nj * 64 * sizeof(float);
+  const dim3 grid(p.slices, (n_queries + QT - 1) / QT), block(256);
+#define MRAG_TOPK_CASE(M, Q, J)                                                                                   \
+  if (metric == M && QT == Q && JCsel == J) {                                                                     \
+    auto kfn = topk_scan_kernel<M, Q, J>;                                                                         \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    if (e != hipSuccess) return (int)e;                                                                           \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                                     \
+  }
+  MRAG_TOPK_CASE(0, 1, 1) MRAG_TOPK_CASE(0, 1, 4) MRAG_TOPK_CASE(0, 4, 1) MRAG_TOPK_CASE(0, 4, 2) MRAG_TOPK_CASE(0, 16, 1) MRAG_TOPK_CASE(0, 16, 2)
+  MRAG_TOPK_CASE(1, 1, 1) MRAG_TOPK_CASE(1, 1, 4) MRAG_TOPK_CASE(1, 4, 1) MRAG_TOPK_CASE(1, 4, 2) MRAG_TOPK_CASE(1, 16, 1) MRAG_TOPK_CASE(1, 16, 2)
+#undef MRAG_TOPK_CASE
   MRAG_LAUNCH_CHECK();
   MRAG_LAUNCH(topk_merge_kernel, dim3(n_queries), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();

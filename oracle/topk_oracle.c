@@ -13,8 +13,8 @@
  * reference holds no test or golden vector for retrieval.
  *
  * Two scoring modes:
- *   mode 0: float32 sequential fmaf chain over d = 0..D-1 -- the exact chain the HIP kernel runs, so
- *           distances and indices are BIT-EXACT comparable;
+ *   mode 0: float32, 16 interleaved fmaf chains + a fixed pairwise tree (chain16 below) -- the exact evaluation
+ *           order of the HIP kernel, so distances and indices are BIT-EXACT comparable;
  *   mode 1: float64 accumulation (canonical math), used to check that mode 0 ranks the same rows.
  * Ties: (distance asc, row asc).  Missing results: row = -1, dist = +inf.
  */
@@ -26,12 +26,35 @@ typedef struct { double d; int32_t r; } cand_t;
 
 static int cand_less(cand_t a, cand_t b) { return a.d < b.d || (a.d == b.d && a.r < b.r); }
 
+/* mode 0: the fp32 evaluation order the HIP kernel uses (motionrag_amd/csrc/topk.hip): 16 interleaved fmaf chains -- chain l
+ * runs over k = 64 j + 4 l + c (j = 0.., c = 0..3) -- folded by a fixed pairwise tree p[l] += p[l ^ 8], ^4, ^2, ^1.  (A SIMD
+ * flat scan such as lance's also keeps per-lane partial sums and adds them horizontally at the end; the exact lane count of
+ * lance's kernels is not pinned, see the header.) */
+static float chain16(const float* q, const float* x, int dim, int metric) {
+  float p[16];
+  for (int l = 0; l < 16; ++l) {
+    float acc = 0.0f;
+    for (int j = 0; 64 * j + 4 * l < dim; ++j)
+      for (int c = 0; c < 4; ++c) {
+        const int k = 64 * j + 4 * l + c;
+        if (k >= dim) break;
+        if (metric == 0) { const float df = q[k] - x[k]; acc = fmaf(df, df, acc); }
+        else acc = fmaf(q[k], x[k], acc);
+      }
+    p[l] = acc;
+  }
+  for (int m = 8; m >= 1; m >>= 1) {
+    float t[16];
+    for (int l = 0; l < 16; ++l) t[l] = p[l] + p[l ^ m];
+    for (int l = 0; l < 16; ++l) p[l] = t[l];
+  }
+  return p[0];
+}
+
 static double score(const float* q, const float* x, int dim, int metric, int mode) {
   if (mode == 0) {
-    float acc = 0.0f;
-    if (metric == 0) { for (int d = 0; d < dim; ++d) { float df = q[d] - x[d]; acc = fmaf(df, df, acc); } return (double)acc; }
-    for (int d = 0; d < dim; ++d) acc = fmaf(q[d], x[d], acc);
-    return (double)(1.0f - acc);
+    const float acc = chain16(q, x, dim, metric);
+    return metric == 0 ? (double)acc : (double)(1.0f - acc);
   } else {
     double acc = 0.0;
     if (metric == 0) { for (int d = 0; d < dim; ++d) { double df = (double)q[d] - (double)x[d]; acc += df * df; } return acc; }

@@ -272,3 +272,42 @@ def dc_ddim_step(v_cond, v_uncond, x, noise, guidance, ac32, t, sigma, a_t, a_pr
     pred_x0 = (sa * x - sb * v) * (scale_prev / scale_t)
     dir_xt = torch.sqrt(1.0 - a_prev - sigma ** 2) * e_t
     return torch.sqrt(a_prev) * pred_x0 + dir_xt + sigma * noise, pred_x0
+
+
+# ------------------------------------------------------------------------------------------------ generation glue (row a20)
+def image_guided_synthesis_ref(unet_sd: SD, spec: "UNetSpec", proj_sd: SD, embedder, text, first_stage, condition_transformer, image: torch.Tensor,
+                               prompts, ref_videos: torch.Tensor, num_frames: int, ddim_steps: int, guidance: float, fs: int, x_T: torch.Tensor,
+                               noises, proj_heads: int = 2, proj_depth: int = 2) -> torch.Tensor:
+    """scripts/evaluation/inference.py:174-305 + pipelines/pipeline.py:64-115 restated on the oracle's own UNet / DDIM restatement
+    (condition_transformer branch, uncond_type 'empty_seq', conditioning_key 'hybrid', eta = 1).  Returns frames [b, t, c, h, w]."""
+    from . import cama_ref
+    b = image.shape[0]
+    videos = image[:, :, None].expand(-1, -1, num_frames, -1, -1)                                     # pipeline.py:95
+    img = videos[:, :, 0]                                                                              # inference.py:189
+    proj = lambda e: cama_ref.resampler(proj_sd, e, proj_heads, proj_depth)
+    cond = {"image": proj(embedder(img)),                                                               # :190-192
+            "action": condition_transformer.predict({"ref_videos": ref_videos, "video": img[:, None].expand(-1, ref_videos.size(2), -1, -1, -1)}),   # :219-223
+            "prompt": text(prompts)}                                                                    # :225-226
+    x = videos.permute(0, 2, 1, 3, 4).reshape(b * num_frames, *videos.shape[1:2], *videos.shape[3:])    # get_latent_z :165-170
+    z = first_stage.encode_first_stage(x)
+    z = z.reshape(b, num_frames, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+    img_cat = z[:, :, :1].expand(-1, -1, z.shape[2], -1, -1)                                            # :235-237
+    uc = {"prompt": text(b * [""]), "image": proj(embedder(torch.zeros_like(img))),                     # :239-251
+          "action": condition_transformer.encode_vision(torch.zeros_like(ref_videos[:, 0:1]))[:, 0]}     # :257-259
+    ac = dc_schedule()
+    ts = dc_ddim_timesteps(ddim_steps)
+    sig, al, alp = dc_ddim_params(ac, ts, 1.0)
+    ac32 = torch.tensor(ac, dtype=torch.float32)
+    sc_t = torch.from_numpy(dc_scale_arr())[ts]
+    sc_prev = torch.cat([sc_t[0:1], sc_t[:-1]])
+    xs = x_T.clone()
+    fs_t = torch.tensor([fs] * (2 * b))
+    for i in range(len(ts)):                                                                            # ddim.py:166-200, CFG batch cond FIRST :219-237
+        index = len(ts) - 1 - i
+        t = int(ts[index])
+        xin = torch.cat([torch.cat([xs, img_cat], dim=1)] * 2, dim=0)
+        ctx = {k: torch.cat([cond[k], uc[k]], dim=0) for k in cond}
+        v = unet_forward(unet_sd, spec, xin, torch.full((2 * b,), t), ctx, fs_t)
+        xs, _ = dc_ddim_step(v[:b], v[b:], xs, noises[i], guidance, ac32, t, sig[index], al[index], alp[index], sc_t[index], sc_prev[index])
+    out = first_stage.decode_first_stage(xs)                                                            # :301  b c t h w
+    return out.permute(0, 2, 1, 3, 4)                                                                   # pipeline.py:115

@@ -87,7 +87,7 @@ def install_stubs():
               "lightning", "lightning.pytorch.utilities", "lightning.pytorch.utilities.types", "lightning.pytorch.cli",
               "lightning.pytorch.loggers", "lightning.pytorch.callbacks", "diffusers", "diffusers.models", "diffusers.models.lora",
               "diffusers.models.attention_processor", "diffusers.models.embeddings", "diffusers.utils", "timm", "timm.models",
-              "timm.models.layers"]:
+              "timm.models.layers", "omegaconf", "decord"]:
         _stub(n)
     _stub("lightning.pytorch", LightningModule=LightningModule)
     sys.modules["lightning"].pytorch = sys.modules["lightning.pytorch"]
@@ -203,7 +203,8 @@ def main():
     np.savez(os.path.join(OUT, "dc_cross_attention.npz"), x=xq.numpy(), prompt=ctx["prompt"].numpy(), image=ctx["image"].numpy(),
              action=ctx["action"].numpy(), y_cross=y_cross.numpy(), y_self=y_self.numpy(), **blob)
     # ---- G8-G12 DynamiCrafter UNet blocks, reduced-width UNetModel, schedule tables, DDIM steps ----
-    gen_dynamicrafter(attn_mod)
+    unet_ref = gen_dynamicrafter(attn_mod)
+    gen_dc_pipeline(unet_ref, res_mod)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.0f} KiB")
@@ -329,9 +330,110 @@ def gen_dynamicrafter(attn_mod):
         tsx = torch.full((2,), int(steps[i]), dtype=torch.long)
         x, _ = smp.p_sample_ddim(x, c, tsx, index=index, unconditional_guidance_scale=2.0, unconditional_conditioning=uc)
         xs.append(x.numpy())
+    gen_dynamicrafter.tables = (ac, betas)
     np.savez(os.path.join(OUT, "dc_schedule.npz"), alphas_cumprod=ac, t30=t30, t50=t50, sigmas=sig.numpy(), alphas=al.numpy(), alphas_prev=alp.numpy(),
              temb=temb.numpy(), xT=xT.numpy(), c_shift=c["shift"].numpy(), uc_shift=uc["shift"].numpy(), noises=np.stack(noises), xs=np.stack(xs),
              scale_arr=smp.model.scale_arr.numpy())
+    return unet
+
+
+def gen_dc_pipeline(unet, res_mod):
+    """G14: the reference's OWN image_guided_synthesis / DynamiCrafterPipelineRef glue (inference.py:174-305, pipelines/pipeline.py:64-115)
+    driven end to end on CPU: reduced-width reference UNetModel (the G10 weights), reference Resampler as image_proj_model, reference
+    DDIMSampler, deterministic stand-ins (oracle/stubs.py) for the third-party encoders / VAE.  The torch.randn stream the sampler draws
+    (x_T, then one eta-noise per step) is recorded so that the GPU test can replay it."""
+    import importlib
+    from oracle import stubs
+    inf = importlib.import_module("dcroot.scripts.evaluation.inference")
+    ddim_mod = importlib.import_module("dcroot.lvdm.models.samplers.ddim")
+    ac, betas = gen_dynamicrafter.tables
+
+    class Wrapper(nn.Module):                       # DiffusionWrapper, conditioning_key 'hybrid' (ddpm3d.py:1378-1382)
+        conditioning_key = "hybrid"
+
+        def __init__(self, dm):
+            super().__init__()
+            self.diffusion_model = dm
+
+        def forward(self, x, t, c_concat=None, c_crossattn=None, **kwargs):
+            return self.diffusion_model(torch.cat([x] + c_concat, dim=1), t, context=c_crossattn, **kwargs)
+
+    class DuckLVD(nn.Module):                       # the attributes image_guided_synthesis and DDIMSampler read from LatentVisualDiffusion
+        num_timesteps, parameterization, use_dynamic_rescale, uncond_type = 1000, "v", True, "empty_seq"
+        action_embedder = None
+
+        def __init__(self):
+            super().__init__()
+            self.model = Wrapper(unet)
+            self.embedder = stubs.ImageEmbedderStub(tokens=9, dim=48)
+            self.image_proj_model = res_mod.Resampler(dim=64, depth=2, dim_head=64, heads=2, num_queries=3, embedding_dim=48, output_dim=64, video_length=4).eval()
+            seeded_state(self.image_proj_model, 404, std=0.08)
+            self.condition_transformer = stubs.ConditionTransformerStub(dim=64)
+            self.first_stage = stubs.FirstStageStub()
+            self.text = stubs.TextStub(tokens=7, dim=64)
+            self.alphas_cumprod_np = ac
+            self.register_buffer("betas", torch.tensor(betas, dtype=torch.float32))
+            self.register_buffer("alphas_cumprod", torch.tensor(ac, dtype=torch.float32))
+            self.register_buffer("alphas_cumprod_prev", torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32))
+            self.register_buffer("sqrt_alphas_cumprod", torch.tensor(np.sqrt(ac), dtype=torch.float32))
+            self.register_buffer("sqrt_one_minus_alphas_cumprod", torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32))
+            self.register_buffer("scale_arr", torch.tensor(np.concatenate((np.linspace(1.0, 0.3, 400), np.full(1000, 0.3))), dtype=torch.float32))
+
+        device = torch.device("cpu")
+
+        def get_learned_conditioning(self, prompts):
+            return self.text(prompts)
+
+        def encode_first_stage(self, x):
+            return self.first_stage.encode_first_stage(x)
+
+        def decode_first_stage(self, z):
+            return self.first_stage.decode_first_stage(z)
+
+        def apply_model(self, x_noisy, t, cond, **kwargs):       # ddpm3d.py:745-760 (dict branch)
+            return self.model(x_noisy, t, **cond, **kwargs)
+
+        def predict_start_from_z_and_v(self, x, t, v):           # ddpm3d.py:251-256
+            return self.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * x - self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * v
+
+        def predict_eps_from_z_and_v(self, x, t, v):             # ddpm3d.py:258-263
+            return self.sqrt_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * v + self.sqrt_one_minus_alphas_cumprod[t].view(-1, 1, 1, 1, 1) * x
+
+    ddim_mod.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)      # the reference forces .to("cuda")
+    model = DuckLVD().eval()
+    pipe_cls = type("Pipe", (), {})                  # pipelines/pipeline.py cannot be imported (pulls ddpm3d -> lightning/torchvision): call the glue directly
+    gi = torch.Generator().manual_seed(405)
+    b, T, H, W = 1, 4, 64, 64
+    image = torch.rand(b, 3, H, W, generator=gi) * 2 - 1
+    ref_videos = torch.rand(b, 3, T, 3, 16, 16, generator=gi) * 2 - 1
+    prompts = ["a corgi running on the beach"]
+    drawn = []
+    real_randn = torch.randn
+
+    def recording_randn(*a, **k):
+        k.pop("device", None)
+        v = real_randn(*a, **k)
+        drawn.append(v.clone())
+        return v
+
+    torch.manual_seed(406)
+    torch.randn = recording_randn
+    try:
+        with torch.no_grad():
+            videos = image[:, :, None].expand(-1, -1, T, -1, -1)                         # DynamiCrafterPipelineRef.__call__ :95
+            out = inf.image_guided_synthesis(model=model, prompts=prompts, videos=videos, noise_shape=[b, 4, T, H // 8, W // 8], n_samples=1, ddim_steps=5,
+                                             ddim_eta=1.0, unconditional_guidance_scale=2.0, cfg_img=None, fs=15, text_input=True, multiple_cond_cfg=False,
+                                             loop=False, interp=False, timestep_spacing="uniform", guidance_rescale=0.0, ref_videos=ref_videos,
+                                             ref_fusion_type=None, metadata=None)
+    finally:
+        torch.randn = real_randn
+    frames = out[:, 0].permute(0, 2, 1, 3, 4)                                            # 'b 1 c t h w -> b t c h w'  :115
+    shape5 = [d for d in drawn if tuple(d.shape) == (b, 4, T, H // 8, W // 8)]
+    assert len(shape5) == 6, [tuple(d.shape) for d in drawn]                             # x_T + one noise per DDIM step (5 steps)
+    import json
+    np.savez(os.path.join(OUT, "dc_pipeline.npz"), image=image.numpy(), ref_videos=ref_videos.numpy(), prompt=np.array(prompts[0]), frames=frames.numpy(),
+             x_T=shape5[0].numpy(), noises=np.stack([d.numpy() for d in shape5[1:]]),
+             proj_meta=np.array(json.dumps(dict(seed=404, **SEEDED_META[404]))))
 
 
 if __name__ == "__main__":

@@ -322,3 +322,19 @@ def test_svd_oracle_self_consistency():
         cx, cv = svd_ref.euler_coeffs(float(sig[i]), float(sig[i + 1]))
         got = cx * x + cv * (vu + gs.view(1, -1, 1, 1, 1) * (vc - vu))
         assert torch.allclose(got, want, rtol=1e-10, atol=1e-10)
+
+
+def test_dc_pipeline_glue_oracle_matches_reference(golden_dir):
+    """row a20: the oracle's restatement of image_guided_synthesis / DynamiCrafterPipelineRef equals the reference's own run (G14)"""
+    import json
+    from oracle import stubs
+    from oracle.seeded import seeded_sd
+    g = _load(golden_dir, "dc_pipeline.npz")
+    _, sd, spec, _, _ = dc_unet_fixture(golden_dir)
+    pm = json.loads(str(g["proj_meta"]))
+    proj_sd = seeded_sd(pm["keys"], pm["shapes"], pm["seed"], pm["std"])
+    frames = dynamicrafter_ref.image_guided_synthesis_ref(
+        sd, spec, proj_sd, stubs.ImageEmbedderStub(tokens=9, dim=48), stubs.TextStub(tokens=7, dim=64), stubs.FirstStageStub(),
+        stubs.ConditionTransformerStub(dim=64), torch.from_numpy(g["image"]), [str(g["prompt"])], torch.from_numpy(g["ref_videos"]), num_frames=4,
+        ddim_steps=5, guidance=2.0, fs=15, x_T=torch.from_numpy(g["x_T"]), noises=[torch.from_numpy(n) for n in g["noises"]])
+    np.testing.assert_allclose(frames.numpy(), g["frames"], rtol=2e-3, atol=2e-3)

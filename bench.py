@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=42, help="debug only: the judged workload is 42")
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
+                    help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
+                         "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
     return ap.parse_args()
 
 
@@ -108,12 +111,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(dev))
     from motionrag_amd import _lib, ops
-    from motionrag_amd.dist import gather_latents
+    from motionrag_amd.dist import SequenceParallel, gather_latents
     _lib.lib()   # fail loudly if the HIP library is missing
 
     lat_frames = (args.frames - 1) // 4 + 1
     dit, cam, pipe = build_models(dev, args.layers, lat_frames)
-    g = torch.Generator().manual_seed(1234 + rank)          # each rank denoises its own clip
+    seq = args.shard == "sequence" and world > 1
+    sp = SequenceParallel(rank, world) if seq else None
+    g = torch.Generator().manual_seed(1234 + (0 if seq else rank))          # each rank denoises its own clip (sequence mode: the same clip)
     b = 1
     latents = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
     image_latents = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
@@ -141,7 +146,7 @@ def main():
     def step(i):
         t = int(ts[i])
         timestep = torch.full((2 * b,), float(t), dtype=torch.float32, device=dev)
-        v = dit(latents, prompt, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=2 * b)
+        v = dit(latents, prompt, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=2 * b, sp=sp)
         ops.cfg_ddim_step_(v, latents, 6.0, *sched.coeffs(t))
 
     def barrier():
@@ -157,7 +162,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    gathered = gather_latents(latents, world)        # RCCL all-gather of the ranks' clips at the end of the loop
+    gathered = latents if seq else gather_latents(latents, world)        # RCCL all-gather of the ranks' clips at the end of the loop
     barrier()
     elapsed = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
@@ -171,7 +176,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        frames = args.frames * b * world
+        frames = args.frames * b * (1 if seq else world)
         value = frames / (elapsed / args.steps)
         durs = [e0.elapsed_time(e1) * 1e-3 for (_, _, e0, e1) in timing]
         flops = timing[0][1] if timing else 0.0
@@ -187,11 +192,12 @@ def main():
             traffic_src = "profiles/r1_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)"
         out = {
             "metric": "denoise_step_frames_per_sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if seq else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CogVideoX-5B-I2V DiT ({args.layers} layers) + CAMA motion injection, {args.frames}x480x720, CFG batch 2, "
-                                   f"one DDIM denoise step per clip, clip-sharded dp{world}", "clips_per_gpu": b, "tokens": S,
-                       "parallelism": f"dp{world}"},
+                                   f"one DDIM denoise step per clip, " + (f"token sequence sharded sp{world} (K/V all-gather per block)" if seq else f"clip-sharded dp{world}"),
+                       "clips_per_gpu": b, "tokens": S,
+                       "parallelism": (f"sp{world}" if seq else f"dp{world}")},
             "frames_per_sec_per_gpu": round(value / world, 4),
             "step_tflops_algorithmic": round(step_flops / 1e12, 1),
             "step_tflops_per_sec_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),

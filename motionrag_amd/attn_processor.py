@@ -77,9 +77,11 @@ class _FusedWeights:
         self._cache.clear()
 
 
-def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hidden_states: Optional[torch.Tensor], scale: float):
+def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hidden_states: Optional[torch.Tensor], scale: float, sp=None):
     """attn_processor.py:209-273 on the joint [text ; video] sequence x [B, S, D] (bf16, contiguous).
-    Returns the attention output BEFORE to_out: `o + scale * ip_attention(to_q_ip(o))`."""
+    Returns the attention output BEFORE to_out: `o + scale * ip_attention(to_q_ip(o))`.
+    `sp` (dist.SequenceParallel): x holds only this rank's rows (text_len / rope already local); K and V rows of all ranks are
+    all-gathered after qk-norm + RoPE, everything else stays local."""
     B, S, D = x.shape
     H = attn.heads
     fw = proc._fused
@@ -98,7 +100,12 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
                      nk.weight if nk is not None else None, nk.bias if nk is not None else None, cos, sin, text_len,
                      eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)     # :220-231
     q5 = qkv.view(B, S, 3, H, 64)
-    o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237
+    if sp is None:
+        o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237
+    else:
+        kv = q5[:, :, 1:].permute(1, 0, 2, 3, 4).contiguous()                     # [s_loc, B, 2, H, 64]: rows outermost -> the gather is one flat buffer
+        g = sp.all_gather(kv)                                                     # [S, B, 2, H, 64]
+        o = ops.attention(q5[:, :, 0], g[:, :, 0].permute(1, 0, 2, 3), g[:, :, 1].permute(1, 0, 2, 3), q_prescaled=True)
     if ip_hidden_states is not None and scale != 0:                               # :243-249
         ip = ip_hidden_states if ip_hidden_states.dtype == torch.bfloat16 else ip_hidden_states.to(torch.bfloat16)
         ip = ip.contiguous()

@@ -151,11 +151,13 @@ class CogVideoXTransformer3DModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
-                image_rotary_emb=None, image_latents: Optional[torch.Tensor] = None, batch: Optional[int] = None) -> torch.Tensor:
+                image_rotary_emb=None, image_latents: Optional[torch.Tensor] = None, batch: Optional[int] = None, sp=None) -> torch.Tensor:
         """hidden_states [Bl, F, C, H, W] bf16 (C = in_channels, or the noisy half when `image_latents`
         carries the other half); encoder_hidden_states [B, L, text_dim]; timestep [B] fp32;
         image_rotary_emb = ((cos, sin), action_emb) as handed over by the pipeline (pipeline.py:46-57).
-        Batch entry b reads latent b % Bl (CFG duplication without materialising torch.cat([latents] * 2))."""
+        Batch entry b reads latent b % Bl (CFG duplication without materialising torch.cat([latents] * 2)).
+        `sp` (dist.SequenceParallel): this rank computes rows [r0, r1) of the joint sequence of every batch entry; one K/V all-gather per
+        block and one all-gather of the projected output rows; the returned tensor is complete on every rank."""
         cfg = self.cfg
         D, Hh, p = cfg["dim"], cfg["heads"], cfg["patch"]
         B = encoder_hidden_states.shape[0] if batch is None else batch
@@ -174,14 +176,24 @@ class CogVideoXTransformer3DModel(nn.Module):
         ms = mod.stride(0)
 
         # patch embed (Conv2d k=2 s=2 as a GEMM over patch rows) + text projection + positional embedding
-        x = torch.empty(B, S, D, dtype=torch.bfloat16, device=hidden_states.device)
+        r0, r1 = (0, S) if sp is None else sp.shard(S)              # this rank's rows of the joint sequence
+        Sl = r1 - r0
+        Ltl = min(max(Lt - r0, 0), Sl)                              # local text rows come first
+        t0, v0, v1 = r0, max(r0, Lt) - Lt, r1 - Lt                  # text rows [t0, t0 + Ltl), video rows [v0, v1)
+        x = torch.empty(B, Sl, D, dtype=torch.bfloat16, device=hidden_states.device)
         pos = self.patch_embed.pos_embedding[0]
         patches = ops.patchify(hidden_states, image_latents, B).view(B, Nv, -1)
         for b in range(B):
-            ops.linear(encoder_hidden_states[b], self.patch_embed.text_proj.weight, self.patch_embed.text_proj.bias, out=x[b, :Lt],
-                       epilogue=ops.EPI_RESID, resid=pos[:Lt])
-            ops.linear(patches[b], self._fused["patch_w"], self.patch_embed.proj.bias, out=x[b, Lt:], epilogue=ops.EPI_RESID,
-                       resid=pos[Lt:Lt + Nv])
+            if Ltl > 0:
+                ops.linear(encoder_hidden_states[b, t0:t0 + Ltl], self.patch_embed.text_proj.weight, self.patch_embed.text_proj.bias, out=x[b, :Ltl],
+                           epilogue=ops.EPI_RESID, resid=pos[t0:t0 + Ltl])
+            if v1 > v0:
+                ops.linear(patches[b, v0:v1], self._fused["patch_w"], self.patch_embed.proj.bias, out=x[b, Ltl:], epilogue=ops.EPI_RESID,
+                           resid=pos[Lt + v0:Lt + v1])
+        if sp is not None and rope is not None:
+            rope = (rope[0][v0:v1], rope[1][v0:v1])                 # RoPE rows of the local video tokens
+        S_full, Lt_full = S, Lt
+        S, Lt = Sl, Ltl                                             # everything below is per-row: local row count / local split
 
         def chunk(layer_slot: int, j: int) -> torch.Tensor:
             off = (layer_slot * 6 + j) * D
@@ -193,7 +205,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             nh = ops.layernorm(x, blk.norm1.norm.weight, blk.norm1.norm.bias, cfg["norm_eps"], shift0=chunk(2 * i, 3), scale0=chunk(2 * i, 4),
                                shift1=chunk(2 * i, 0), scale1=chunk(2 * i, 1), rows_per_batch=S, split=Lt, mod_stride=ms)
             scale = proc.scale[0] if ip is not None else 0.0
-            o = joint_attention_core(blk.attn1, proc, nh, Lt, rope, ip, scale)
+            o = joint_attention_core(blk.attn1, proc, nh, Lt, rope, ip, scale, sp=sp)
             ops.linear(o, blk.attn1.to_out[0].weight, blk.attn1.to_out[0].bias, out=x, epilogue=ops.EPI_GATE_RESID, resid=x,
                        gate0=chunk(2 * i, 5), gate1=chunk(2 * i, 2), rows_per_batch=S, split=Lt, gate_stride=ms)
             nh = ops.layernorm(x, blk.norm2.norm.weight, blk.norm2.norm.bias, cfg["norm_eps"], shift0=chunk(2 * i + 1, 3),
@@ -210,7 +222,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         y = ops.layernorm(y, self.norm_out.norm.weight, self.norm_out.norm.bias, cfg["norm_eps"], shift0=sh, scale0=sc, shift1=sh, scale1=sc,
                           rows_per_batch=S, split=Lt, mod_stride=ms, out=y)
         out = ops.linear(y, self.proj_out.weight, self.proj_out.bias)
-        out = out[:, Lt:].contiguous()
+        if sp is not None:                                          # [Sl, B, C] per rank -> [S, B, C] -> [B, S, C]
+            out = sp.all_gather(out.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        out = out[:, Lt_full:].contiguous()
         return ops.unpatchify(out, B, F, cfg["out_channels"], H, W)
 
 
@@ -292,7 +306,7 @@ class CogVideoXImageToVideoCTPipeline:
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
-                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None) -> torch.Tensor:
+                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None) -> torch.Tensor:
         """the hot loop: latents [b, F, 16, h, w] bf16 (N(0,1) noise), prompt_embeds = cat([negative, positive])
         [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329)."""
         self.action_emb = action_emb
@@ -303,7 +317,7 @@ class CogVideoXImageToVideoCTPipeline:
         B = 2 * b
         for i, t in enumerate(ts):
             timestep = torch.full((B,), float(t), dtype=torch.float32, device=latents.device)
-            v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B)
+            v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B, sp=sp)
             sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))
             ops.cfg_ddim_step_(v, latents, guidance_scale, sa, sb, a_t, b_t)
             if callback is not None:

@@ -33,3 +33,33 @@ def gather_latents(latents: torch.Tensor, world: int) -> torch.Tensor:
         dist.all_gather(parts, x)
         out = torch.cat(parts, dim=0)
     return out
+
+
+class SequenceParallel:
+    """Tier 2: ONE clip's joint [text ; video] token sequence sharded over the ranks of a node (BASELINE config
+    "CogVideoX-5B-I2V 49x720x480 frame-sharded across 8xMI355X, RCCL all-gather over xGMI").  Every per-token op of the DiT stays
+    local to a rank's rows; the only exchange is one all-gather of the rank's K and V rows per block (after qk-norm + RoPE), so a
+    rank's queries attend to the whole sequence, plus one all-gather of the output rows at the end of the forward.
+
+    xGMI is point-to-point (7 links per GPU): the gather is a single RCCL all-gather of `S/world x B x 2D` bf16 per rank
+    (54.6 MB per rank and block at S = 17 776, B = 2, D = 3072), not a ring of small messages.  `all_gather` may be replaced
+    (tests run two 'ranks' as threads on one GPU)."""
+
+    def __init__(self, rank: int, world: int, all_gather=None, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self._ag = all_gather
+
+    def shard(self, n_rows: int):
+        if n_rows % self.world:
+            raise ValueError(f"sequence of {n_rows} rows does not split evenly over {self.world} ranks")
+        s = n_rows // self.world
+        return self.rank * s, (self.rank + 1) * s
+
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        """[n, ...] per rank -> [world * n, ...] (rank-major) on every rank"""
+        if self._ag is not None:
+            return self._ag(x)
+        x = x.contiguous()
+        out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out

@@ -50,3 +50,31 @@ def test_gather_latents_world1_is_identity():
     from motionrag_amd.dist import gather_latents
     x = torch.randn(2, 3)
     assert gather_latents(x, 1) is x
+
+
+def _sp_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from motionrag_amd.dist import SequenceParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = SequenceParallel(rank, world)
+        r0, r1 = sp.shard(82)
+        # the K/V exchange of one block: [s_loc, B, 2, H, 64] rows of this rank -> [S, B, 2, H, 64] on every rank, rank-major == row order
+        rows = torch.arange(r0, r1, dtype=torch.float32).view(-1, 1, 1, 1, 1).expand(-1, 2, 2, 1, 4).contiguous()
+        out = sp.all_gather(rows)
+        ret[rank] = ((r0, r1), tuple(out.shape), out[:, 0, 0, 0, 0].tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sequence_parallel_gather_world2_gloo():
+    """tier-2 sharding: row ranges tile the sequence and the gathered K/V rows come back in global row order on every rank"""
+    world, port = 2, 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sp_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][0] == (0, 41) and ret[1][0] == (41, 82)
+    for r in range(world):
+        assert ret[r][1] == (82, 2, 2, 1, 4) and ret[r][2] == [float(i) for i in range(82)]

@@ -236,3 +236,54 @@ def test_svd_processor_accepts_tuple_tensor(hip):
     got = attn(hidden, tt)
     want = attn(hidden, (img.to(DEV, torch.bfloat16).repeat_interleave(F, dim=0), act.to(DEV, torch.bfloat16)))   # r = F broadcast inside
     close_exactish(got, want, rtol=1e-6, atol_frac=1e-6)
+
+
+def test_sequence_parallel_dit_equals_unsharded(hip):
+    """SURVEY 8e tier 2: the joint token sequence sharded over 2 'ranks' (two threads with their own streams on this one GPU; the K/V
+    and output all-gathers are a barrier + concatenation) gives the same forward as the unsharded model on every rank."""
+    import threading
+    from motionrag_amd.dist import SequenceParallel
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit(seed=41)
+    g = torch.Generator().manual_seed(42)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(DEV, torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(DEV, torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(DEV, torch.bfloat16)
+    t = torch.tensor([481.0, 481.0], device=DEV)
+    cos, sin = (x.to(DEV) for x in cogvideox_ref.rope_3d(64, 3, 4, 6))
+    want = model(lat, text, t, image_rotary_emb=((cos, sin), ip), image_latents=img, batch=2)      # also builds the fused-weight caches
+    torch.cuda.synchronize()
+    world = 2
+    slots, bar, outs, errs = [None] * world, threading.Barrier(world), [None] * world, []
+
+    def gather_for(rank):
+        def ag(x):
+            torch.cuda.current_stream().synchronize()
+            slots[rank] = x.contiguous()
+            bar.wait()
+            out = torch.cat(list(slots), dim=0)
+            torch.cuda.current_stream().synchronize()
+            bar.wait()
+            return out
+        return ag
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                outs[rank] = model(lat, text, t, image_rotary_emb=((cos, sin), ip), image_latents=img, batch=2,
+                                   sp=SequenceParallel(rank, world, all_gather=gather_for(rank)))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                                            # surface thread failures in the test
+            errs.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not errs, errs
+    for r in range(world):
+        assert outs[r] is not None and outs[r].shape == want.shape
+        err = ((outs[r].float() - want.float()).norm() / want.float().norm()).item()
+        assert err < 2e-3, f"rank {r}: relative error {err}"
+    with pytest.raises(ValueError):
+        SequenceParallel(0, 3).shard(82)

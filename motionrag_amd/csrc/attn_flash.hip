@@ -45,6 +45,13 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
 #endif
 
+#ifndef MRAG_ATTN_MFMA_MAX
+// 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block) instead of 32 v_add per tile.
+// Measured on MI355X (interleaved A/B, B=2 H=48 S=17776): 992.6-994.8 vs 994.1-995.6 TFLOP/s -> neutral, so off: trading 128
+// vector-issue cycles for 64 matrix cycles does not move this kernel, i.e. it is not purely vector-issue-bound.
+#define MRAG_ATTN_MFMA_MAX 0
+#endif
+
 namespace {
 
 struct AttnP {
@@ -109,7 +116,16 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
   between();
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C
+#if MRAG_ATTN_MFMA_MAX
+  // The running max is subtracted BY THE MATRIX PIPE: one more k-step whose key fragment is the constant (-1, 0, ..., 0) and whose
+  // query fragment is (m, 0, ..., 0) adds -m to every score of the lane's query.  The vector pipe is the saturated one here
+  // (per tile 32 v_exp + 32 row-sum adds + 17 v_max3 + 16 cvt_pk against 16 MFMAs); this trades 32 v_add (128 issue cycles)
+  // for 2 MFMAs (64 matrix cycles, 16 issue cycles).  m is kept bf16-representable so the product is exact (softmax_tile).
+  const u32x4 kneg = {ln.hh == 0 ? 0x0000bf80u : 0u, 0u, 0u, 0u};
+  const u32x4 qm = {__float_as_uint(negm[1]), 0u, 0u, 0u};
+#else
   const float nm = negm[0];   // register-lean form: the running max is one VGPR and is subtracted after the chain
+#endif
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
@@ -119,8 +135,13 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
+#if MRAG_ATTN_MFMA_MAX
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
+#else
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
+#endif
 #else
   u32x4 k0f[4], k1f[4];
   const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
@@ -268,7 +289,13 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
   // deferred rescale: move the running max only on the first tile or when a row grew past THR
   const bool first = (t == 0);
   if (first || __any(tm > kThr)) {
-    const float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
+    float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_MFMA_MAX
+    // the shift lives in a bf16 MFMA operand: round the new running max to bf16 and move by the EXACT difference (both ends are
+    // bf16 values, their fp32 difference is exact), so O / l / P all see the same shift.  Rows that do not move keep delta == 0.
+    const float m_new = bf_round(r.m + delta);
+    delta = m_new - r.m;
+#endif
     if (!first) {
       const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -283,6 +310,9 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
     r.m += delta;
 #if MRAG_ATTN_WPS >= 4
     r.negm[0] = -r.m;
+#if MRAG_ATTN_MFMA_MAX
+    r.negm[1] = __uint_as_float(ln.hh == 0 ? (unsigned)f2bf(r.m) : 0u);   // query-side fragment (m, 0, ..., 0) of the max-subtracting k-step
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
 #else

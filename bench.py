@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=42, help="debug only: the judged workload is 42")
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
     ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
                     help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
                          "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
@@ -168,6 +169,18 @@ def main():
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     assert torch.isfinite(gathered.float()).all(), "non-finite latents"
 
+    # BASELINE's second metric, MEASURED outside the timed region: one whole clip = CAMA + 50 motion-injected DDIM steps (N = 1 only)
+    e2e_sec = None
+    if world == 1 and not args.no_e2e and args.layers == 42 and args.frames == 49:
+        lat2 = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ae = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
+        out2 = pipe.denoise(lat2, image_latents, prompt, ae, num_inference_steps=50, guidance_scale=6.0)
+        torch.cuda.synchronize()
+        e2e_sec = time.perf_counter() - t1
+        assert torch.isfinite(out2.float()).all(), "non-finite latents after 50 steps"
+
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -203,6 +216,7 @@ def main():
             "step_tflops_per_sec_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
             "cama_ms": round(cama_ms, 2), "cama_first_call_ms": round(cama_first_ms, 1),
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
+            "e2e_sec_per_clip_50_steps_measured": round(e2e_sec, 2) if e2e_sec is not None else None,
             "roofline": {"kernel": "attn_fwd_kernel<8,false,false,false> (joint text+video flash attention, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",

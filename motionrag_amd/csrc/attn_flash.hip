@@ -629,6 +629,75 @@ int launch_attn(hipStream_t s, AttnP p) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- tiny sequences
+// Temporal attention of the UNets (TemporalTransformer / TemporalBasicTransformerBlock: 14-16 frames per pixel, head_dim 64, one
+// (pixel, head) pair = 6 KB of Q/K/V) is pure data movement: the 64-key tiles of the flash kernel above would pad every pair 4-8x.
+// Here one wavefront owns a pair: Q and K go from global memory straight into 16x16x32 MFMA operand registers (row = lane & 15,
+// 16-byte chunk = lane >> 4), S^T = K.Q^T is 2 MFMAs, the softmax over <= 16 keys is 4 registers x 4 lane groups, P^T is re-laid into
+// the B operand with two cross-lane moves, V is staged (2 KB, row pitch 144 B) in a per-wave LDS slot and read column-wise for the
+// V^T operand of the four O^T = V^T.P^T MFMAs.  No barrier: every LDS byte is written and read by the same wave.
+__global__ __launch_bounds__(256) void attn_tiny_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) char vsm[4][16 * 144];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  char* vs = vsm[wave];
+  const int total = p.B * p.H;
+  for (int pair = blockIdx.x * 4 + wave; pair < total; pair += gridDim.x * 4) {
+    const int b = pair / p.H, h = pair - b * p.H, kb = b / p.kv_div;
+    const bf16_t* Qp = p.Q + (long long)b * p.q_sb + (long long)h * p.q_sh;
+    const bf16_t* Kp = p.K + (long long)kb * p.k_sb + (long long)h * p.k_sh;
+    const bf16_t* Vp = p.V + (long long)kb * p.v_sb + (long long)h * p.v_sh;
+    const int qrow = r16 < p.Sq ? r16 : p.Sq - 1, krow = r16 < p.Skv ? r16 : p.Skv - 1;   // clamped rows are masked / never stored
+    const bf16x8 q0 = *(const bf16x8*)(Qp + (long long)qrow * p.q_ss + kq * 8), q1 = *(const bf16x8*)(Qp + (long long)qrow * p.q_ss + 32 + kq * 8);
+    const bf16x8 k0 = *(const bf16x8*)(Kp + (long long)krow * p.k_ss + kq * 8), k1 = *(const bf16x8*)(Kp + (long long)krow * p.k_ss + 32 + kq * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                      // V: 16 rows x 8 chunks of 16 bytes
+      const int c = lane + 64 * j, row = c >> 3, col = c & 7;
+      const int vrow = row < p.Skv ? row : p.Skv - 1;
+      *(u32x4*)(vs + row * 144 + col * 16) = *(const u32x4*)(Vp + (long long)vrow * p.v_ss + col * 8);
+    }
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, st, 0, 0, 0);      // st[i] = S[q = r16][key = 4 kq + i]
+    float sv[4], m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sv[i] = (4 * kq + i < p.Skv) ? st[i] * p.qscale : -INFINITY;
+      m = fmaxf(m, sv[i]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); l += sv[i]; }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const unsigned own0 = pack_bf2(sv[0], sv[1]), own1 = pack_bf2(sv[2], sv[3]);
+    const unsigned a0 = __shfl(own0, lane + 16), a1 = __shfl(own1, lane + 16), c0 = __shfl(own0, lane + 32), c1 = __shfl(own1, lane + 32);
+    u32x4 pw = {0u, 0u, 0u, 0u};                        // P^T as B operand: lane (q, kq) holds keys 8 kq .. 8 kq + 7
+    if (kq == 0) pw = u32x4{own0, own1, a0, a1};
+    else if (kq == 1) pw = u32x4{a0, a1, c0, c1};
+    const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
+    const float inv = p.out_scale / l;
+    bf16_t* Op = p.O + (long long)b * p.o_sb + (long long)r16 * p.o_ss + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      u32x4 vw = {0u, 0u, 0u, 0u};                      // V^T as A operand: lane (d = 16 dt + r16, kq) holds keys 8 kq .. 8 kq + 7
+      if (kq < 2) {
+        const unsigned short* col = (const unsigned short*)(vs + (8 * kq) * 144 + (16 * dt + r16) * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vw[e] = (unsigned)col[(2 * e) * 72] | ((unsigned)col[(2 * e + 1) * 72] << 16);
+      }
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pb, o, 0, 0, 0);   // o[i] = O[q = r16][d = 16 dt + 4 kq + i]
+      if (r16 < p.Sq) {
+        u32x2 out = {pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv)};
+        *(u32x2*)(Op + 16 * dt + 4 * kq) = out;
+      }
+    }
+  }
+}
+
 extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   if (!a || !a->Q || !a->K || !a->V || !a->O) return MRAG_EINVAL;
   if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Skv <= 0 || a->kv_batch_div <= 0) return MRAG_EINVAL;
@@ -651,6 +720,14 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   hipStream_t s = (hipStream_t)stream;
   // The intra-wave software-pipelined variant (PIPE) measures SLOWER than the staggered-barrier loop on MI355X with
   // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
+  if (a->Sq <= 16 && a->Skv <= 16 && !a->mask && !a->resid && !getenv("MRAG_ATTN_NO_TINY")) {   // temporal attention of the UNets
+    const long long pairs = (long long)a->B * a->H;
+    long long blocks = (pairs + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    MRAG_LAUNCH(attn_tiny_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    MRAG_LAUNCH_CHECK();
+    return MRAG_OK;
+  }
   bool pipe = false;
   if (const char* e = getenv("MRAG_ATTN_PIPE")) pipe = e[0] == '1';
   if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);

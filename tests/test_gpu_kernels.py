@@ -5,6 +5,7 @@ Tolerances (stated per the task): bf16 outputs carry 8 significant bits, accumul
   |got - want| <= 2e-2 * |want| + 2e-2 * scale     (scale = typical magnitude of the output)
 retrieval rows and distances are BIT-EXACT against oracle/topk_oracle.c (same fp32 fmaf chain)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -350,3 +351,30 @@ def test_gemm_geglu_epilogue(hip, M, inner, K):
     close(got, want, scale=want.abs().mean().item())
     close(ops.linear(x.to(DEV), wi, None, epilogue=ops.EPI_GEGLU), (lambda z: z[:, :inner] * torch.nn.functional.gelu(z[:, inner:]))((x.float() @ w.float().T).to(torch.bfloat16).float()),
           scale=want.abs().mean().item())
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,kvdiv", [(37, 5, 16, 16, 1), (100, 3, 14, 14, 1), (9, 2, 1, 16, 1), (12, 4, 16, 5, 3), (1000, 5, 16, 16, 1)])
+def test_attention_tiny_sequences(hip, B, H, Sq, Skv, kvdiv):
+    """the per-wave kernel for <= 16 x 16 attention (UNet temporal attention): contiguous layout, the strided (b hw) t c view the temporal
+    transformers hand over, kv batch repeat, out_scale, pre-scaled Q -- and agreement with the 64-key-tile kernel on the same inputs"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(B + Sq)
+    q = bf(torch.randn(B, Sq, H, 64, generator=g))
+    k, v = (bf(torch.randn(B // kvdiv, Skv, H, 64, generator=g)) for _ in range(2))
+    want = sdpa_ref(q, k, v, kv_div=kvdiv)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), kv_batch_div=kvdiv)
+    close(got, want, scale=0.3)
+    close(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), kv_batch_div=kvdiv, out_scale=0.5), 0.5 * want, scale=0.15)
+    os.environ["MRAG_ATTN_NO_TINY"] = "1"
+    try:
+        old = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), kv_batch_div=kvdiv)
+    finally:
+        del os.environ["MRAG_ATTN_NO_TINY"]
+    close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)     # two bf16 results of the same math: a bf16 ulp or two apart
+    if Sq == Skv and kvdiv == 1:            # temporal layout: fused qkv rows ordered (t, hw), attention over t for every hw
+        t, hw = Sq, B
+        qkv = bf(torch.randn(t, hw, 3, H, 64, generator=g)).to(DEV)
+        out = torch.empty(t, hw, H * 64, dtype=torch.bfloat16, device=DEV)
+        ops.attention(qkv[:, :, 0].permute(1, 0, 2, 3), qkv[:, :, 1].permute(1, 0, 2, 3), qkv[:, :, 2].permute(1, 0, 2, 3), out=out.permute(1, 0, 2))
+        c = qkv.cpu()
+        close(out.permute(1, 0, 2), sdpa_ref(c[:, :, 0].permute(1, 0, 2, 3), c[:, :, 1].permute(1, 0, 2, 3), c[:, :, 2].permute(1, 0, 2, 3)), scale=0.3)

@@ -45,6 +45,10 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
 #endif
 
+#ifndef MRAG_ATTN_YOUNG_PRIO
+// static s_setprio for waves 4-7 of the 8-wave workgroup: measured 948-966 (prio 1) and 951-955 (prio 2) vs 966-983 TFLOP/s without -> off
+#define MRAG_ATTN_YOUNG_PRIO 0
+#endif
 #ifndef MRAG_ATTN_MFMA_MAX
 // 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block) instead of 32 v_add per tile.
 // Measured on MI355X (interleaved A/B, B=2 H=48 S=17776): 992.6-994.8 vs 994.1-995.6 TFLOP/s -> neutral, so off: trading 128
@@ -463,6 +467,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   // retired by a COUNTED vmcnt (every wave issues exactly 2*PPW DMA instructions per tile pair, tiles past the end
   // re-read clamped rows so the count never changes) + a raw s_barrier: __syncthreads() would drain the queue.
   const int nt = (p.Skv + KVB - 1) / KVB;
+#if MRAG_ATTN_YOUNG_PRIO
+  // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment (stamps: QK^T 1600 vs 1220 cycles,
+  // exp / PV 1300 vs 1000) and the first half then waits for it at the per-tile barrier: one static priority bump for that half
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(MRAG_ATTN_YOUNG_PRIO);
+#endif
 #ifndef MRAG_ATTN_STAGGER
   constexpr int D = NS - 1;   // without the half-tile stagger the stage refilled after barrier #t is the one read in iteration t-1
 #else

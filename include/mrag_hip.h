@@ -111,6 +111,24 @@ typedef struct mrag_attn_args {
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
 /* ------------------------------------------------------------------------ */
+/* Motion-adapter branch with the query projection folded into the keys:      */
+/*   hidden += scale * SDPA(to_q_ip(hidden), K_ip, V_ip)                       */
+/* (attn_processor.py:250-273 / :93-127) where, per head h,                    */
+/*   to_q_ip(hidden)_h . K_ip,h^T = hidden . (K_ip,h . Wq_h)^T = hidden . M_h^T */
+/* M = [H * 32, D] (25 motion keys per head padded to 32, built once per clip   */
+/* because the motion tokens do not change over the denoising steps), so the    */
+/* [S, D] x [D, D] projection becomes a [S, D] x [D, 32 H] GEMM (mrag_gemm_bf16) */
+/* and this kernel finishes: softmax over the `keys` valid scores of every      */
+/* (row, head) times `scale`, times V_ip, added into `hidden` in place.         */
+/*   scores [B*S, scores_ld] bf16, key k of head h at column 32 h + k;          */
+/*   v: element (kv batch, key, h, d) at v + kb*v_batch_stride + key*v_key_stride + 64 h + d; */
+/*   hidden [B*S, hidden_ld] bf16; q batch b uses K/V batch b / kv_batch_div.   */
+/* ------------------------------------------------------------------------ */
+int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const void* v, void* hidden, int32_t B, int64_t S, int32_t H, int32_t keys,
+                             int32_t kv_batch_div, int64_t scores_ld, int64_t hidden_ld, int64_t v_batch_stride, int64_t v_key_stride,
+                             float scale, float out_scale);
+
+/* ------------------------------------------------------------------------ */
 /* LayerNorm (+ optional AdaLN modulation): y = LN(x)*gamma+beta, then       */
 /*   y = y*(1+scale[b])+shift[b].  nn.LayerNorm at resampler.py:47,76-77,    */
 /*   129; nn.TransformerEncoderLayer norm1/norm2; diffusers                  */

@@ -24,7 +24,7 @@ EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={o
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_attn_fwd_bf16", "mrag_layernorm_bf16",
-    "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16",
+    "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32",
@@ -153,6 +153,8 @@ def lib() -> ctypes.CDLL:
     L.mrag_add_rows_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64]
     L.mrag_add_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
     L.mrag_conv_bf16.argtypes = [c_void_p, POINTER(ConvArgs)]
+    L.mrag_ip_attn_folded_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
+                                           c_int64, c_float, c_float]
     L.mrag_add_bcast_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64]
     L.mrag_axpby_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float]
     L.mrag_cfg_euler_step_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_float, c_float]

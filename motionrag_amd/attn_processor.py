@@ -22,6 +22,10 @@ from torch import nn
 from . import ops
 
 
+# fold `to_q_ip` into the motion keys once per clip (joint_attention_core); False reproduces the reference's op order literally
+FOLD_IP_QUERY = True
+
+
 class Attention(nn.Module):
     """Field-compatible stand-in for diffusers.models.attention_processor.Attention."""
 
@@ -110,13 +114,34 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
         ip = ip_hidden_states if ip_hidden_states.dtype == torch.bfloat16 else ip_hidden_states.to(torch.bfloat16)
         ip = ip.contiguous()
         r = B // ip.size(0)                                                       # :254
-        ip_q = ops.linear(o, proc.to_q_ip[0].weight)                              # :250  (text tokens included)
         wkv = fw.get(("ipkv", proc.to_k_ip[0].weight.data_ptr()), lambda: _cat_weights([proc.to_k_ip[0], proc.to_v_ip[0]]))
-        kv = ops.linear(ip, wkv)                                                  # :251-252 (one GEMM)
-        k_ip = kv[..., :D].unflatten(-1, (H, 64))
-        v_ip = kv[..., D:].unflatten(-1, (H, 64))
-        # :264-273  o = o + scale * SDPA(ip_q, ip_k, ip_v), residual fused in the attention epilogue (in place)
-        ops.attention(ip_q.view(B, S, H, 64), k_ip, v_ip, out=o, resid=o, kv_batch_div=r, out_scale=float(scale))
+        if FOLD_IP_QUERY and ip.size(1) <= 32:
+            # The motion tokens are fixed for a clip, so to_q_ip is folded into the keys ONCE per clip:
+            #   to_q_ip(o)_h . K_h^T = o . (K_h . Wq_h)^T = o . M_h^T,  M [B', H*32, D]  (25 keys per head padded to 32)
+            # and every step runs a [S, D] x [D, 32 H] GEMM instead of the [S, D] x [D, D] projection (half the flops of :250) plus one
+            # kernel that finishes softmax . V_ip and the `o + scale * ip` update (:264-273) in place.
+            def build():
+                kv0 = ops.linear(ip, wkv)                                         # :251-252 (one GEMM)
+                Bp, nk = ip.size(0), ip.size(1)
+                wq_t = proc.to_q_ip[0].weight.detach().t().contiguous()           # [D_in, D_out]: the contraction index (h, d) must be contiguous
+                M = torch.zeros(Bp, H * 32, D, dtype=torch.bfloat16, device=ip.device)
+                k4 = kv0[..., :D].unflatten(-1, (H, 64))
+                for bp in range(Bp):
+                    for h in range(H):
+                        ops.linear(k4[bp, :, h], wq_t[:, h * 64:(h + 1) * 64], out=M[bp, h * 32:h * 32 + nk])
+                return M, kv0[..., D:]
+            M, v_ip = fw.get(("ipfold", ip.data_ptr(), ip._version, tuple(ip.shape), proc.to_q_ip[0].weight.data_ptr()), build)
+            sc = torch.empty(B, S, H * 32, dtype=torch.bfloat16, device=o.device)
+            for b in range(B):
+                ops.linear(o[b], M[b // r], out=sc[b])
+            ops.ip_attn_folded_(sc, v_ip, o, H, ip.size(1), kv_batch_div=r, scale=0.125, out_scale=float(scale))
+        else:
+            ip_q = ops.linear(o, proc.to_q_ip[0].weight)                          # :250  (text tokens included)
+            kv = ops.linear(ip, wkv)                                              # :251-252 (one GEMM)
+            k_ip = kv[..., :D].unflatten(-1, (H, 64))
+            v_ip = kv[..., D:].unflatten(-1, (H, 64))
+            # :264-273  o = o + scale * SDPA(ip_q, ip_k, ip_v), residual fused in the attention epilogue (in place)
+            ops.attention(ip_q.view(B, S, H, 64), k_ip, v_ip, out=o, resid=o, kv_batch_div=r, out_scale=float(scale))
     return o
 
 

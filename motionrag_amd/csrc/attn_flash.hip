@@ -707,6 +707,100 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(const AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- folded motion-adapter branch
+// hidden += scale * softmax(scores / 8) . V_ip with scores = hidden . M^T already produced by the GEMM, M = K_ip . W_q_ip per head
+// (see include/mrag_hip.h: mrag_ip_attn_folded_bf16).  One wavefront owns 16 rows x one head at a time: the 32 (25 valid) scores of a
+// (row, head) are 64 contiguous bytes = the 16x16x32 B-operand layout (row = lane & 15, 8 keys per lane >> 4) straight from global
+// memory, the softmax is 8 registers x 4 lane groups, V^T of the block's 16 heads sits transposed in LDS as the A operand, and
+// O^T = V^T . P^T leaves every lane with 4 consecutive features of one row -> 8-byte read-modify-write of `hidden`.
+struct IpFoldP {
+  const bf16_t* scores; const bf16_t* v; bf16_t* o;
+  long long rows, s_ld, o_ld, v_bs, v_ks, rows_per_batch;
+  int H, keys, kv_div;
+  float qscale, out_scale;
+};
+
+__global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
+  constexpr int HG = 16;                                   // heads per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* vt = (bf16_t*)smem;                               // [HG][64 d][32 keys]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int h0 = blockIdx.y * HG, kb = blockIdx.z;          // blockIdx.z = K/V batch (one V^T image per block)
+  const int nh = min(HG, p.H - h0);
+  for (int i = threadIdx.x; i < HG * 64 * 32; i += 256) {
+    const int key = i & 31, d = (i >> 5) & 63, hl = i >> 11;
+    vt[i] = (key < p.keys && hl < nh) ? p.v[(long long)kb * p.v_bs + (long long)key * p.v_ks + (h0 + hl) * 64 + d] : (bf16_t)0;
+  }
+  __syncthreads();
+  // this K/V batch covers q batches [kb * kv_div, (kb + 1) * kv_div): rows [row_lo, row_hi)
+  const long long row_lo = (long long)kb * p.kv_div * p.rows_per_batch, row_hi = row_lo + (long long)p.kv_div * p.rows_per_batch;
+  for (long long g0 = row_lo + ((long long)blockIdx.x * 4 + wave) * 16; g0 < row_hi; g0 += (long long)gridDim.x * 64) {
+    const long long row = g0 + r16;
+    const long long rc = row < row_hi ? row : row_hi - 1;
+    for (int hl = 0; hl < nh; ++hl) {
+      const int h = h0 + hl;
+      const u32x4 raw = *(const u32x4*)(p.scores + rc * p.s_ld + h * 32 + kq * 8);
+      float sv[8], m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sv[2 * e] = __uint_as_float(raw[e] << 16) * p.qscale;
+        sv[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u) * p.qscale;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (kq * 8 + e >= p.keys) sv[e] = -INFINITY;
+        m = fmaxf(m, sv[e]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - m); l += sv[e]; }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const u32x4 pw = {pack_bf2(sv[0], sv[1]), pack_bf2(sv[2], sv[3]), pack_bf2(sv[4], sv[5]), pack_bf2(sv[6], sv[7])};
+      const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
+      const float inv = p.out_scale / l;
+      bf16_t* op = p.o + rc * p.o_ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 va = *(const bf16x8*)(vt + ((hl * 64 + dt * 16 + r16) * 32 + kq * 8));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 16 dt + 4 kq + i]
+        if (row < row_hi) {
+          u32x2* dst = (u32x2*)(op + 16 * dt + 4 * kq);
+          const u32x2 old = *dst;
+          u32x2 nw;
+          nw[0] = pack_bf2(__uint_as_float(old[0] << 16) + acc[0] * inv, __uint_as_float(old[0] & 0xffff0000u) + acc[1] * inv);
+          nw[1] = pack_bf2(__uint_as_float(old[1] << 16) + acc[2] * inv, __uint_as_float(old[1] & 0xffff0000u) + acc[3] * inv);
+          *dst = nw;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const void* v, void* hidden, int32_t B, int64_t S, int32_t H, int32_t keys,
+                                        int32_t kv_batch_div, int64_t scores_ld, int64_t hidden_ld, int64_t v_batch_stride, int64_t v_key_stride,
+                                        float scale, float out_scale) {
+  if (!scores || !v || !hidden || B <= 0 || S <= 0 || H <= 0 || keys <= 0 || keys > 32 || kv_batch_div <= 0 || B % kv_batch_div) return MRAG_EINVAL;
+  if (scores_ld % 8 || hidden_ld % 4 || scores_ld < (int64_t)H * 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;
+  if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 7)) return MRAG_EINVAL;
+  IpFoldP p{};
+  p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;
+  p.rows = (long long)B * S; p.s_ld = scores_ld; p.o_ld = hidden_ld; p.v_bs = v_batch_stride; p.v_ks = v_key_stride; p.rows_per_batch = S;
+  p.H = H; p.keys = keys; p.kv_div = kv_batch_div; p.qscale = scale * 1.4426950408889634f; p.out_scale = out_scale;
+  const size_t lds = 16 * 64 * 32 * sizeof(bf16_t);
+  const long long groups = ((long long)kv_batch_div * S + 63) / 64;
+  const unsigned gx = (unsigned)(groups < 512 ? groups : 512);
+  hipError_t e = hipFuncSetAttribute((const void*)ip_attn_folded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + 15) / 16), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
 extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   if (!a || !a->Q || !a->K || !a->V || !a->O) return MRAG_EINVAL;
   if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Skv <= 0 || a->kv_batch_div <= 0) return MRAG_EINVAL;

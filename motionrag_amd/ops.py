@@ -78,6 +78,21 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,
+                    out_scale: float = 1.0) -> torch.Tensor:
+    """hidden [B, S, H*64] += out_scale * softmax(scores[..., h, :keys] * scale) @ v[b // kv_batch_div, :, h]; scores [B, S, H*32] (keys padded to
+    32 per head), v [B', keys, H*64] (rows may be strided)."""
+    _dev(scores, name="scores"); _dev(v, name="v"); _dev(hidden, name="hidden")
+    B, S, W = scores.shape
+    if W != H * 32 or not scores.is_contiguous() or hidden.shape != (B, S, H * 64) or not hidden.is_contiguous():
+        raise ValueError("ip_attn_folded_: scores [B, S, H*32] and hidden [B, S, H*64], contiguous")
+    if v.shape[0] * kv_batch_div != B or v.shape[1] != keys or v.shape[2] != H * 64 or v.stride(2) != 1:
+        raise ValueError("ip_attn_folded_: v [B / kv_batch_div, keys, H*64]")
+    check(_lib.lib().mrag_ip_attn_folded_bf16(_stream(), _p(scores), _p(v), _p(hidden), B, S, H, keys, kv_batch_div, W, H * 64, v.stride(0), v.stride(1),
+                                              float(scale), float(out_scale)), "mrag_ip_attn_folded_bf16")
+    return hidden
+
+
 def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     """re-order the rows of a GEGLU projection ([value rows | gate rows], `chunk(2)` order) into the 16-row [value | gate] groups
     that `linear(..., epilogue=EPI_GEGLU)` expects.  Memory plumbing, done once per weight."""

@@ -378,3 +378,19 @@ def test_attention_tiny_sequences(hip, B, H, Sq, Skv, kvdiv):
         ops.attention(qkv[:, :, 0].permute(1, 0, 2, 3), qkv[:, :, 1].permute(1, 0, 2, 3), qkv[:, :, 2].permute(1, 0, 2, 3), out=out.permute(1, 0, 2))
         c = qkv.cpu()
         close(out.permute(1, 0, 2), sdpa_ref(c[:, :, 0].permute(1, 0, 2, 3), c[:, :, 1].permute(1, 0, 2, 3), c[:, :, 2].permute(1, 0, 2, 3)), scale=0.3)
+
+
+@pytest.mark.parametrize("B,S,H,keys,r", [(2, 100, 3, 25, 1), (4, 77, 16, 25, 2), (2, 513, 20, 7, 2)])
+def test_ip_attn_folded_kernel(hip, B, S, H, keys, r):
+    """hidden += scale * softmax(scores / 8) . V over the valid keys of every (row, head) -- the finishing kernel of the folded motion-adapter
+    branch -- and the whole folded branch against the literal to_q_ip -> SDPA order (attn_processor.py:250-273)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(S + H)
+    sc = bf(torch.randn(B, S, H, 32, generator=g) * 3)
+    v = bf(torch.randn(B // r, keys, H * 64, generator=g))
+    hid = bf(torch.randn(B, S, H * 64, generator=g))
+    p = torch.softmax(sc.float()[..., :keys] * 0.125, dim=-1)                                     # [B, S, H, keys]
+    vv = v.float().view(B // r, keys, H, 64).repeat_interleave(r, dim=0)
+    want = hid.float() + 0.75 * torch.einsum("bshk,bkhd->bshd", p, vv).reshape(B, S, H * 64)
+    got = ops.ip_attn_folded_(sc.view(B, S, H * 32).to(DEV), v.to(DEV), hid.to(DEV).clone(), H, keys, kv_batch_div=r, out_scale=0.75)
+    close(got, want, scale=1.0)

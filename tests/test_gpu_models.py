@@ -185,7 +185,7 @@ def test_denoise_loop_matches_oracle(hip):
         v = cogvideox_ref.dit_forward(sdr, cfg, inp, text.float(), torch.full((2,), float(t)), (cos, sin), ip.float())
         x = cogvideox_ref.cfg_ddim_step(v, x, guidance, cogvideox_ref.ddim_coeffs(ac, int(t), steps))
         x = x.to(torch.bfloat16).float()                                    # the pipeline keeps latents in bf16 between steps
-    close(got, x, rel_l2=4e-2)        # three chained steps
+    close(got, x, rel_l2=4e-2, atol_frac=0.12)        # three chained steps: 4 % Frobenius, single elements within 5 % + 12 % of the mean magnitude
 
 
 def test_rag_database_text_search(hip, tmp_path):

@@ -728,9 +728,13 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
   const int r16 = lane & 15, kq = lane >> 4;
   const int h0 = blockIdx.y * HG, kb = blockIdx.z;          // blockIdx.z = K/V batch (one V^T image per block)
   const int nh = min(HG, p.H - h0);
-  for (int i = threadIdx.x; i < HG * 64 * 32; i += 256) {
-    const int key = i & 31, d = (i >> 5) & 63, hl = i >> 11;
-    vt[i] = (key < p.keys && hl < nh) ? p.v[(long long)kb * p.v_bs + (long long)key * p.v_ks + (h0 + hl) * 64 + d] : (bf16_t)0;
+  for (int i = threadIdx.x; i < HG * 64 * 32 / 8; i += 256) ((u32x4*)vt)[i] = u32x4{0u, 0u, 0u, 0u};   // padding keys / heads
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.keys * nh * 8; i += 256) {     // 16-byte chunk (key, head, 8 features) -> 8 transposed LDS elements
+    const int c8 = i & 7, hl = (i >> 3) % nh, key = (i >> 3) / nh;
+    const u32x4 raw = *(const u32x4*)(p.v + (long long)kb * p.v_bs + (long long)key * p.v_ks + (h0 + hl) * 64 + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[(hl * 64 + c8 * 8 + e) * 32 + key] = (bf16_t)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu));
   }
   __syncthreads();
   // this K/V batch covers q batches [kb * kv_div, (kb + 1) * kv_div): rows [row_lo, row_hi)
@@ -738,9 +742,23 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
   for (long long g0 = row_lo + ((long long)blockIdx.x * 4 + wave) * 16; g0 < row_hi; g0 += (long long)gridDim.x * 64) {
     const long long row = g0 + r16;
     const long long rc = row < row_hi ? row : row_hi - 1;
+    // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
+    u32x4 raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + h0 * 32 + kq * 8);
+    u32x2 old_n[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) old_n[dt] = *(const u32x2*)(p.o + rc * p.o_ld + h0 * 64 + 16 * dt + 4 * kq);
     for (int hl = 0; hl < nh; ++hl) {
       const int h = h0 + hl;
-      const u32x4 raw = *(const u32x4*)(p.scores + rc * p.s_ld + h * 32 + kq * 8);
+      const u32x4 raw = raw_n;
+      bf16_t* op = p.o + rc * p.o_ld + h * 64;
+      u32x2 old[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) old[dt] = old_n[dt];
+      if (hl + 1 < nh) {
+        raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + (h + 1) * 32 + kq * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) old_n[dt] = *(const u32x2*)(op + 64 + 16 * dt + 4 * kq);
+      }
       float sv[8], m = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -762,19 +780,17 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
       const u32x4 pw = {pack_bf2(sv[0], sv[1]), pack_bf2(sv[2], sv[3]), pack_bf2(sv[4], sv[5]), pack_bf2(sv[6], sv[7])};
       const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
       const float inv = p.out_scale / l;
-      bf16_t* op = p.o + rc * p.o_ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 va = *(const bf16x8*)(vt + ((hl * 64 + dt * 16 + r16) * 32 + kq * 8));
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 16 dt + 4 kq + i]
         if (row < row_hi) {
-          u32x2* dst = (u32x2*)(op + 16 * dt + 4 * kq);
-          const u32x2 old = *dst;
+          const u32x2 od = old[dt];
           u32x2 nw;
-          nw[0] = pack_bf2(__uint_as_float(old[0] << 16) + acc[0] * inv, __uint_as_float(old[0] & 0xffff0000u) + acc[1] * inv);
-          nw[1] = pack_bf2(__uint_as_float(old[1] << 16) + acc[2] * inv, __uint_as_float(old[1] & 0xffff0000u) + acc[3] * inv);
-          *dst = nw;
+          nw[0] = pack_bf2(__uint_as_float(od[0] << 16) + acc[0] * inv, __uint_as_float(od[0] & 0xffff0000u) + acc[1] * inv);
+          nw[1] = pack_bf2(__uint_as_float(od[1] << 16) + acc[2] * inv, __uint_as_float(od[1] & 0xffff0000u) + acc[3] * inv);
+          *(u32x2*)(op + 16 * dt + 4 * kq) = nw;
         }
       }
     }
@@ -786,14 +802,15 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
                                         float scale, float out_scale) {
   if (!scores || !v || !hidden || B <= 0 || S <= 0 || H <= 0 || keys <= 0 || keys > 32 || kv_batch_div <= 0 || B % kv_batch_div) return MRAG_EINVAL;
   if (scores_ld % 8 || hidden_ld % 4 || scores_ld < (int64_t)H * 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;
-  if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 7)) return MRAG_EINVAL;
+  if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 7) || ((uintptr_t)v & 15) || v_batch_stride % 8 || v_key_stride % 8) return MRAG_EINVAL;
   IpFoldP p{};
   p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;
   p.rows = (long long)B * S; p.s_ld = scores_ld; p.o_ld = hidden_ld; p.v_bs = v_batch_stride; p.v_ks = v_key_stride; p.rows_per_batch = S;
   p.H = H; p.keys = keys; p.kv_div = kv_batch_div; p.qscale = scale * 1.4426950408889634f; p.out_scale = out_scale;
   const size_t lds = 16 * 64 * 32 * sizeof(bf16_t);
   const long long groups = ((long long)kv_batch_div * S + 63) / 64;
-  const unsigned gx = (unsigned)(groups < 512 ? groups : 512);
+  const long long per = 512 / (((H + 15) / 16) * (long long)(B / kv_batch_div));       // about two workgroups per CU: each one pays a V^T fill
+  const unsigned gx = (unsigned)(groups < (per > 1 ? per : 1) ? groups : (per > 1 ? per : 1));
   hipError_t e = hipFuncSetAttribute((const void*)ip_attn_folded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + 15) / 16), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);

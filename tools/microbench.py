@@ -50,6 +50,26 @@ def gemm():
         print(f"gemm {name:16s} M={M} N={N} K={K}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TFLOP/s ({fl/dt/2.5e15*100:.1f}%)")
 
 
+def ipfold():
+    """folded motion-adapter branch at the BASELINE shape: scores GEMM [S, 3072] x [3072, 1536] per sample + finishing kernel"""
+    B, S, H = 2, 17776, 48
+    o = torch.randn(B, S, H * 64, device=DEV).to(torch.bfloat16)
+    M = (torch.randn(B, H * 32, H * 64, device=DEV) * 0.02).to(torch.bfloat16)
+    v = torch.randn(B, 25, H * 64, device=DEV).to(torch.bfloat16)
+    sc = torch.empty(B, S, H * 32, device=DEV, dtype=torch.bfloat16)
+
+    def gemms():
+        for b in range(B):
+            ops.linear(o[b], M[b], out=sc[b])
+    dt = timeit(gemms)
+    print(f"ipfold scores GEMMs: {dt*1e3:.3f} ms  {2.0*B*S*H*64*H*32/dt/1e12:.0f} TFLOP/s")
+    dt = timeit(lambda: ops.ip_attn_folded_(sc, v, o, H, 25))
+    print(f"ipfold finishing kernel: {dt*1e6:.1f} us  {(sc.numel()+2*o.numel())*2/dt/1e9:.0f} GB/s (scores read, hidden read+write)")
+    wq = (torch.randn(H * 64, H * 64, device=DEV) * 0.02).to(torch.bfloat16)
+    dt = timeit(lambda: ops.linear(o, wq))
+    print(f"literal to_q_ip GEMM: {dt*1e3:.3f} ms")
+
+
 def gemm320():
     """UNet level-0 shapes (28 frames x 72 x 128 rows, widths that are multiples of 320)"""
     M = 28 * 9216

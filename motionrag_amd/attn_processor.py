@@ -130,7 +130,13 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
                     for h in range(H):
                         ops.linear(k4[bp, :, h], wq_t[:, h * 64:(h + 1) * 64], out=M[bp, h * 32:h * 32 + nk])
                 return M, kv0[..., D:]
-            M, v_ip = fw.get(("ipfold", ip.data_ptr(), ip._version, tuple(ip.shape), proc.to_q_ip[0].weight.data_ptr()), build)
+            # cache hit only for the SAME tensor object at the same version: the entry keeps a reference to `ip`, so its address cannot be
+            # recycled for another clip's tokens while the entry lives (a data_ptr key alone would go stale silently)
+            ent = fw._cache.get("ipfold")
+            if ent is None or ent[0] is not ip or ent[1] != ip._version or ent[2] != proc.to_q_ip[0].weight.data_ptr():
+                ent = (ip, ip._version, proc.to_q_ip[0].weight.data_ptr()) + build()
+                fw._cache["ipfold"] = ent
+            M, v_ip = ent[3], ent[4]
             sc = torch.empty(B, S, H * 32, dtype=torch.bfloat16, device=o.device)
             for b in range(B):
                 ops.linear(o[b], M[b // r], out=sc[b])

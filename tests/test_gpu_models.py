@@ -287,3 +287,29 @@ def test_sequence_parallel_dit_equals_unsharded(hip):
         assert err < 2e-3, f"rank {r}: relative error {err}"
     with pytest.raises(ValueError):
         SequenceParallel(0, 3).shard(82)
+
+
+def test_folded_adapter_cache_follows_the_motion_tokens(hip):
+    """the per-clip fold of to_q_ip into the motion keys must be rebuilt when the motion tokens change (new tensor, or the same tensor
+    modified in place) and must equal the literal op order"""
+    from motionrag_amd import attn_processor
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit(seed=51)
+    g = torch.Generator().manual_seed(52)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(DEV, torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(DEV, torch.bfloat16)
+    t = torch.tensor([481.0, 481.0], device=DEV)
+    cos, sin = (x.to(DEV) for x in cogvideox_ref.rope_3d(64, 3, 4, 6))
+    run = lambda ip: model(lat, text, t, image_rotary_emb=((cos, sin), ip), image_latents=img, batch=2).float()
+    ip1 = torch.randn(2, 25, 64, generator=g).to(DEV, torch.bfloat16)
+    ip2 = torch.randn(2, 25, 64, generator=g).to(DEV, torch.bfloat16)
+    a1, a2 = run(ip1), run(ip2)
+    assert (a1 - a2).abs().max() > 1e-2                                     # different tokens -> different output
+    ip1.copy_(ip2)                                                          # same object, new content (version bump)
+    assert torch.equal(run(ip1), a2)
+    attn_processor.FOLD_IP_QUERY = False
+    try:
+        lit = run(ip2)
+    finally:
+        attn_processor.FOLD_IP_QUERY = True
+    assert ((lit - a2).norm() / lit.norm()).item() < 1e-2                   # folded vs literal association: bf16 rounding only

@@ -57,6 +57,11 @@ class Attention(nn.Module):
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, **kwargs)
 
 
+def _wkey(t: torch.Tensor):
+    """cache key of a weight tensor: storage address + in-place version (load_state_dict copies in place)"""
+    return (t.data_ptr(), t._version)
+
+
 def _cat_weights(mods, attr="weight"):
     ts = [getattr(m, attr) for m in mods]
     if any(t is None for t in ts):
@@ -89,7 +94,7 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
     B, S, D = x.shape
     H = attn.heads
     fw = proc._fused
-    wqkv, bqkv = fw.get(("qkv", attn.to_q.weight.data_ptr()), lambda: (_cat_weights([attn.to_q, attn.to_k, attn.to_v]),
+    wqkv, bqkv = fw.get(("qkv", _wkey(attn.to_q.weight), _wkey(attn.to_k.weight), _wkey(attn.to_v.weight)), lambda: (_cat_weights([attn.to_q, attn.to_k, attn.to_v]),
                                                       _cat_weights([attn.to_q, attn.to_k, attn.to_v], "bias")))
     qkv = ops.linear(x, wqkv, bqkv)                                               # :209-211 (one GEMM)
     cos = sin = None
@@ -114,7 +119,7 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
         ip = ip_hidden_states if ip_hidden_states.dtype == torch.bfloat16 else ip_hidden_states.to(torch.bfloat16)
         ip = ip.contiguous()
         r = B // ip.size(0)                                                       # :254
-        wkv = fw.get(("ipkv", proc.to_k_ip[0].weight.data_ptr()), lambda: _cat_weights([proc.to_k_ip[0], proc.to_v_ip[0]]))
+        wkv = fw.get(("ipkv", _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight)), lambda: _cat_weights([proc.to_k_ip[0], proc.to_v_ip[0]]))
         if FOLD_IP_QUERY and ip.size(1) <= 32:
             # The motion tokens are fixed for a clip, so to_q_ip is folded into the keys ONCE per clip:
             #   to_q_ip(o)_h . K_h^T = o . (K_h . Wq_h)^T = o . M_h^T,  M [B', H*32, D]  (25 keys per head padded to 32)
@@ -133,8 +138,8 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
             # cache hit only for the SAME tensor object at the same version: the entry keeps a reference to `ip`, so its address cannot be
             # recycled for another clip's tokens while the entry lives (a data_ptr key alone would go stale silently)
             ent = fw._cache.get("ipfold")
-            if ent is None or ent[0] is not ip or ent[1] != ip._version or ent[2] != proc.to_q_ip[0].weight.data_ptr():
-                ent = (ip, ip._version, proc.to_q_ip[0].weight.data_ptr()) + build()
+            if ent is None or ent[0] is not ip or ent[1] != ip._version or ent[2] != (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight)):
+                ent = (ip, ip._version, (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight))) + build()
                 fw._cache["ipfold"] = ent
             M, v_ip = ent[3], ent[4]
             sc = torch.empty(B, S, H * 32, dtype=torch.bfloat16, device=o.device)
@@ -235,14 +240,14 @@ class APAdapterAttnProcessor2_0(nn.Module):
             raise NotImplementedError("head_dim 64 only")
         q = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias)            # :65
         enc = hidden_states if encoder_hidden_states is None else encoder_hidden_states.contiguous()
-        wkv, bkv = self._fused.get(("kv", attn.to_k.weight.data_ptr()), lambda: (_cat_weights([attn.to_k, attn.to_v]), _cat_weights([attn.to_k, attn.to_v], "bias")))
+        wkv, bkv = self._fused.get(("kv", _wkey(attn.to_k.weight), _wkey(attn.to_v.weight)), lambda: (_cat_weights([attn.to_k, attn.to_v]), _cat_weights([attn.to_k, attn.to_v], "bias")))
         kv = ops.linear(enc, wkv, bkv)                                             # :72-73
         o = ops.attention(q.view(B, L, H, 64), kv[..., :C].unflatten(-1, (H, 64)), kv[..., C:].unflatten(-1, (H, 64)))   # :85-90
         if ip_hidden_states is not None and self.scale[0] != 0:                    # :93-139
             ip = ip_hidden_states.to(torch.bfloat16).contiguous()
             r = B // ip.size(0)
             ip_q = ops.linear(o, self.to_q_ip[0].weight)
-            wip = self._fused.get(("ipkv", self.to_k_ip[0].weight.data_ptr()), lambda: _cat_weights([self.to_k_ip[0], self.to_v_ip[0]]))
+            wip = self._fused.get(("ipkv", _wkey(self.to_k_ip[0].weight), _wkey(self.to_v_ip[0].weight)), lambda: _cat_weights([self.to_k_ip[0], self.to_v_ip[0]]))
             ipkv = ops.linear(ip, wip)
             ops.attention(ip_q.view(B, L, H, 64), ipkv[..., :C].unflatten(-1, (H, 64)), ipkv[..., C:].unflatten(-1, (H, 64)),
                           out=o, resid=o, kv_batch_div=r, out_scale=float(self.scale[0]))

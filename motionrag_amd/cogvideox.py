@@ -136,7 +136,8 @@ class CogVideoXTransformer3DModel(nn.Module):
 
     # ---- fused weights (built once) ----
     def _mod_weights(self):
-        tag = (self.norm_out.linear.weight.data_ptr(), self.norm_out.linear.weight.dtype)
+        tag = tuple((w.data_ptr(), w.dtype, w._version) for w in (self.norm_out.linear.weight, self.transformer_blocks[0].norm1.linear.weight,
+                                                                    self.patch_embed.proj.weight))
         if self._fused.get("tag") != tag:
             self._fused = {"tag": tag}
             ws, bs = [], []

@@ -33,18 +33,21 @@ def _cat0(ts):
 
 
 class _Cache:
-    """weights re-laid-out once per (device, dtype): conv kernels as [Cout, (ky, kx, cin)] GEMM operands, fused K|V projections"""
+    """weights re-laid-out once per weight tensor: conv kernels as [Cout, (ky, kx, cin)] GEMM operands, fused K|V projections, GEGLU row
+    interleaves.  An entry is valid only for the SAME tensor object (weak reference: `id()` of a collected module can be reused), at the
+    same storage address, dtype and in-place version (`load_state_dict` copies in place)."""
 
     def __init__(self):
         self.d = {}
 
     def get(self, key, ref: torch.Tensor, build):
-        tag = (ref.data_ptr(), ref.dtype)
+        import weakref
+        tag = (ref.data_ptr(), ref.dtype, ref._version)
         ent = self.d.get(key)
-        if ent is None or ent[0] != tag:
-            ent = (tag, build())
+        if ent is None or ent[0] != tag or ent[1]() is not ref:
+            ent = (tag, weakref.ref(ref), build())
             self.d[key] = ent
-        return ent[1]
+        return ent[2]
 
 
 _CACHE = _Cache()

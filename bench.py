@@ -224,7 +224,7 @@ def main():
                          "launches": len(durs), "avg_launch_ms": round(avg * 1e3, 4) if durs else None,
                          "algorithmic_tflop_per_launch": round(flops / 1e12, 3)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only (other ranks would idle in the barrier)
             dt, fl, what = cpu_baseline_sample()
             full = dt * (step_flops / fl)
             out["cpu_baseline"] = {"value": round(args.frames / full, 6), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",

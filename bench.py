@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs reported beside the headline (SVD / DynamiCrafter UNet step, retrieval; N = 1 only)")
     ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
                     help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
                          "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
@@ -181,6 +182,19 @@ def main():
         e2e_sec = time.perf_counter() - t1
         assert torch.isfinite(out2.float()).all(), "non-finite latents after 50 steps"
 
+    # the other BASELINE.json configs, measured after the timed region and reported beside the headline (N = 1 only; ~20 s)
+    secondary = None
+    if world == 1 and not args.no_secondary and args.layers == 42 and args.frames == 49:
+        import contextlib
+        import importlib.util
+        import io
+        spec = importlib.util.spec_from_file_location("mrag_microbench", os.path.join(ROOT, "tools", "microbench.py"))
+        mb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mb)
+        with contextlib.redirect_stdout(io.StringIO()):          # bench.py prints ONE line
+            secondary = {"svd_unet_14x576x1024_cfg_step": mb.svd(), "dynamicrafter1024_unet_16x576x1024_cfg_step": mb.unet(),
+                         "retrieval_top12_768d": mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1)))}
+
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -217,6 +231,7 @@ def main():
             "cama_ms": round(cama_ms, 2), "cama_first_call_ms": round(cama_first_ms, 1),
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
             "e2e_sec_per_clip_50_steps_measured": round(e2e_sec, 2) if e2e_sec is not None else None,
+            "secondary_workloads": secondary,
             "roofline": {"kernel": "attn_fwd_kernel<8,false,false,false> (joint text+video flash attention, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",

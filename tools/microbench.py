@@ -91,12 +91,15 @@ def gemm320():
     print(f"conv3x3 320->320 on [28,72,128]: {dt*1e3:.3f} ms  {2.0*M*320*2880/dt/1e12:.1f} TFLOP/s")
 
 
-def topk():
-    for N, Q in ((10000, 1), (10000, 256), (1000000, 1), (1000000, 64)):
+def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
+    res = {}
+    for N, Q in cases:
         db = torch.randn(N, 768, device=DEV)
         q = torch.randn(Q, 768, device=DEV)
         dt = timeit(lambda: ops.topk(db, q, 12), iters=5)
         print(f"topk N={N} Q={Q}: {dt*1e6:.1f} us  db stream {N*768*4/dt/1e9:.0f} GB/s  ({Q/dt:.0f} queries/s)")
+        res[f"N{N}_Q{Q}"] = {"us": round(dt * 1e6, 1), "db_stream_GBps": round(N * 768 * 4 / dt / 1e9), "queries_per_s": round(Q / dt)}
+    return res
 
 
 def norm():
@@ -143,6 +146,7 @@ def unet():
     fs = torch.tensor([15, 15], device=DEV)
     dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=3, warm=1)
     print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {105.7/dt:.0f} TFLOP/s of 105.7 TFLOP algorithmic  -> {16/dt:.1f} frames/s")
+    return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": 105.7, "tflops_per_s": round(105.7 / dt), "frames_per_s": round(16 / dt, 1)}
 
 
 def count_flops(fn):
@@ -208,6 +212,7 @@ def svd():
     fl = count_flops(step)
     dt = timeit(step, iters=3, warm=1)
     print(f"SVD UNet CFG step (14x576x1024, {len(names)} adapter sites): {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP algorithmic  -> {Fr/dt:.1f} frames/s")
+    return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(Fr / dt, 1)}
 
 
 if __name__ == "__main__":

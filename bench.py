@@ -107,11 +107,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    # MRAG_BENCH_ONE_GPU=1 (developer check of the N > 1 code path on a single-GPU box): every rank uses cuda:0 and the collectives go
+    # through gloo; the judged multi-GPU run is one rank per GPU over RCCL
+    one_gpu = os.environ.get("MRAG_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     from motionrag_amd import _lib, ops
     from motionrag_amd.dist import SequenceParallel, gather_latents
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -197,7 +205,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

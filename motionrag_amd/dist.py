@@ -25,6 +25,8 @@ def gather_latents(latents: torch.Tensor, world: int) -> torch.Tensor:
     if world == 1:
         return latents
     x = latents.contiguous()
+    if x.is_cuda and dist.get_backend() == "gloo":    # developer runs of the N > 1 path on one GPU (bench.py MRAG_BENCH_ONE_GPU): stage through the host
+        return gather_latents(x.cpu(), world).to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     try:
         dist.all_gather_into_tensor(out, x)
@@ -60,6 +62,10 @@ class SequenceParallel:
         if self._ag is not None:
             return self._ag(x)
         x = x.contiguous()
+        if x.is_cuda and dist.get_backend(self.group) == "gloo":   # developer runs on one GPU: stage through the host
+            parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, x.cpu(), group=self.group)
+            return torch.cat(parts, dim=0).to(x.device)
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x, group=self.group)
         return out

@@ -53,8 +53,14 @@ enum mrag_epilogue {
   MRAG_EPI_RESID = 3,       /* C = resid + (acc + bias)                               */
   MRAG_EPI_GATE_RESID = 4,  /* C = resid + gate[b(m), n] * (acc + bias)  (AdaLN-zero) */
   MRAG_EPI_SILU = 5,        /* C = silu(acc + bias)            (timestep MLP)         */
-  MRAG_EPI_GEGLU = 6        /* C[M, N/2] = v * gelu_erf(g): W / bias rows interleaved in 16-row [value | gate] groups
+  MRAG_EPI_GEGLU = 6,       /* C[M, N/2] = v * gelu_erf(g): W / bias rows interleaved in 16-row [value | gate] groups
                              * (GEGLU of lvdm/modules/attention.py:448-455 and diffusers' FeedForward, N % 32 == 0)  */
+  MRAG_EPI_QKNORM_ROPE = 7  /* fused QKV projection of the joint attention (attn_processor.py:209-231): C = [Q | K | V] with
+                             * N = 3 * qk_dmodel; per-head LayerNorm(64) of the Q and K thirds (computed on the bf16-rounded
+                             * projection, as the reference's norm_q / norm_k see it), RoPE on rows whose position inside the
+                             * sample (m % rows_per_batch) is >= rope_text_len, Q multiplied by q_premul.  Same arithmetic as
+                             * mrag_qknorm_rope_bf16 after a plain GEMM; MRAG_ENOTSUP when the launch cannot take the LDS-staged
+                             * epilogue (small problems, unaligned C) -- run the two kernels then.                          */
 };
 
 typedef struct mrag_gemm_args {
@@ -73,6 +79,14 @@ typedef struct mrag_gemm_args {
   int64_t lda, ldw, ldc, ldr;
   int64_t rows_per_batch, split, gate_stride;
   int32_t epilogue;   /* enum mrag_epilogue */
+  /* MRAG_EPI_QKNORM_ROPE only (rows_per_batch = tokens per sample): */
+  int32_t rope_text_len;
+  const void* q_gamma; const void* q_beta;   /* [64] bf16 or NULL (no norm) */
+  const void* k_gamma; const void* k_beta;
+  const float* rope_cos;                     /* [rows_per_batch - rope_text_len, 64] fp32 or NULL */
+  const float* rope_sin;
+  int64_t qk_dmodel;                         /* D = H * 64 */
+  float qk_eps, q_premul;
 } mrag_gemm_args;
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);

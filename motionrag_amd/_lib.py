@@ -42,7 +42,9 @@ class GemmArgs(Structure):
         ("M", c_int64), ("N", c_int64), ("K", c_int64),
         ("lda", c_int64), ("ldw", c_int64), ("ldc", c_int64), ("ldr", c_int64),
         ("rows_per_batch", c_int64), ("split", c_int64), ("gate_stride", c_int64),
-        ("epilogue", c_int32),
+        ("epilogue", c_int32), ("rope_text_len", c_int32),
+        ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
+        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float),
     ]
 
 
@@ -93,6 +95,8 @@ class ConvArgs(Structure):
         ("stride", c_int32), ("upsample", c_int32), ("mode", c_int32), ("epilogue", c_int32),
     ]
 
+
+MRAG_OK, MRAG_EINVAL, MRAG_ENOTSUP = 0, -1, -2
 
 _lib = None
 

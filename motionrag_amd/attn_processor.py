@@ -96,7 +96,6 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
     fw = proc._fused
     wqkv, bqkv = fw.get(("qkv", _wkey(attn.to_q.weight), _wkey(attn.to_k.weight), _wkey(attn.to_v.weight)), lambda: (_cat_weights([attn.to_q, attn.to_k, attn.to_v]),
                                                       _cat_weights([attn.to_q, attn.to_k, attn.to_v], "bias")))
-    qkv = ops.linear(x, wqkv, bqkv)                                               # :209-211 (one GEMM)
     cos = sin = None
     if rope is not None:
         cos, sin = fw.get(("rope", rope[0].data_ptr(), S, text_len),
@@ -105,9 +104,10 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
         if getattr(attn, "is_cross_attention", False):
             raise NotImplementedError("RoPE on Q only (is_cross_attention=True) is not used by CogVideoX attn1")
     nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)
-    ops.qknorm_rope_(qkv, H, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
-                     nk.weight if nk is not None else None, nk.bias if nk is not None else None, cos, sin, text_len,
-                     eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)     # :220-231
+    # :209-211 + :220-231 in ONE GEMM: the projection's epilogue applies norm_q / norm_k and the rotary embedding to the Q and K thirds
+    qkv = ops.qkv_linear_qknorm_rope(x, wqkv, bqkv, H, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
+                                     nk.weight if nk is not None else None, nk.bias if nk is not None else None, cos, sin, text_len,
+                                     eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)
     q5 = qkv.view(B, S, 3, H, 64)
     if sp is None:
         o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237

@@ -45,6 +45,9 @@ struct GemmP {
   const bf16_t* gate0; const bf16_t* gate1;
   long long M, N, K, lda, ldw, ldc, ldr, rows_per_batch, split, gate_stride;
   int tiles_m, tiles_n, group_m, staged;
+  // MRAG_EPI_QKNORM_ROPE
+  const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
+  long long qk_D; int rope_text_len; float qk_eps, q_premul;
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T;
   long long cv_C, cv_HW;
@@ -353,6 +356,65 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       const int row = g * 8 + rsub;
       const long long m = bm0 + wm * TM * 16 + row;
       u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
+      if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
+        // the wave's 64 columns are one head (256-wide tiles, 64-column wave tiles), 8 lanes x 8 features per row: per-head LayerNorm across
+        // those 8 lanes, RoPE on the lane's 4 (even, odd) pairs, Q pre-multiplied -- the arithmetic of qknorm_rope_kernel (norm.hip)
+        const int which = (int)(n / p.qk_D);                       // 0 = Q, 1 = K, 2 = V (wave-uniform)
+        if (which < 2) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(val[e] << 16); v[2 * e + 1] = __uint_as_float(val[e] & 0xffff0000u); }
+          const bf16_t* g = which ? p.kg : p.qg;
+          const bf16_t* bt = which ? p.kb : p.qb;
+          const int d0 = chunk * 8;
+          if (g) {
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[e];
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+            const float mean = sum * (1.0f / 64.0f);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+            const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.qk_eps);
+            const u32x4 graw = *(const u32x4*)(g + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] = v[2 * e] * rstd * __uint_as_float(graw[e] << 16);
+              v[2 * e + 1] = v[2 * e + 1] * rstd * __uint_as_float(graw[e] & 0xffff0000u);
+            }
+            if (bt) {
+              const u32x4 braw = *(const u32x4*)(bt + d0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(braw[e] << 16); v[2 * e + 1] += __uint_as_float(braw[e] & 0xffff0000u); }
+            }
+          }
+          const long long mc = m < p.M ? m : p.M - 1;
+          const int pos = (int)(mc % p.rows_per_batch);
+          if (p.rcos && pos >= p.rope_text_len) {
+            const long long ro = (long long)(pos - p.rope_text_len) * 64 + d0;
+            const f32x4 c0 = *(const f32x4*)(p.rcos + ro), c1 = *(const f32x4*)(p.rcos + ro + 4);
+            const f32x4 s0 = *(const f32x4*)(p.rsin + ro), s1 = *(const f32x4*)(p.rsin + ro + 4);
+            const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            float o[8];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+              o[2 * i2] = v[2 * i2] * cc[2 * i2] - v[2 * i2 + 1] * ss[2 * i2];
+              o[2 * i2 + 1] = v[2 * i2 + 1] * cc[2 * i2 + 1] + v[2 * i2] * ss[2 * i2 + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = o[e];
+          }
+          if (which == 0 && p.q_premul != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.q_premul;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        }
+      }
       if (m < p.M && n + 8 <= p.N) {
         if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
           const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + n);
@@ -481,6 +543,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
   if (getenv("MRAG_GEMM_NO_STAGED") || epi == MRAG_EPI_GEGLU) p.staged = 0;   // tuning knob; GEGLU writes [M, N/2] from the accumulator layout
+  if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
 #define MRAG_GEMM_CASE(E)                                                                              \
@@ -506,6 +569,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
       MRAG_GEMM_CASE(MRAG_EPI_GATE_RESID)
       MRAG_GEMM_CASE(MRAG_EPI_SILU)
       MRAG_GEMM_CASE(MRAG_EPI_GEGLU)
+      MRAG_GEMM_CASE(MRAG_EPI_QKNORM_ROPE)
       default: return MRAG_EINVAL;
     }
   }
@@ -535,6 +599,13 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.gate0 = (const bf16_t*)a->gate0; p.gate1 = (const bf16_t*)a->gate1;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
+  if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
+    if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N != 3 * a->qk_dmodel || a->rows_per_batch <= 0) return MRAG_EINVAL;
+    if ((a->rope_cos != nullptr) != (a->rope_sin != nullptr) || (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 15)) return MRAG_EINVAL;
+    if (((uintptr_t)a->q_gamma | (uintptr_t)a->q_beta | (uintptr_t)a->k_gamma | (uintptr_t)a->k_beta) & 15) return MRAG_EINVAL;
+    p.qg = (const bf16_t*)a->q_gamma; p.qb = (const bf16_t*)a->q_beta; p.kg = (const bf16_t*)a->k_gamma; p.kb = (const bf16_t*)a->k_beta;
+    p.rcos = a->rope_cos; p.rsin = a->rope_sin; p.qk_D = a->qk_dmodel; p.rope_text_len = a->rope_text_len; p.qk_eps = a->qk_eps; p.q_premul = a->q_premul;
+  }
   hipStream_t s = (hipStream_t)stream;
   // big problems: 256x256 tiles, 8 waves (1 workgroup per CU); small ones: 128x128, 4 waves,
   // so that a few hundred rows still spread over the 256 CUs.

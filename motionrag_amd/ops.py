@@ -7,6 +7,7 @@ int32 where stated) on a ROCm device, otherwise `HipOnly` is raised.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -14,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import AttnArgs, GemmArgs, LnArgs, QkNormRopeArgs, check
 
-EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU, EPI_GEGLU = range(7)
+EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU, EPI_GEGLU, EPI_QKNORM_ROPE = range(8)
 LOG2E = 1.4426950408889634
 
 
@@ -210,6 +211,34 @@ def qknorm_rope_(qkv: torch.Tensor, H: int, q_gamma, q_beta, k_gamma, k_beta, co
     a.B, a.S, a.H, a.text_len, a.eps, a.q_premul = B, S, H, text_len, eps, q_premul
     check(_lib.lib().mrag_qknorm_rope_bf16(_stream(), ctypes.byref(a)), "mrag_qknorm_rope_bf16")
     return qkv
+
+
+def qkv_linear_qknorm_rope(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], H: int, q_gamma, q_beta, k_gamma, k_beta,
+                           cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], text_len: int, eps: float = 1e-6, q_premul: float = 1.0) -> torch.Tensor:
+    """fused QKV projection + per-head qk LayerNorm + RoPE: x [B, S, K] -> [B, S, 3*H*64] (attn_processor.py:209-231).  One GEMM whose epilogue does
+    what `qknorm_rope_` does in a second pass; falls back to the two kernels when the launch cannot take that epilogue (MRAG_ENOTSUP)."""
+    _dev(x, name="x"); _dev(weight, name="weight")
+    B, S, K = x.shape
+    N = weight.shape[0]
+    if N != 3 * H * 64 or weight.shape[1] != K or not x.is_contiguous() or K % 64 != 0:
+        raise ValueError("qkv_linear_qknorm_rope: x [B, S, K] contiguous, weight [3*H*64, K], K % 64 == 0")
+    out = torch.empty(B, S, N, dtype=torch.bfloat16, device=x.device)
+    a = GemmArgs()
+    a.A, a.W, a.bias, a.C = _p(x), _p(weight), _p(bias), _p(out)
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = B * S, N, K, K, weight.stride(0), N
+    a.epilogue, a.rows_per_batch, a.rope_text_len, a.qk_dmodel, a.qk_eps, a.q_premul = EPI_QKNORM_ROPE, S, text_len, H * 64, eps, q_premul
+    a.q_gamma, a.q_beta, a.k_gamma, a.k_beta = _p(q_gamma), _p(q_beta), _p(k_gamma), _p(k_beta)
+    if cos is not None:
+        _dev(cos, torch.float32, "cos"); _dev(sin, torch.float32, "sin")
+        if tuple(cos.shape) != (S - text_len, 64) or not cos.is_contiguous() or not sin.is_contiguous():
+            raise ValueError("cos/sin must be contiguous [S - text_len, 64] fp32")
+        a.rope_cos, a.rope_sin = _p(cos), _p(sin)
+    rc = _lib.MRAG_ENOTSUP if os.environ.get("MRAG_NO_QKV_FUSE") else _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))   # env: A/B knob
+    if rc == _lib.MRAG_ENOTSUP:                                   # small problem / unaligned output: plain GEMM, then the norm + RoPE pass
+        linear(x, weight, bias, out=out)
+        return qknorm_rope_(out, H, q_gamma, q_beta, k_gamma, k_beta, cos, sin, text_len, eps=eps, q_premul=q_premul)
+    check(rc, "mrag_gemm_bf16")
+    return out
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:

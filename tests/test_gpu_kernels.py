@@ -394,3 +394,26 @@ def test_ip_attn_folded_kernel(hip, B, S, H, keys, r):
     want = hid.float() + 0.75 * torch.einsum("bshk,bkhd->bshd", p, vv).reshape(B, S, H * 64)
     got = ops.ip_attn_folded_(sc.view(B, S, H * 32).to(DEV), v.to(DEV), hid.to(DEV).clone(), H, keys, kv_batch_div=r, out_scale=0.75)
     close(got, want, scale=1.0)
+
+
+@pytest.mark.parametrize("B,S,H,K,text_len", [(2, 8200, 4, 256, 10), (1, 16500, 4, 192, 0), (2, 100, 2, 128, 7)])
+def test_qkv_gemm_fused_qknorm_rope_epilogue(hip, B, S, H, K, text_len):
+    """the QKV GEMM whose epilogue applies per-head qk LayerNorm + RoPE + Q pre-scale (attn_processor.py:209-231) equals the plain GEMM
+    followed by the norm / RoPE kernel: same arithmetic on the same bf16-rounded projection, so results agree except for a handful of
+    round-to-nearest ties decided differently by the two compilations' fp32 contraction (measured: 25 of 12.6 M elements, one bf16 ulp);
+    the last shape takes the MRAG_ENOTSUP fallback (small problem -> 128x128 tiles without the LDS-staged epilogue)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(S + H)
+    D = H * 64
+    x = bf(torch.randn(B, S, K, generator=g)).to(DEV)
+    w = bf(torch.randn(3 * D, K, generator=g) * K ** -0.5).to(DEV)
+    b = bf(torch.randn(3 * D, generator=g) * 0.1).to(DEV)
+    qg, qb, kg, kb = (bf(1.0 + 0.2 * torch.randn(64, generator=g)).to(DEV) if i % 2 == 0 else bf(0.1 * torch.randn(64, generator=g)).to(DEV) for i in range(4))
+    ang = torch.rand(S - text_len, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
+    got = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+    want = ops.qknorm_rope_(ops.linear(x, w, b), H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+    diff = (got.float() - want.float()).abs()
+    assert (diff > 0).float().mean().item() < 1e-4 and (diff <= want.float().abs() * 2.0 ** -7 + 1e-6).all()
+    got2 = ops.qkv_linear_qknorm_rope(x, w, None, H, None, None, None, None, None, None, 0)          # no norm, no RoPE: a plain GEMM
+    assert torch.equal(got2, ops.linear(x, w))

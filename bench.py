@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs reported beside the headline (SVD / DynamiCrafter UNet step, retrieval; N = 1 only)")
+    ap.add_argument("--secondary", action="store_true", help="also measure the other BASELINE configs after the timed region (SVD / DynamiCrafter UNet step, retrieval; N = 1 only, ~20 s); "
+                    "off by default so that a rocprofv3 summary of the default command holds only the headline workload's launches")
     ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
                     help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
                          "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
@@ -192,7 +193,7 @@ def main():
 
     # the other BASELINE.json configs, measured after the timed region and reported beside the headline (N = 1 only; ~20 s)
     secondary = None
-    if world == 1 and not args.no_secondary and args.layers == 42 and args.frames == 49:
+    if world == 1 and args.secondary:
         import contextlib
         import importlib.util
         import io

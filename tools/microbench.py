@@ -70,6 +70,21 @@ def ipfold():
     print(f"literal to_q_ip GEMM: {dt*1e3:.3f} ms")
 
 
+def ceilings():
+    """the box's practical ceilings: vendor-library bf16 GEMM (hipBLASLt through torch) and device-to-device copy bandwidth"""
+    M, N, K = 35552, 9216, 3072
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16); w = (torch.randn(N, K, device=DEV) * 0.02).to(torch.bfloat16)
+    dt = timeit(lambda: torch.nn.functional.linear(x, w), iters=50, warm=10)
+    print(f"hipBLASLt bf16 GEMM M={M} N={N} K={K}: {2.0*M*N*K/dt/1e12:.0f} TFLOP/s (sustained over 50 launches)")
+    dt = timeit(lambda: ops.linear(x, w), iters=50, warm=10)
+    print(f"this repo's GEMM, same shape:            {2.0*M*N*K/dt/1e12:.0f} TFLOP/s")
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=DEV); b = torch.empty_like(a)
+    dt = timeit(lambda: b.copy_(a), iters=20, warm=3)
+    print(f"device-to-device copy of 1 GiB: {2 * a.numel() / dt / 1e12:.2f} TB/s (read + write)")
+    res = {"hipblaslt_bf16_gemm_tflops": None}
+    return res
+
+
 def gemm320():
     """UNet level-0 shapes (28 frames x 72 x 128 rows, widths that are multiples of 320)"""
     M = 28 * 9216

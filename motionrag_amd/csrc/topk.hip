@@ -94,9 +94,16 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
   const int slice = blockIdx.x;
   const int nj = (p.dim + 63) / 64, dimp = nj * 64;
 
-  for (int i = tid; i < QT * dimp; i += 256) {
-    const int qi = i / dimp, k = i - qi * dimp;
-    qs[i] = (q0 + qi < p.nq && k < p.dim) ? p.q[(long long)(q0 + qi) * p.dim + k] : 0.f;
+  // QT == 1: qs[k].  Query tiles: query-minor image qs[(block j, lane s)][c][qi] (quad pitch QS = 4 QT + 4 floats, conflict-free for the 16
+  // lanes of a row) so one ds_read_b128 returns the SAME feature of 4 queries -> packed fp32 math (v_pk_add_f32 / v_pk_fma_f32) on query pairs
+  constexpr int QS = 4 * QT + 4;
+  if constexpr (QT == 1) {
+    for (int i = tid; i < dimp; i += 256) qs[i] = (q0 < p.nq && i < p.dim) ? p.q[(long long)q0 * p.dim + i] : 0.f;
+  } else {
+    for (int i = tid; i < QT * dimp; i += 256) {
+      const int qi = i / dimp, k = i - qi * dimp;
+      qs[(k >> 2) * QS + (k & 3) * QT + qi] = (q0 + qi < p.nq && k < p.dim) ? p.q[(long long)(q0 + qi) * p.dim + k] : 0.f;
+    }
   }
   __syncthreads();
   int excl[QT];
@@ -125,9 +132,12 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
         else dst[jj] = __builtin_nontemporal_load((const f32x4*)(base + 64 * j));
       }
     };
-    float dist[QT], acc[QT];
+    float dist[QT], acc[1] = {0.f};
+    f32x2 acc2[QT / 2 > 0 ? QT / 2 : 1];
 #pragma unroll
-    for (int qi = 0; qi < QT; ++qi) { dist[qi] = 0.f; acc[qi] = 0.f; }
+    for (int qi = 0; qi < QT; ++qi) dist[qi] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (QT / 2 > 0 ? QT / 2 : 1); ++i) acc2[i] = f32x2{0.f, 0.f};
     int lt = 0, lch = 0;                          // next (quad, chunk) to request
     auto advance = [&]() { if (++lch == nchunk) { lch = 0; ++lt; } };
     int t = 0, ch = 0;                            // (quad, chunk) being consumed
@@ -135,16 +145,34 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
 #pragma unroll
       for (int jj = 0; jj < JC; ++jj) {
         const f32x4 x = xb[jj];
-        const float* qp = qs + (ch * JC + jj) * 64 + 4 * s;
-#pragma unroll
-        for (int qi = 0; qi < QT; ++qi) {
-          const f32x4 qv = *(const f32x4*)(qp + qi * dimp);
+        if constexpr (QT == 1) {
+          const f32x4 qv = *(const f32x4*)(qs + (ch * JC + jj) * 64 + 4 * s);
           if constexpr (METRIC == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float df = qv[e] - x[e]; acc[qi] = __builtin_fmaf(df, df, acc[qi]); }
+            for (int e = 0; e < 4; ++e) { const float df = qv[e] - x[e]; acc[0] = __builtin_fmaf(df, df, acc[0]); }
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[qi] = __builtin_fmaf(qv[e], x[e], acc[qi]);
+            for (int e = 0; e < 4; ++e) acc[0] = __builtin_fmaf(qv[e], x[e], acc[0]);
+          }
+        } else {
+          // chain order per query is unchanged (feature c = 0..3 in sequence); two queries share one packed instruction
+          const float* qp = qs + ((ch * JC + jj) * 16 + s) * QS;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x2 xc = {x[c], x[c]};
+#pragma unroll
+            for (int qb = 0; qb < QT / 4; ++qb) {
+              const f32x4 qv = *(const f32x4*)(qp + c * QT + qb * 4);
+              const f32x2 qlo = {qv[0], qv[1]}, qhi = {qv[2], qv[3]};
+              if constexpr (METRIC == 0) {
+                const f32x2 dlo = qlo - xc, dhi = qhi - xc;
+                acc2[2 * qb] = __builtin_elementwise_fma(dlo, dlo, acc2[2 * qb]);
+                acc2[2 * qb + 1] = __builtin_elementwise_fma(dhi, dhi, acc2[2 * qb + 1]);
+              } else {
+                acc2[2 * qb] = __builtin_elementwise_fma(qlo, xc, acc2[2 * qb]);
+                acc2[2 * qb + 1] = __builtin_elementwise_fma(qhi, xc, acc2[2 * qb + 1]);
+              }
+            }
           }
         }
       }
@@ -152,10 +180,15 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
         ch = 0;
 #pragma unroll
         for (int qi = 0; qi < QT; ++qi) {
-          float v = acc[qi];
+          float v;
+          if constexpr (QT == 1) { v = acc[0]; acc[0] = 0.f; }
+          else { v = acc2[qi >> 1][qi & 1]; }
           v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
           if (t == s) dist[qi] = v;
-          acc[qi] = 0.f;
+        }
+        if constexpr (QT > 1) {
+#pragma unroll
+          for (int i = 0; i < QT / 2; ++i) acc2[i] = f32x2{0.f, 0.f};
         }
         ++t;
       }
@@ -312,7 +345,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   const int QT = pick_qt(n_queries), nj = (dim + 63) / 64;
   // blocks of 64 floats per register-ring step: 4 for the single query, 2 for query tiles (their chains need the registers)
   const int JCsel = QT == 1 ? (nj % 4 == 0 ? 4 : 1) : (nj % 2 == 0 ? 2 : 1);
-  const size_t lds = (size_t)QT * nj * 64 * sizeof(float);
+  const size_t lds = (QT == 1 ? (size_t)nj * 64 : (size_t)nj * 16 * (4 * QT + 4)) * sizeof(float);
   const dim3 grid(p.slices, (n_queries + QT - 1) / QT), block(256);
 #define MRAG_TOPK_CASE(M, Q, J)                                                                                   \
   if (metric == M && QT == Q && JCsel == J) {                                                                     \

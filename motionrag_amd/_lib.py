@@ -11,7 +11,7 @@ import ctypes
 import os
 import subprocess
 import sys
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")

@@ -20,7 +20,6 @@ takes prompt embeddings and image latents, or user-supplied encoders.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np

@@ -15,7 +15,7 @@ nn.Module is a weight container; every arithmetic op is a libmrag_hip.so kernel 
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Sequence
+from typing import Dict, Sequence
 
 import torch
 from torch import nn

@@ -26,6 +26,7 @@
 //   * grid = q-tiles x (b, h) with an XCD-aware order: all q-tiles of one (b, h) run on one XCD,
 //     so its K/V (4.5 MB at S = 17 776) streams from that XCD's L2.
 #include "common.h"
+#include <type_traits>
 #include "../../include/mrag_hip.h"
 #include <stdlib.h>
 
@@ -45,6 +46,17 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
 #endif
 
+#ifndef MRAG_ATTN_PK_ADD
+// packed fp32 adds (v_pk_add_f32) for the max subtraction and the row sums: 16 instead of 32 vector instructions per block, but measured
+// SLOWER beside the MFMAs (927-936 vs 951-968 TFLOP/s, interleaved A/B) -> off
+#define MRAG_ATTN_PK_ADD 0
+#endif
+#ifndef MRAG_ATTN_SPLIT
+// per-32-key-block softmax + PV (softmax_block / pv_half: block 0's vector work under block 1's MFMA chain, block 0's PV under block 1's
+// vector work) instead of one softmax over the 64-key tile: bit-correct, spill-free at 127 VGPRs, and measured EQUAL (997-999 vs 996-1004
+// TFLOP/s): with four waves per SIMD the other waves already fill those gaps -> off, the simpler path ships
+#define MRAG_ATTN_SPLIT 0
+#endif
 #ifndef MRAG_ATTN_YOUNG_PRIO
 // static s_setprio for waves 4-7 of the 8-wave workgroup: measured 948-966 (prio 1) and 951-955 (prio 2) vs 966-983 TFLOP/s without -> off
 #define MRAG_ATTN_YOUNG_PRIO 0
@@ -143,8 +155,19 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
 #else
+#if MRAG_ATTN_PK_ADD
+  {   // 16 v_pk_add_f32 per block instead of 32 v_add_f32
+    const f32x2 nm2 = {nm, nm};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const f32x2 a = f32x2{s0[i], s0[i + 1]} + nm2, b = f32x2{s1[i], s1[i + 1]} + nm2;
+      s0[i] = a[0]; s0[i + 1] = a[1]; s1[i] = b[0]; s1[i + 1] = b[1];
+    }
+  }
+#else
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
+#endif
 #endif
 #else
   u32x4 k0f[4], k1f[4];
@@ -356,6 +379,87 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int
   }
 }
 
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
+// Per-block softmax + PV (4-waves-per-SIMD form): the two 32-key blocks of a tile are independent online-softmax steps, so block 0's
+// max / exp / convert depends only on S0 and is issued while the matrix pipe still runs S1's MFMA chain, and block 0's PV MFMAs run under
+// block 1's vector work -- an intra-wave software pipeline at no extra registers.  With the deferred rescale the running max moves
+// rarely, so the second threshold check per tile is one more half-wave swap + v_max3.
+__device__ __forceinline__ void softmax_block(int t, int kb, f32x16& s, f32x16* pending, Run& r, bf16x8 (&pb)[4]) {
+  float ma = max3_asm(s[0], s[1], s[2]), mb = max3_asm(s[3], s[4], s[5]);
+  ma = max3_asm(ma, s[6], s[7]); mb = max3_asm(mb, s[8], s[9]);
+  ma = max3_asm(ma, s[10], s[11]); mb = max3_asm(mb, s[12], s[13]);
+  const float tm = half_swap_max(max3_asm(max3_asm(ma, s[14], s[15]), mb, mb));
+  const bool first = (t == 0 && kb == 0);
+  if (first || __any(tm > kThr)) {
+    const float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
+    if (!first) {
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { r.o0[i] *= alpha; r.o1[i] *= alpha; }
+      r.lacc[0] *= alpha;
+    }
+    r.m += delta;
+    r.negm[0] = -r.m;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] -= delta;
+    if (pending) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) (*pending)[i] -= delta;     // block 1 of this tile was formed against the old max
+    }
+  }
+#if MRAG_ATTN_PK_ADD
+  f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    s[i] = __builtin_amdgcn_exp2f(s[i]); s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1]);
+    l2 += f32x2{s[i], s[i + 1]};
+  }
+  r.lacc[0] += l2[0] + l2[1];
+#else
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i]); l += s[i]; }
+  r.lacc[0] += l;
+#endif
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[8 * h2 + 2 * j], s[8 * h2 + 2 * j + 1]);
+    pb[2 * kb + h2] = __builtin_bit_cast(bf16x8, w);
+  }
+}
+
+__device__ __forceinline__ void pv_half(const char* vst, const Lane& ln, int half, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
+  const unsigned c0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0), c1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
+  u32x2 u0[4], u1[4];
+  if (half == 0) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:0\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %4, %9 offset:0\n\tds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
+                 "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                 : "v"(c0), "v"(c1) : "memory");
+  } else {
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:4096\n\tds_read_b64_tr_b16 %1, %8 offset:5120\n\t"
+                 "ds_read_b64_tr_b16 %4, %9 offset:4096\n\tds_read_b64_tr_b16 %5, %9 offset:5120\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:6144\n\tds_read_b64_tr_b16 %3, %8 offset:7168\n\t"
+                 "ds_read_b64_tr_b16 %6, %9 offset:6144\n\tds_read_b64_tr_b16 %7, %9 offset:7168\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                 : "v"(c0), "v"(c1) : "memory");
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+    const u32x4 w0 = {u0[2 * k2][0], u0[2 * k2][1], u0[2 * k2 + 1][0], u0[2 * k2 + 1][1]};
+    const u32x4 w1 = {u1[2 * k2][0], u1[2 * k2][1], u1[2 * k2 + 1][0], u1[2 * k2 + 1][1]};
+    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
+  }
+}
+#endif
+
 // SHORTKV: key sets of at most one tile (motion tokens, text, temporal frames) -- same code, no barrier stagger; a separate
 // instantiation so that profiles list the HBM-bound small-KV launches apart from the MFMA-bound long-sequence ones.
 template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false>
@@ -513,7 +617,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 #ifdef MRAG_ATTN_STAMPS
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, ta, tb, tc, td, te, tg;
 #endif
-    for (int t = 0; t < nt; ++t) {
+    auto iter = [&](int t, auto split_c) {
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(ta);
 #endif
@@ -533,20 +637,42 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
         MRAG_STAMP(te);
 #endif
       };
-      if (!wave_active) { early_issue(); mid(); continue; }
+      if (!wave_active) { early_issue(); mid(); return; }
       f32x16 s0, s1;
       bf16x8 pb[4];
       qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(tc);
 #endif
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
+      if constexpr (decltype(split_c)::value) {
+        softmax_block(t, 0, s0, &s1, r, pb);
+        mid();
+        pv_half(smem + V_BASE + (t % NS) * TILE_BYTES, ln, 0, pb, r.o0, r.o1);
+        softmax_block(t, 1, s1, nullptr, r, pb);
+        pv_half(smem + V_BASE + (t % NS) * TILE_BYTES, ln, 1, pb, r.o0, r.o1);
+      } else {
+        softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
+        pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
+      }
+#else
       softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
+#endif
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(tg);
       acc_t[0] += tb - ta; acc_t[1] += tc - tb; acc_t[2] += td - tc; acc_t[3] += te - td; acc_t[4] += tg - te; acc_t[5] += tg - ta;
 #endif
-    }
+        };
+    // full unmasked tiles take the per-block pipeline; the ragged last tile (and the masked instantiation) the one-softmax path,
+    // in separate loops so that neither path's live state burdens the other
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
+    const int n_split = HAS_MASK ? 0 : ((p.Skv & (KVB - 1)) ? nt - 1 : nt);
+#else
+    const int n_split = 0;
+#endif
+    for (int t = 0; t < n_split; ++t) iter(t, std::true_type{});
+    for (int t = n_split; t < nt; ++t) iter(t, std::false_type{});
 #ifdef MRAG_ATTN_STAMPS
     if (g_stamp_buf && lane == 0 && blockIdx.x < 2048) {
       for (int k = 0; k < 6; ++k) g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + k] = acc_t[k];

@@ -46,6 +46,9 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
 #endif
 
+#ifndef MRAG_ATTN_IMM_STAGE
+#define MRAG_ATTN_IMM_STAGE 1   // ring stage as a ds_read offset immediate (main loop unrolled by the ring depth)
+#endif
 #ifndef MRAG_ATTN_PK_ADD
 // packed fp32 adds (v_pk_add_f32) for the max subtraction and the row sums: 16 instead of 32 vector instructions per block, but measured
 // SLOWER beside the MFMAs (927-936 vs 951-968 TFLOP/s, interleaved A/B) -> off
@@ -108,6 +111,7 @@ __device__ __forceinline__ float half_swap_max(float v) {
 
 struct Lane {
   int hh, k_row_off, k_swz, v_lane_off, v_half0, v_half1;
+  unsigned kb[4], vc0, vc1;   // loop-invariant LDS addresses of this lane's K fragment chunks / V^T reads in ring stage 0 (MRAG_ATTN_IMM_STAGE)
 };
 
 struct NoHook {
@@ -266,6 +270,65 @@ __device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const b
   }
 #endif
 }
+
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+// The ring stage as an INSTRUCTION IMMEDIATE (ds_read offset field) instead of per-tile address arithmetic: the main loop is unrolled by
+// NS, so `t % NS` is a compile-time constant, the lane's base addresses are loop-invariant registers, and ~11 integer vector instructions
+// per tile (of ~144) disappear from a loop whose vector pipe is ~77 % busy.
+template <int STG, typename Between = NoHook>
+__device__ __forceinline__ void qk_tile_imm(const Lane& ln, const bf16x8 (&qf)[4], const f32x16& negm, f32x16& s0, f32x16& s1, Between between = Between()) {
+  u32x4 kf[4];
+  asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"
+               : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(ln.kb[0]), "v"(ln.kb[1]), "v"(ln.kb[2]), "v"(ln.kb[3]), "n"(STG * TILE_BYTES) : "memory");
+  between();
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float nm = negm[0];
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
+  asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(ln.kb[0]), "v"(ln.kb[1]), "v"(ln.kb[2]), "v"(ln.kb[3]), "n"(STG * TILE_BYTES + 4096) : "memory");
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
+}
+
+template <int STG>
+__device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u32x2 u0[4], u1[4];
+    if (half == 0) {
+      asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+                   "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+                   "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                   : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 1024), "n"(STG * TILE_BYTES + 2048), "n"(STG * TILE_BYTES + 3072) : "memory");
+    } else {
+      asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+                   "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+                   "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                   : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 5120), "n"(STG * TILE_BYTES + 6144), "n"(STG * TILE_BYTES + 7168) : "memory");
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const u32x4 w0 = {u0[2 * k2][0], u0[2 * k2][1], u0[2 * k2 + 1][0], u0[2 * k2 + 1][1]};
+      const u32x4 w1 = {u1[2 * k2][0], u1[2 * k2][1], u1[2 * k2 + 1][0], u1[2 * k2 + 1][1]};
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
+    }
+  }
+}
+#endif
 
 struct Run {
   f32x16 o0, o1, negm;
@@ -561,6 +624,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   ln.v_lane_off = (4 * ln.hh + q4) * 128 + (g16 & 1) * 32 + p4 * 8;
   ln.v_half0 = (q4 >> 1) * 64;        // d-tile 0: 64-byte half index 0 ^ ((key >> 1) & 1)
   ln.v_half1 = (1 - (q4 >> 1)) * 64;  // d-tile 1
+  {
+    const unsigned kbase = (unsigned)(size_t)(smem + ln.k_row_off);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ln.kb[c] = kbase + ((2 * c + ln.hh) ^ ln.k_swz) * 16;
+    ln.vc0 = (unsigned)(size_t)(smem + NS * TILE_BYTES + ln.v_lane_off + ln.v_half0);
+    ln.vc1 = (unsigned)(size_t)(smem + NS * TILE_BYTES + ln.v_lane_off + ln.v_half1);
+  }
 
   Run r;
 #pragma unroll
@@ -617,7 +687,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 #ifdef MRAG_ATTN_STAMPS
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, ta, tb, tc, td, te, tg;
 #endif
-    auto iter = [&](int t, auto split_c) {
+    auto iter = [&](int t, auto split_c, auto stage_c) {
+      constexpr int STG = decltype(stage_c)::value;   // ring stage as a compile-time constant, or -1
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(ta);
 #endif
@@ -640,6 +711,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       if (!wave_active) { early_issue(); mid(); return; }
       f32x16 s0, s1;
       bf16x8 pb[4];
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+      if constexpr (STG >= 0) qk_tile_imm<STG>(ln, qf, r.negm, s0, s1, early_issue);
+      else
+#endif
       qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(tc);
@@ -657,6 +732,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       }
 #else
       softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+      if constexpr (STG >= 0) pv_tile_imm<STG>(ln, pb, r.o0, r.o1);
+      else
+#endif
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
 #endif
 #ifdef MRAG_ATTN_STAMPS
@@ -671,8 +750,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 #else
     const int n_split = 0;
 #endif
-    for (int t = 0; t < n_split; ++t) iter(t, std::true_type{});
-    for (int t = n_split; t < nt; ++t) iter(t, std::false_type{});
+    using RT = std::integral_constant<int, -1>;
+    for (int t = 0; t < n_split; ++t) iter(t, std::true_type{}, RT{});
+    int t = n_split;
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+    if constexpr (NS == 4 && NW == 8 && !HAS_MASK && !SHORTKV) {
+      // unrolled by the ring depth: stage = t % NS is an immediate (n_split is 0 here, so t starts at a multiple of NS)
+      for (; t + NS <= nt; t += NS) {
+        iter(t, std::false_type{}, std::integral_constant<int, 0>{});
+        iter(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        iter(t + 2, std::false_type{}, std::integral_constant<int, 2>{});
+        iter(t + 3, std::false_type{}, std::integral_constant<int, 3>{});
+      }
+    }
+#endif
+    for (; t < nt; ++t) iter(t, std::false_type{}, RT{});
 #ifdef MRAG_ATTN_STAMPS
     if (g_stamp_buf && lane == 0 && blockIdx.x < 2048) {
       for (int k = 0; k < 6; ++k) g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + k] = acc_t[k];

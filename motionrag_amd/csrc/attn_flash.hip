@@ -65,10 +65,11 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_YOUNG_PRIO 0
 #endif
 #ifndef MRAG_ATTN_MFMA_MAX
-// 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block) instead of 32 v_add per tile.
-// Measured on MI355X (interleaved A/B, B=2 H=48 S=17776): 992.6-994.8 vs 994.1-995.6 TFLOP/s -> neutral, so off: trading 128
-// vector-issue cycles for 64 matrix cycles does not move this kernel, i.e. it is not purely vector-issue-bound.
-#define MRAG_ATTN_MFMA_MAX 0
+// 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block whose key fragment is (-1, 0, ...) and whose
+// query fragment is (m, 0, ...), m kept bf16-representable) instead of 32 v_add per tile.  Measured on MI355X (interleaved A/B, B=2 H=48
+// S=17776): neutral in the first 4-waves-per-SIMD kernel (992-995 vs 994-996 TFLOP/s), +1.6 % once the ring stage became an immediate
+// and the loop was unrolled (1010-1016 vs 994-999): the vector pipe is the busier one (PMC: ~77 % active, 9-10 vector instructions per MFMA)
+#define MRAG_ATTN_MFMA_MAX 1
 #endif
 
 namespace {
@@ -283,7 +284,12 @@ __device__ __forceinline__ void qk_tile_imm(const Lane& ln, const bf16x8 (&qf)[4
   between();
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if MRAG_ATTN_MFMA_MAX
+  const u32x4 kneg = {ln.hh == 0 ? 0x0000bf80u : 0u, 0u, 0u, 0u};
+  const u32x4 qm = {__float_as_uint(negm[1]), 0u, 0u, 0u};
+#else
   const float nm = negm[0];
+#endif
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
@@ -293,8 +299,13 @@ __device__ __forceinline__ void qk_tile_imm(const Lane& ln, const bf16x8 (&qf)[4
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
+#if MRAG_ATTN_MFMA_MAX
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
+#else
 #pragma unroll
   for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
+#endif
 }
 
 template <int STG>

@@ -32,8 +32,11 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2 u)
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  // x * sigmoid(2u) with u = x (c1 + c2 x^2); exp2 with the constants folded and v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+  // (~10 instructions) that `x / (1 + e)` compiles to: the result is rounded to bf16 anyway
+  const float t = __builtin_fmaf(x * x, 0.0356774081363001f, 0.7978845608028654f);
+  const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * (t * x));      // exp(-2u) = exp2(-2 log2(e) u)
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 // exact-erf GELU.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): one v_rcp + one v_exp + 7 FMAs
 // instead of the ~40-instruction branchy libm erff -- in a short-K GEMM (K = 320 GEGLU projections) the libm call was
@@ -49,7 +52,7 @@ __device__ __forceinline__ float erf_as_f(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.7071067811865476f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // async global -> LDS copy of 16 bytes per lane; LDS destination is
 // wave-uniform base + lane*16 (cdna_hip_programming.md section 5 caveat).

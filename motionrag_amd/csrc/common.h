@@ -43,12 +43,12 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 // ~20k of a workgroup's ~43k cycles.
 __device__ __forceinline__ float erf_as_f(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE reciprocal sequence
   float pl = fmaf(1.061405429f, t, -1.453152027f);
   pl = fmaf(pl, t, 1.421413741f);
   pl = fmaf(pl, t, -0.284496736f);
   pl = fmaf(pl, t, 0.254829592f);
-  const float r = 1.0f - pl * t * __expf(-ax * ax);
+  const float r = 1.0f - pl * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.7071067811865476f)); }

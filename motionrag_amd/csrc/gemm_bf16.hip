@@ -306,6 +306,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     }
   }
 
+  // (batch, position-in-batch) of a row without a 64-bit division per row (~100 vector instructions each): ONE division per workgroup for
+  // its first row, then rows advance by < 256 -- a short subtract loop (rows_per_batch is 17 776 on the DiT; tiny values still terminate)
+  long long wg_b = 0, wg_pos = 0;
+  if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_QKNORM_ROPE) {
+    wg_b = bm0 / p.rows_per_batch;
+    wg_pos = bm0 - wg_b * p.rows_per_batch;
+  }
+  auto row_bp = [&](long long m, long long& b, long long& pos) {
+    b = wg_b; pos = wg_pos + (m - bm0);
+    while (pos >= p.rows_per_batch) { pos -= p.rows_per_batch; ++b; }
+  };
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n0 + (lane >> 4) * 4 + {0..3}
   constexpr bool STAGED = (TM == 8 && TN == 4 && WM == 2 && WN == 4);
   if (STAGED && p.staged) {
@@ -322,7 +333,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       const bf16_t* gate = nullptr;
       if constexpr (EPI == MRAG_EPI_GATE_RESID) {
         const long long mc = m < p.M ? m : p.M - 1;
-        const long long b = mc / p.rows_per_batch, pos = mc - b * p.rows_per_batch;
+        long long b, pos;
+        row_bp(mc, b, pos);
         gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
       }
 #pragma unroll
@@ -351,7 +363,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     // row layout: lane -> row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7): one instruction = 8 x 128 contiguous bytes
     const int rsub = lane >> 3, chunk = lane & 7;
     const long long n = bn0 + wn * TN * 16 + chunk * 8;
-#pragma unroll 4
+    // residual epilogues: all 16 residual vectors of the lane are requested up front (the accumulator registers are free once the tile sits
+    // in LDS), so the tail of a workgroup pays ONE memory latency instead of four batches of four
+    u32x4 rpre[16];
+    if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const long long m = bm0 + wm * TM * 16 + g * 8 + rsub;
+        rpre[g] = (m < p.M && n + 8 <= p.N) ? *(const u32x4*)(p.resid + m * p.ldr + n) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int row = g * 8 + rsub;
       const long long m = bm0 + wm * TM * 16 + row;
@@ -391,7 +413,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
             }
           }
           const long long mc = m < p.M ? m : p.M - 1;
-          const int pos = (int)(mc % p.rows_per_batch);
+          long long rb, rpos;
+          row_bp(mc, rb, rpos);
+          const int pos = (int)rpos;
           if (p.rcos && pos >= p.rope_text_len) {
             const long long ro = (long long)(pos - p.rope_text_len) * 64 + d0;
             const f32x4 c0 = *(const f32x4*)(p.rcos + ro), c1 = *(const f32x4*)(p.rcos + ro + 4);
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       }
       if (m < p.M && n + 8 <= p.N) {
         if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
-          const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + n);
+          const u32x4 rr = rpre[g];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(rr[e] << 16);
@@ -491,7 +515,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     if (m >= p.M) continue;
     const bf16_t* gate = nullptr;
     if constexpr (EPI == MRAG_EPI_GATE_RESID) {
-      const long long b = m / p.rows_per_batch, pos = m - b * p.rows_per_batch;
+      long long b, pos;
+      row_bp(m, b, pos);
       gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
     }
 #pragma unroll

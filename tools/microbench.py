@@ -106,6 +106,24 @@ def gemm320():
     print(f"conv3x3 320->320 on [28,72,128]: {dt*1e3:.3f} ms  {2.0*M*320*2880/dt/1e12:.1f} TFLOP/s")
 
 
+def gemm_epi():
+    """the DiT's fused-epilogue GEMMs: gate * out + resid (to_out / FF2) and QKV + qk-norm + RoPE"""
+    B, S, D = 2, 17776, 3072
+    x = torch.randn(B, S, D, device=DEV).to(torch.bfloat16)
+    res = torch.randn(B, S, D, device=DEV).to(torch.bfloat16)
+    gate = torch.randn(B, 2 * D, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(D, D, device=DEV) * 0.02).to(torch.bfloat16); bias = torch.randn(D, device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(res)
+    dt = timeit(lambda: ops.linear(x, w, bias, out=out, epilogue=ops.EPI_GATE_RESID, resid=res, gate0=gate[:, :D], gate1=gate[:, D:], rows_per_batch=S, split=226,
+                                   gate_stride=gate.stride(0)))
+    print(f"gemm to_out gate+resid N=3072 K=3072: {dt*1e3:.3f} ms  {2.0*B*S*D*D/dt/1e12:.0f} TFLOP/s")
+    wq = (torch.randn(3 * D, D, device=DEV) * 0.02).to(torch.bfloat16); bq = torch.randn(3 * D, device=DEV).to(torch.bfloat16)
+    g = torch.ones(64, device=DEV, dtype=torch.bfloat16); bb = torch.zeros(64, device=DEV, dtype=torch.bfloat16)
+    cos = torch.rand(S - 226, 64, device=DEV); sin = torch.rand(S - 226, 64, device=DEV)
+    dt = timeit(lambda: ops.qkv_linear_qknorm_rope(x, wq, bq, 48, g, bb, g, bb, cos, sin, 226, q_premul=0.18))
+    print(f"gemm qkv + qknorm + rope N=9216 K=3072: {dt*1e3:.3f} ms  {2.0*B*S*3*D*D/dt/1e12:.0f} TFLOP/s")
+
+
 def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
     res = {}
     for N, Q in cases:

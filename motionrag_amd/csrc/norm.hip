@@ -68,11 +68,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 
   const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
   if (p.shift0) {
-    const long long b = row / p.rows_per_batch, pos = row - b * p.rows_per_batch;
-    shift = (pos < p.split ? p.shift0 : p.shift1) + b * p.mod_stride;
-    scale = (pos < p.split ? p.scale0 : p.scale1) + b * p.mod_stride;
+    // rows fit 32 bits (host check): a 32-bit unsigned division is ~4x shorter than the 64-bit sequence
+    const unsigned b = (unsigned)row / (unsigned)p.rows_per_batch, pos = (unsigned)row - b * (unsigned)p.rows_per_batch;
+    shift = ((long long)pos < p.split ? p.shift0 : p.shift1) + (long long)b * p.mod_stride;
+    scale = ((long long)pos < p.split ? p.scale0 : p.scale1) + (long long)b * p.mod_stride;
   }
-  bf16_t* y = p.y_rpb > 0 ? p.y + (row / p.y_rpb) * p.y_bstride + (row % p.y_rpb) * p.ldy : p.y + row * p.ldy;
+  bf16_t* y = p.y_rpb > 0 ? p.y + (long long)((unsigned)row / (unsigned)p.y_rpb) * p.y_bstride + (long long)((unsigned)row % (unsigned)p.y_rpb) * p.ldy : p.y + row * p.ldy;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const long long idx = ((long long)c * 64 + lane) * 8;
@@ -176,7 +177,7 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   if (!a || !a->x || !a->y || a->rows <= 0 || a->D <= 0) return MRAG_EINVAL;
   if (a->D % 8 != 0 || a->ldx % 8 != 0 || a->ldy % 8 != 0) return MRAG_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->y) & 15) return MRAG_EINVAL;
-  if (a->D > 8192) return MRAG_ENOTSUP;
+  if (a->D > 8192 || a->rows >= (1LL << 31) || a->rows_per_batch >= (1LL << 31) || a->y_rows_per_batch >= (1LL << 31)) return MRAG_ENOTSUP;
   if (a->shift0 && (!a->scale0 || !a->shift1 || !a->scale1 || a->rows_per_batch <= 0 || a->mod_stride % 8 != 0))
     return MRAG_EINVAL;
   LnP p{};

@@ -144,14 +144,28 @@ __global__ void cfg_ddim_kernel(const bf16_t* vp, bf16_t* x, long long n8, long 
 // y[r, :] = x[r, :] + table[(r / div) % period, :]  (per-frame / per-sample vectors broadcast over the pixels of a frame)
 __global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long div, long long period) {
   const long long total = rows * D8;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / D8, c = i - r * D8;
+  // (row, column vector) advance incrementally: one 64-bit division per thread instead of three per 16-byte vector
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long rstep = stride / D8, cstep = stride - rstep * D8;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long r = i / D8, c = i - r * D8;
+  long long bidx = (r / div) % period, brem = r % div;       // table row of r and r's offset inside its group of `div` rows
+  for (; i < total; i += stride) {
     float u[8], v[8];
     unpack8(*(const u32x4*)(x + i * 8), u);
-    unpack8(*(const u32x4*)(table + (((r / div) % period) * D8 + c) * 8), v);
+    unpack8(*(const u32x4*)(table + (bidx * D8 + c) * 8), v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) u[e] += v[e];
     *(u32x4*)(y + i * 8) = pack8(u);
+    long long dr = rstep;
+    c += cstep;
+    if (c >= D8) { c -= D8; ++dr; }
+    brem += dr;
+    if (brem >= div) {                                       // crossing into another group: divide only then (always, for div == 1)
+      const long long q = brem / div;
+      brem -= q * div;
+      bidx = (bidx + q) % period;
+    }
   }
 }
 

@@ -141,8 +141,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p, const float*
   const long long vecs = p.HW * C8;
   const bf16_t* xb = p.x + (long long)n * p.HW * p.C;
   bf16_t* yb = p.y + (long long)n * p.HW * p.C;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (long long)gridDim.x * 256) {
-    const int c0 = (int)(i % C8) * 8;
+  // channel vector of element i without a 64-bit modulo per vector (~100 instructions against 8 FMAs): one modulo per thread, then a
+  // conditional subtract per grid stride
+  const unsigned stride = gridDim.x * 256u, cstep = stride % (unsigned)C8;
+  unsigned cv = (unsigned)((blockIdx.x * 256u + threadIdx.x) % (unsigned)C8);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += stride, cv = cv + cstep >= (unsigned)C8 ? cv + cstep - (unsigned)C8 : cv + cstep) {
+    const int c0 = (int)cv * 8;
     float v[8];
     unpack8(*(const u32x4*)(xb + i * 8), v);
 #pragma unroll

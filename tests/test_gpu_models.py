@@ -313,3 +313,28 @@ def test_folded_adapter_cache_follows_the_motion_tokens(hip):
     finally:
         attn_processor.FOLD_IP_QUERY = True
     assert ((lit - a2).norm() / lit.norm()).item() < 1e-2                   # folded vs literal association: bf16 rounding only
+
+
+def test_dit_full_width_layer_matches_oracle(hip):
+    """ONE CogVideoX-5B-width block (48 heads x 64 = 3072, text 226 x 4096, FF 12288, 1024-d motion tokens) on 2 latent frames of the 60x90 grid
+    (S = 226 + 2700) against the fp32 oracle: the BASELINE kernels' real shapes -- 256x256 GEMM tiles, the fused QKV / qk-norm / RoPE and
+    gate-residual epilogues, the 8-wave flash attention with a ragged last tile, the folded adapter branch -- not only the reduced-width model"""
+    from motionrag_amd.cogvideox import CogVideoXTransformer3DModel
+    from oracle import cogvideox_ref
+    cfg = cogvideox_ref.DiTConfig(num_layers=1, frames=2)
+    sd = cogvideox_ref.random_dit_sd(cfg, seed=61, std=0.02)
+    model = CogVideoXTransformer3DModel(num_layers=1, sample_frames=2)
+    model.install_motion_adapters(1024)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(62)
+    lat, img = (torch.randn(1, 2, 16, 60, 90, generator=g).to(torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 226, 4096, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, 1024, generator=g).to(torch.bfloat16)
+    t = torch.tensor([481.0, 481.0])
+    cos, sin = cogvideox_ref.rope_3d(64, 2, 30, 45)
+    got = model(lat.to(DEV), text.to(DEV), t.to(DEV), image_rotary_emb=((cos.to(DEV), sin.to(DEV)), ip.to(DEV)), image_latents=img.to(DEV), batch=2)
+    x = torch.cat([torch.cat([lat] * 2), torch.cat([img] * 2)], dim=2).float()
+    want = cogvideox_ref.dit_forward(_bf_round(sd), cfg, x, text.float(), t, (cos, sin), ip.float())
+    assert got.shape == want.shape == (2, 2, 16, 60, 90)
+    close(got, want)

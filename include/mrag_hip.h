@@ -120,9 +120,19 @@ typedef struct mrag_attn_args {
   float out_scale;      /* multiplies the attention output (adapter scale)   */
   int32_t q_prescaled;  /* nonzero: Q already carries scale*log2(e) (q_premul
                            of mrag_qknorm_rope_bf16); `scale` is then ignored */
+  void* workspace;         /* optional scratch, 16-byte aligned, private to the
+                              call until it completes on `stream`; NULL = none */
+  int64_t workspace_bytes; /* >= mrag_attn_workspace_bytes(B, H, Sq, Skv) enables
+                              the key-split tail of long sequences (same
+                              result up to fp32 summation order)              */
 } mrag_attn_args;
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
+
+/* Scratch bytes with which mrag_attn_fwd_bf16 runs the ragged last query tile
+ * (Sq % 256 rows per (b, h)) as several short key-chunk workgroups + a merge
+ * instead of B*H full-length stragglers; 0 when the shape has no such tail.  */
+int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv);
 
 /* ------------------------------------------------------------------------ */
 /* Motion-adapter branch with the query projection folded into the keys:      */

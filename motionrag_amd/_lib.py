@@ -23,7 +23,7 @@ EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={o
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_attn_fwd_bf16", "mrag_layernorm_bf16",
+    "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
@@ -57,6 +57,7 @@ class AttnArgs(Structure):
         ("o_sb", c_int64), ("o_ss", c_int64),
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Skv", c_int32), ("kv_batch_div", c_int32),
         ("scale", c_float), ("out_scale", c_float), ("q_prescaled", c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -150,6 +151,8 @@ def lib() -> ctypes.CDLL:
         raise HipLibraryMissing(f"{LIB_PATH} has ABI {L.mrag_abi_version()}, expected {ABI_VERSION}: rebuild")
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
+    L.mrag_attn_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
+    L.mrag_attn_workspace_bytes.restype = c_int64
     L.mrag_layernorm_bf16.argtypes = [c_void_p, POINTER(LnArgs)]
     L.mrag_qknorm_rope_bf16.argtypes = [c_void_p, POINTER(QkNormRopeArgs)]
     L.mrag_timestep_embedding_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32]

@@ -79,6 +79,10 @@ struct AttnP {
   long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss;
   int B, H, Sq, Skv, kv_div, n_qtiles;
   float qscale, out_scale;
+  // key-split tail (KVSPLIT instantiation): workgroups >= n_main own (b, h, chunk) of the ragged last query tile
+  int n_main, kv_splits, chunk_keys, rem_rows;
+  float* part_o;    // [B*H*kv_splits, rem_rows, 64] unnormalised partial outputs
+  float2* part_ml;  // [B*H*kv_splits, rem_rows] (running max in log2 units, row sum)
 };
 
 constexpr float kThr = 5.0f;          // deferred-rescale threshold in log2 units (P <= 32)
@@ -350,19 +354,20 @@ struct Run {
 // softmax bookkeeping of one tile: masks, tile max, deferred rescale, P = exp2(S'), row sum, bf16 B fragments.
 // register i of block kb holds key t*64 + kb*32 + (i&3) + 8*(i>>2) + 4*hh for query (lane & 31).
 template <bool HAS_MASK, bool HAS_NEXT, typename Mid = NoHook>
-__device__ __forceinline__ void softmax_tile(const AttnP& p, const Lane& ln, int t, int nt, int qrow_c, f32x16& s0, f32x16& s1, f32x16& n0,
-                                             f32x16& n1, Run& r, bf16x8 (&pb)[4], Mid mid = Mid()) {
+__device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, const Lane& ln, int t, int nt, int qrow_c, f32x16& s0, f32x16& s1,
+                                             f32x16& n0, f32x16& n1, Run& r, bf16x8 (&pb)[4], Mid mid = Mid()) {
+  // skv = keys this workgroup scans (p.Skv, or its chunk of them in the key-split tail; the mask path is never split)
   // key held by register i of block kb: tile_start + kb*32 + (i&3) + 8*(i>>2) + 4*hh; the last tile of a long sequence starts at
   // Skv-64 (slid back), keys before t*64 were already consumed by the previous tile
-  const int tile_start = p.Skv >= KVB ? (t * KVB < p.Skv - KVB ? t * KVB : p.Skv - KVB) : 0;
+  const int tile_start = skv >= KVB ? (t * KVB < skv - KVB ? t * KVB : skv - KVB) : 0;
   const int kbase_idx = tile_start + 4 * ln.hh;
-  if (t == nt - 1 && (p.Skv & (KVB - 1))) {
+  if (t == nt - 1 && (skv & (KVB - 1))) {
     const int lo = t * KVB;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
-      if (key < lo || key >= p.Skv) s0[i] = -INFINITY;
-      if (key + 32 < lo || key + 32 >= p.Skv) s1[i] = -INFINITY;
+      if (key < lo || key >= skv) s0[i] = -INFINITY;
+      if (key + 32 < lo || key + 32 >= skv) s1[i] = -INFINITY;
     }
   }
   if constexpr (HAS_MASK) {
@@ -536,7 +541,9 @@ __device__ __forceinline__ void pv_half(const char* vst, const Lane& ln, int hal
 
 // SHORTKV: key sets of at most one tile (motion tokens, text, temporal frames) -- same code, no barrier stagger; a separate
 // instantiation so that profiles list the HBM-bound small-KV launches apart from the MFMA-bound long-sequence ones.
-template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false>
+// KVSPLIT: the launch's last workgroups (blockIdx >= n_main) each scan ONE CHUNK of the keys for the ragged last query tile of a
+// (b, h) pair and leave (unnormalised O, running max, row sum) in the workspace for attn_combine_kernel -- see launch_attn_split.
+template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false, bool KVSPLIT = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATTN_WPS : 1) void attn_fwd_kernel(const AttnP p) {
   constexpr int PPW = NW >= 8 ? 1 : 8 / NW;  // 1 KiB DMA pieces per wave per K (or V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,7 +556,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   // ---- XCD-aware block -> (q-tile, b, h)
   const int nbh = p.B * p.H;
   int bh, qt;
-  if ((nbh & 7) == 0) {
+  int skv = p.Skv, key0 = 0;          // keys this workgroup scans: [key0, key0 + skv)
+  bool split_unit = false;
+  if (KVSPLIT && (int)blockIdx.x >= p.n_main) {
+    const int u = blockIdx.x - p.n_main;
+    bh = u / p.kv_splits;
+    qt = p.n_qtiles;                  // the ragged tile after the n_qtiles full ones
+    key0 = (u % p.kv_splits) * p.chunk_keys;
+    skv = p.Skv - key0 < p.chunk_keys ? p.Skv - key0 : p.chunk_keys;
+    split_unit = true;
+  } else if ((nbh & 7) == 0) {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     bh = (j / p.n_qtiles) * 8 + x;
     qt = j % p.n_qtiles;
@@ -577,8 +593,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   }
 
   // ---- LDS-DMA staging: piece = 8 keys x 128 B; lane i -> key (i >> 3), 16-byte position (i & 7)
-  const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh;
-  const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh;
+  const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh + (long long)key0 * p.k_ss;
+  const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh + (long long)key0 * p.v_ss;
   const int prow = lane >> 3, ppos = lane & 7;
   unsigned k_loff[PPW], v_loff[PPW];   // loop-invariant per-lane byte offsets inside a tile (source-side swizzles folded in)
 #pragma unroll
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   // A partial last tile is SLID BACK to keys [Skv-64, Skv) (its already-seen keys are masked in softmax_tile), and prefetches past
   // the end re-read that tile: every DMA of a >= 64-key sequence is a full in-range tile -> scalar tile base + loop-invariant
   // per-lane offset, no per-lane clamping (no 64-bit lane arithmetic, nothing to spill).  Shorter key sets clamp rows instead.
-  const int last_start = p.Skv - KVB;
+  const int last_start = skv - KVB;
   const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_k = [&](int stage, int t) {
     if (last_start >= 0) {
@@ -603,7 +619,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       for (int i = 0; i < PPW; ++i) {
         const int piece = (wave + i * NW) & 7;
         const int kit = piece * 8 + prow;
-        const int key = kit < p.Skv ? kit : p.Skv - 1;  // rows past the end re-read a valid row; their scores are masked
+        const int key = kit < skv ? kit : skv - 1;  // rows past the end re-read a valid row; their scores are masked
         glds16(kbase + (long long)key * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8, smem + stage * TILE_BYTES + piece * 1024);
       }
     }
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       for (int i = 0; i < PPW; ++i) {
         const int piece = (wave + i * NW) & 7;
         const int kit = piece * 8 + prow;
-        const int key = kit < p.Skv ? kit : p.Skv - 1;
+        const int key = kit < skv ? kit : skv - 1;
         glds16(vbase + (long long)key * p.v_ss + (ppos ^ (((kit >> 1) & 1) << 2)) * 8, smem + V_BASE + stage * TILE_BYTES + piece * 1024);
       }
     }
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   // ---- main loop.  K and V each own a ring of NS stages; the DMA runs D = NS-1 tiles ahead of the compute and is
   // retired by a COUNTED vmcnt (every wave issues exactly 2*PPW DMA instructions per tile pair, tiles past the end
   // re-read clamped rows so the count never changes) + a raw s_barrier: __syncthreads() would drain the queue.
-  const int nt = (p.Skv + KVB - 1) / KVB;
+  const int nt = (skv + KVB - 1) / KVB;
 #if MRAG_ATTN_YOUNG_PRIO
   // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment (stamps: QK^T 1600 vs 1220 cycles,
   // exp / PV 1300 vs 1000) and the first half then waits for it at the per-tile barrier: one static priority bump for that half
@@ -738,11 +754,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
         softmax_block(t, 1, s1, nullptr, r, pb);
         pv_half(smem + V_BASE + (t % NS) * TILE_BYTES, ln, 1, pb, r.o0, r.o1);
       } else {
-        softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
+        softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
         pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
       }
 #else
-      softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
+      softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
       if constexpr (STG >= 0) pv_tile_imm<STG>(ln, pb, r.o0, r.o1);
       else
@@ -757,7 +773,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     // full unmasked tiles take the per-block pipeline; the ragged last tile (and the masked instantiation) the one-softmax path,
     // in separate loops so that neither path's live state burdens the other
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
-    const int n_split = HAS_MASK ? 0 : ((p.Skv & (KVB - 1)) ? nt - 1 : nt);
+    const int n_split = HAS_MASK ? 0 : ((skv & (KVB - 1)) ? nt - 1 : nt);
 #else
     const int n_split = 0;
 #endif
@@ -804,9 +820,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       bf16x8 pb[4];
       if (t + 1 < nt) {
         qk_tile(smem + ((t + 1) % NS) * TILE_BYTES, ln, qf, r.negm, n0, n1);
-        softmax_tile<HAS_MASK, true>(p, ln, t, nt, qrow_c, c0, c1, n0, n1, r, pb);
+        softmax_tile<HAS_MASK, true>(p, skv, ln, t, nt, qrow_c, c0, c1, n0, n1, r, pb);
       } else {
-        softmax_tile<HAS_MASK, false>(p, ln, t, nt, qrow_c, c0, c1, c0, c1, r, pb);
+        softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, c0, c1, c0, c1, r, pb);
       }
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
     };
@@ -826,6 +842,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     r.lacc[0] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
 #endif
+  if (KVSPLIT && split_unit) {   // partial result of this key chunk; attn_combine_kernel merges the chunks
+    const long long prow_i = (long long)(blockIdx.x - p.n_main) * p.rem_rows + wave * 32 + r32;
+    float* po = p.part_o + prow_i * 64 + 4 * ln.hh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = dt ? f32x4{r.o1[4 * g], r.o1[4 * g + 1], r.o1[4 * g + 2], r.o1[4 * g + 3]}
+                           : f32x4{r.o0[4 * g], r.o0[4 * g + 1], r.o0[4 * g + 2], r.o0[4 * g + 3]};
+        *(f32x4*)(po + dt * 32 + 8 * g) = v;
+      }
+    }
+    if (ln.hh == 0) p.part_ml[prow_i] = make_float2(r.m, r.lacc[0]);
+    return;
+  }
   const float inv = p.out_scale / r.lacc[0];
   const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * ln.hh;
 #pragma unroll
@@ -865,7 +896,90 @@ int launch_attn(hipStream_t s, AttnP p) {
   return MRAG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- key-split tail
+// Long-sequence launches are many rounds of 512 resident workgroups (2 per CU) and the LAST round is what the ragged query tile of each
+// (b, h) pair leaves: B*H workgroups that each scan ALL keys for Sq % 256 rows.  At the BASELINE shape (B*H = 96, Sq = 17 776 =
+// 69 x 256 + 112) those 96 workgroups are 1.4 % of the launch's work and 4 % of its time (tools/tail_probe.py: 7.33 ms for the 6624
+// full tiles, 7.63 ms with the ragged ones).  Splitting THEIR keys into `kv_splits` chunks turns the 96 long stragglers into ~512 short
+// workgroups that drain into the slots the last full round frees; each leaves (unnormalised O, running max, row sum) in a caller-provided
+// workspace and attn_combine_kernel merges the chunks, applies out_scale / resid and writes bf16 -- the same online-softmax algebra as
+// between two key tiles, carried through HBM instead of registers.
+struct SplitPlan {
+  int splits = 1, chunk_keys = 0, rem_rows = 0, n_full = 0;
+  size_t bytes = 0;
+};
+
+SplitPlan plan_kv_split(int B, int H, int Sq, int Skv) {
+  SplitPlan pl;
+  const int rem = Sq % 256, n_full = Sq / 256, nt = (Skv + KVB - 1) / KVB;
+  const long long nbh = (long long)B * H;
+  int want = (int)(512 / nbh);
+  if (want > 8) want = 8;
+  if (const char* e = getenv("MRAG_ATTN_KV_SPLITS")) want = atoi(e);   // tuning knob; 0 / 1 = never split
+  if (rem == 0 || nbh * n_full < 1024 || want < 2 || nt < 8 * want) return pl;
+  const int tpc = (nt + want - 1) / want;
+  const int chunk = tpc * KVB, splits = (Skv + chunk - 1) / chunk;
+  if (splits < 2 || Skv - (splits - 1) * chunk < KVB) return pl;       // every chunk must hold one whole (slid-back) tile
+  pl.splits = splits; pl.chunk_keys = chunk; pl.rem_rows = rem; pl.n_full = n_full;
+  pl.bytes = (size_t)nbh * splits * rem * (64 * sizeof(float) + sizeof(float2));
+  return pl;
+}
+
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
+  const long long idx = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);   // (b*H + h, row of the ragged tile); 16 lanes x 4 columns per row
+  if (idx >= (long long)p.B * p.H * p.rem_rows) return;
+  const int bh = (int)(idx / p.rem_rows), row = (int)(idx % p.rem_rows), d = (threadIdx.x & 15) * 4;
+  const long long u0 = (long long)bh * p.kv_splits;
+  float M = -INFINITY;
+  for (int c = 0; c < p.kv_splits; ++c) M = fmaxf(M, p.part_ml[(u0 + c) * p.rem_rows + row].x);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int c = 0; c < p.kv_splits; ++c) {
+    const long long pr = (u0 + c) * p.rem_rows + row;
+    const float2 ml = p.part_ml[pr];
+    const float w = __builtin_amdgcn_exp2f(ml.x - M);
+    l += w * ml.y;
+    acc += *(const f32x4*)(p.part_o + pr * 64 + d) * w;
+  }
+  const float inv = p.out_scale / l;
+  const int b = bh / p.H, h = bh % p.H;
+  const long long off = (long long)b * p.o_sb + (long long)(p.n_qtiles * 256 + row) * p.o_ss + h * 64 + d;
+  float v[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+  if (p.resid) {
+    const u32x2 rr = *(const u32x2*)(p.resid + off);
+    v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+    v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+  }
+  u32x2 out;
+  out[0] = pack_bf2(v[0], v[1]);
+  out[1] = pack_bf2(v[2], v[3]);
+  *(u32x2*)(p.O + off) = out;
+}
+
+int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspace) {
+  const int nbh = p.B * p.H;
+  p.n_qtiles = pl.n_full;
+  p.n_main = pl.n_full * nbh;
+  p.kv_splits = pl.splits; p.chunk_keys = pl.chunk_keys; p.rem_rows = pl.rem_rows;
+  p.part_o = (float*)workspace;
+  p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl.splits * pl.rem_rows * 64 * sizeof(float));
+  const size_t lds = 2 * NS * TILE_BYTES;
+  const void* kf = (const void*)attn_fwd_kernel<8, false, false, false, true>;
+  const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  MRAG_LAUNCH((attn_fwd_kernel<8, false, false, false, true>), dim3(p.n_main + nbh * pl.splits), dim3(512), lds, s, p);
+  MRAG_LAUNCH_CHECK();
+  MRAG_LAUNCH(attn_combine_kernel, dim3((unsigned)(((long long)nbh * pl.rem_rows + 15) / 16)), dim3(256), 0, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
 }  // namespace
+
+extern "C" int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv) {
+  if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
+  return (int64_t)plan_kv_split(B, H, Sq, Skv).bytes;
+}
 
 // ---------------------------------------------------------------------------------------------- tiny sequences
 // Temporal attention of the UNets (TemporalTransformer / TemporalBasicTransformerBlock: 14-16 frames per pixel, head_dim 64, one
@@ -1083,6 +1197,11 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   int nw_big = 8;
   if (const char* e = getenv("MRAG_ATTN_NW")) nw_big = atoi(e);   // tuning knob (tools/microbench.py)
   if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
+  if (a->Sq > 128 && !pipe && !a->mask && a->workspace) {   // key-split tail for the ragged last query tile (plan_kv_split)
+    if (((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
+    const SplitPlan pl = plan_kv_split(a->B, a->H, a->Sq, a->Skv);
+    if (pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes) return launch_attn_split(s, p, pl, a->workspace);
+  }
   if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
   if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
   return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);

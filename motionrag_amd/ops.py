@@ -106,6 +106,19 @@ def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     return weight.detach()[perm].contiguous(), (bias.detach()[perm].contiguous() if bias is not None else None)
 
 
+_ATTN_WS = {}
+
+
+def _attn_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """scratch for mrag_attn_fwd_bf16's key-split tail, one grow-only buffer per (device, stream): launches on one stream are ordered,
+    so consecutive calls may share it"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _ATTN_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optional[torch.Tensor] = None,
               resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, kv_batch_div: int = 1,
               scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False) -> torch.Tensor:
@@ -150,6 +163,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
     a.scale = (64 ** -0.5) if scale is None else scale
     a.out_scale = out_scale
     a.q_prescaled = 1 if q_prescaled else 0
+    if mask is None:
+        need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)   # > 0: long sequence with a ragged last query tile (key-split tail)
+        if need > 0:
+            ws = _attn_workspace(q.device, need)
+            a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     timed = KERNEL_TIMING is not None and Skv >= 1024
     if timed:  # bench.py's roofline leg: HIP events on the launch stream around this one kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -186,6 +186,37 @@ def test_attention_large_sequence_properties(hip):
     close(out[:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
 
 
+def test_attention_key_split_tail(hip):
+    """long launches hand the ragged last query tile (Sq % 256 rows per head) to short key-chunk workgroups + a merge kernel
+    (attn_flash.hip plan_kv_split): the tail rows and a sample of the others equal the fp32 reference, with even and ragged chunkings, a
+    fused residual, and agree with the unsplit kernel to a bf16 ulp or two"""
+    from motionrag_amd import ops, _lib
+    g = torch.Generator().manual_seed(9)
+    B, H, Sq, Skv = 1, 16, 64 * 256 + 112, 4200
+    assert _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv) > 0 and _lib.lib().mrag_attn_workspace_bytes(B, H, 64 * 256, Skv) == 0
+    q = bf(torch.randn(B, Sq, H, 64, generator=g))
+    k, v = (bf(torch.randn(B, Skv, H, 64, generator=g)) for _ in range(2))
+    k[:, 3000] = bf(9.0 * q[:, Sq - 5] / q[:, Sq - 5].norm(dim=-1, keepdim=True))     # one tail row's max lives in a late chunk
+    resid = bf(torch.randn(B, Sq, H * 64, generator=g))
+    rows = torch.cat([torch.arange(Sq - 112, Sq), torch.randint(0, Sq - 112, (80,), generator=g)])
+    want = sdpa_ref(q[:, rows], k, v)
+    qd, kd, vd, rd = q.to(DEV), k.to(DEV), v.to(DEV), resid.to(DEV)
+    outs = {}
+    for splits in ("", "3", "0"):
+        if splits:
+            os.environ["MRAG_ATTN_KV_SPLITS"] = splits
+        try:
+            outs[splits] = ops.attention(qd, kd, vd)
+            fused = ops.attention(qd, kd, vd, resid=rd, out_scale=0.5)
+        finally:
+            os.environ.pop("MRAG_ATTN_KV_SPLITS", None)
+        close(outs[splits][:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
+        close(fused[:, rows.to(DEV)], resid[:, rows].float() + 0.5 * want, scale=1.0)
+    for splits in ("", "3"):
+        assert torch.equal(outs[splits][:, :Sq - 112], outs["0"][:, :Sq - 112])          # full tiles: same code path, bit-identical
+        close(outs[splits][:, Sq - 112:], outs["0"][:, Sq - 112:].float().cpu(), scale=0.05, rtol=2e-2, atol_frac=4e-2)
+
+
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104)])
 def test_layernorm(hip, rows, D):

@@ -38,6 +38,13 @@ extern "C" int mrag_debug_set_gemm_stamp_buffer(void* p) { return (int)hipMemcpy
 #define MRAG_DIAG_KSTEP BK
 #endif
 
+#ifndef MRAG_QK_RING
+#define MRAG_QK_RING 4   // row groups of RoPE table rows in flight in the QKNORM_ROPE epilogue (16 registers each; 6+ spill and lose)
+#endif
+#ifndef MRAG_QK_PRE
+#define MRAG_QK_PRE 0    // of which requested before the accumulators are staged (measured equal to 0 on MI355X: 1.925 vs 1.927 ms)
+#endif
+
 namespace {
 
 struct GemmP {
@@ -326,6 +333,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     // residual add in the row layout (same rounding points as the reference's bf16 tensors: gate * out, then + residual).
     constexpr int ROWB = 144;
     char* wbase = smem + wave * (128 * ROWB);
+    // QKNORM_ROPE: the wave's 64 columns are one head (256-wide tiles, 64-column wave tiles); in the row layout below 8 lanes x 8 features
+    // hold a row: per-head LayerNorm across those 8 lanes, RoPE on the lane's 4 (even, odd) pairs, Q pre-multiplied -- the arithmetic of
+    // qknorm_rope_kernel (norm.hip).  The fp32 cos / sin rows cost 64 B per lane and row group (1 KB per lane over the tile); issued
+    // inside the per-row `is a video row` branch they serialised 16 global-load latencies per workgroup.  They are fetched UNCONDITIONALLY
+    // instead (text rows read table row 0 and discard it) through a ring of QK_RING row groups of registers, each slot refilled as it is
+    // consumed.  MI355X, M = 35 552, N = 9216, K = 3072 (interleaved A/B): 1.99-2.01 ms before, 1.925 ms with a ring of 3 or 4; rings of
+    // 5+ make hipcc spill the table registers and lose the gain again.
+    constexpr int QK_RING = MRAG_QK_RING, QK_PRE = MRAG_QK_PRE;
+    f32x4 qk_tab[EPI == MRAG_EPI_QKNORM_ROPE ? QK_RING : 1][4];
+    unsigned qk_video = 0;              // bit g: row group g's row lies past the text rows (RoPE applies)
+    int qk_which = 2;                   // 0 = Q, 1 = K, 2 = V columns (wave-uniform)
+    bool has_rope = false;
+    const int rsub = lane >> 3, chunk = lane & 7;   // row layout: lane -> row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7)
+    auto qk_fetch = [&](int g) {
+      if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
+        const long long m = bm0 + wm * TM * 16 + g * 8 + rsub;
+        long long rb, rpos;
+        row_bp(m < p.M ? m : p.M - 1, rb, rpos);
+        const int pos = (int)rpos - p.rope_text_len;
+        if (pos >= 0) qk_video |= 1u << g;
+        const long long ro = (long long)(pos > 0 ? pos : 0) * 64 + chunk * 8;
+        f32x4(&dst)[4] = qk_tab[g % QK_RING];
+        dst[0] = *(const f32x4*)(p.rcos + ro); dst[1] = *(const f32x4*)(p.rcos + ro + 4);
+        dst[2] = *(const f32x4*)(p.rsin + ro); dst[3] = *(const f32x4*)(p.rsin + ro + 4);
+      }
+    };
+    if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
+      qk_which = (int)((bn0 + wn * TN * 16) / p.qk_D);
+      has_rope = p.rcos != nullptr && qk_which < 2;
+      if (has_rope) {
+#pragma unroll
+        for (int g = 0; g < QK_PRE; ++g) qk_fetch(g);
+      }
+    }
     __syncthreads();   // every wave is done with the operand stages that these per-wave regions overlay
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -360,8 +401,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         *(u32x2*)(wbase + (i * 16 + frag_row) * ROWB + (j * 16 + frag_q * 4) * 2) = out;
       }
     }
-    // row layout: lane -> row (lane >> 3) of an 8-row group, 16-byte chunk (lane & 7): one instruction = 8 x 128 contiguous bytes
-    const int rsub = lane >> 3, chunk = lane & 7;
+    // row layout: one instruction = 8 x 128 contiguous bytes
     const long long n = bn0 + wn * TN * 16 + chunk * 8;
     // residual epilogues: all 16 residual vectors of the lane are requested up front (the accumulator registers are free once the tile sits
     // in LDS), so the tail of a workgroup pays ONE memory latency instead of four batches of four
@@ -373,23 +413,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         rpre[g] = (m < p.M && n + 8 <= p.N) ? *(const u32x4*)(p.resid + m * p.ldr + n) : u32x4{0u, 0u, 0u, 0u};
       }
     }
+    bool qk_done = false;
+    if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
+      if (qk_which < 2) {
+        qk_done = true;
+        const bf16_t* gm = qk_which ? p.kg : p.qg;
+        const bf16_t* bt = qk_which ? p.kb : p.qb;
+        const int d0 = chunk * 8;
+        float gam[8], bet[8];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int row = g * 8 + rsub;
-      const long long m = bm0 + wm * TM * 16 + row;
-      u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
-      if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
-        // the wave's 64 columns are one head (256-wide tiles, 64-column wave tiles), 8 lanes x 8 features per row: per-head LayerNorm across
-        // those 8 lanes, RoPE on the lane's 4 (even, odd) pairs, Q pre-multiplied -- the arithmetic of qknorm_rope_kernel (norm.hip)
-        const int which = (int)(n / p.qk_D);                       // 0 = Q, 1 = K, 2 = V (wave-uniform)
-        if (which < 2) {
+        for (int e = 0; e < 8; ++e) { gam[e] = 1.f; bet[e] = 0.f; }
+        if (gm) {
+          const u32x4 graw = *(const u32x4*)(gm + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gam[2 * e] = __uint_as_float(graw[e] << 16); gam[2 * e + 1] = __uint_as_float(graw[e] & 0xffff0000u); }
+          if (bt) {
+            const u32x4 braw = *(const u32x4*)(bt + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bet[2 * e] = __uint_as_float(braw[e] << 16); bet[2 * e + 1] = __uint_as_float(braw[e] & 0xffff0000u); }
+          }
+        }
+        if (has_rope) {
+#pragma unroll
+          for (int g = QK_PRE; g < QK_RING; ++g) qk_fetch(g);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          __builtin_amdgcn_sched_barrier(0);   // one row group at a time: hoisting all 16 LDS reads / address computations spills the ring
+          const int row = g * 8 + rsub;
+          const long long m = bm0 + wm * TM * 16 + row;
+          u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(val[e] << 16); v[2 * e + 1] = __uint_as_float(val[e] & 0xffff0000u); }
-          const bf16_t* g = which ? p.kg : p.qg;
-          const bf16_t* bt = which ? p.kb : p.qb;
-          const int d0 = chunk * 8;
-          if (g) {
+          if (gm) {
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += v[e];
@@ -400,45 +457,44 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
             for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
             sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
             const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.qk_eps);
-            const u32x4 graw = *(const u32x4*)(g + d0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] = v[2 * e] * rstd * __uint_as_float(graw[e] << 16);
-              v[2 * e + 1] = v[2 * e + 1] * rstd * __uint_as_float(graw[e] & 0xffff0000u);
-            }
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e];
             if (bt) {
-              const u32x4 braw = *(const u32x4*)(bt + d0);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(braw[e] << 16); v[2 * e + 1] += __uint_as_float(braw[e] & 0xffff0000u); }
+              for (int e = 0; e < 8; ++e) v[e] += bet[e];
             }
           }
-          const long long mc = m < p.M ? m : p.M - 1;
-          long long rb, rpos;
-          row_bp(mc, rb, rpos);
-          const int pos = (int)rpos;
-          if (p.rcos && pos >= p.rope_text_len) {
-            const long long ro = (long long)(pos - p.rope_text_len) * 64 + d0;
-            const f32x4 c0 = *(const f32x4*)(p.rcos + ro), c1 = *(const f32x4*)(p.rcos + ro + 4);
-            const f32x4 s0 = *(const f32x4*)(p.rsin + ro), s1 = *(const f32x4*)(p.rsin + ro + 4);
-            const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-            const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            float o[8];
+          if (has_rope) {
+            const f32x4(&t4)[4] = qk_tab[g % QK_RING];
+            const float cc[8] = {t4[0][0], t4[0][1], t4[0][2], t4[0][3], t4[1][0], t4[1][1], t4[1][2], t4[1][3]};
+            const float ss[8] = {t4[2][0], t4[2][1], t4[2][2], t4[2][3], t4[3][0], t4[3][1], t4[3][2], t4[3][3]};
+            const bool vid = (qk_video >> g) & 1u;
 #pragma unroll
             for (int i2 = 0; i2 < 4; ++i2) {
-              o[2 * i2] = v[2 * i2] * cc[2 * i2] - v[2 * i2 + 1] * ss[2 * i2];
-              o[2 * i2 + 1] = v[2 * i2 + 1] * cc[2 * i2 + 1] + v[2 * i2] * ss[2 * i2 + 1];
+              const float a = v[2 * i2], b2 = v[2 * i2 + 1];
+              const float oa = a * cc[2 * i2] - b2 * ss[2 * i2];
+              const float ob = b2 * cc[2 * i2 + 1] + a * ss[2 * i2 + 1];
+              v[2 * i2] = vid ? oa : a;
+              v[2 * i2 + 1] = vid ? ob : b2;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = o[e];
+            if (g + QK_RING < 16) qk_fetch(g + QK_RING);   // refill the slot just consumed
           }
-          if (which == 0 && p.q_premul != 1.0f) {
+          if (qk_which == 0 && p.q_premul != 1.0f) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.q_premul;
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) val[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+          if (m < p.M) *(u32x4*)(p.C + m * p.ldc + n) = val;
         }
       }
+    }
+    if (!qk_done)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int row = g * 8 + rsub;
+      const long long m = bm0 + wm * TM * 16 + row;
+      u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
       if (m < p.M && n + 8 <= p.N) {
         if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
           const u32x4 rr = rpre[g];

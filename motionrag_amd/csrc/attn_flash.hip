@@ -64,6 +64,11 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 // static s_setprio for waves 4-7 of the 8-wave workgroup: measured 948-966 (prio 1) and 951-955 (prio 2) vs 966-983 TFLOP/s without -> off
 #define MRAG_ATTN_YOUNG_PRIO 0
 #endif
+#ifndef MRAG_ATTN_DOT2_SUM
+// softmax row sums by v_dot2c_f32_bf16 over the packed bf16 P pairs (see softmax_tile): 16 instead of 32 vector instructions per tile.
+// Interleaved A/B on MI355X: 7.743 vs 7.769 ms (+0.3 %) -- the vector-instruction count is no longer what bounds the loop.
+#define MRAG_ATTN_DOT2_SUM 1
+#endif
 #ifndef MRAG_ATTN_MFMA_MAX
 // 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block whose key fragment is (-1, 0, ...) and whose
 // query fragment is (m, 0, ...), m kept bf16-representable) instead of 32 v_add per tile.  Measured on MI355X (interleaved A/B, B=2 H=48
@@ -297,9 +302,11 @@ __device__ __forceinline__ void qk_tile_imm(const Lane& ln, const bf16x8 (&qf)[4
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
+#ifndef MRAG_ATTN_EXP_HALF_LDS   // diagnostic builds only (wrong results): how much of the loop is LDS bandwidth?
   asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\t"
                "s_waitcnt lgkmcnt(0)"
                : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(ln.kb[0]), "v"(ln.kb[1]), "v"(ln.kb[2]), "v"(ln.kb[3]), "n"(STG * TILE_BYTES + 4096) : "memory");
+#endif
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
@@ -326,6 +333,9 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
                    : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
                    : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 1024), "n"(STG * TILE_BYTES + 2048), "n"(STG * TILE_BYTES + 3072) : "memory");
     } else {
+#ifdef MRAG_ATTN_EXP_HALF_LDS
+      asm volatile("" : "=v"(u0[0]), "=v"(u0[1]), "=v"(u0[2]), "=v"(u0[3]), "=v"(u1[0]), "=v"(u1[1]), "=v"(u1[2]), "=v"(u1[3]));
+#else
       asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
                    "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
                    "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
@@ -333,6 +343,7 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
                    : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 5120), "n"(STG * TILE_BYTES + 6144), "n"(STG * TILE_BYTES + 7168) : "memory");
+#endif
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -438,11 +449,11 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
   for (int i = 0; i < 16; ++i) {
     s0[i] = __builtin_amdgcn_exp2f(s0[i]);
     s1[i] = __builtin_amdgcn_exp2f(s1[i]);
-#if MRAG_ATTN_WPS >= 4
+#if MRAG_ATTN_WPS >= 4 && !MRAG_ATTN_DOT2_SUM
     la += s0[i]; lb += s1[i];
 #endif
   }
-#if MRAG_ATTN_WPS >= 4
+#if MRAG_ATTN_WPS >= 4 && !MRAG_ATTN_DOT2_SUM
   r.lacc[0] += la + lb;   // lane-local half of the row sum; the two half-waves are combined in the epilogue
 #endif
 #pragma unroll
@@ -452,10 +463,23 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
     for (int j = 0; j < 4; ++j) {
       w0[j] = pack_bf2(s0[8 * s + 2 * j], s0[8 * s + 2 * j + 1]);
       w1[j] = pack_bf2(s1[8 * s + 2 * j], s1[8 * s + 2 * j + 1]);
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_DOT2_SUM
+      // row sum of the bf16 pairs the PV MFMAs consume: one v_dot2c_f32_bf16 (pair . (1, 1) + acc, fp32) per packed register instead of
+      // two v_add_f32 per pair -- 16 instead of 32 vector instructions per tile, and l sums exactly the P values that multiply V
+      // (the packed registers pass through an empty asm: hipcc 7.2 otherwise selects sub-register 0 of the u32x4 for all four dot2c)
+      unsigned p0 = w0[j], p1 = w1[j];
+      asm volatile("" : "+v"(p0), "+v"(p1));
+      w0[j] = p0; w1[j] = p1;
+      la = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, p0), __builtin_bit_cast(bf16v2, 0x3f803f80u), la, false);
+      lb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, p1), __builtin_bit_cast(bf16v2, 0x3f803f80u), lb, false);
+#endif
     }
     pb[s] = __builtin_bit_cast(bf16x8, w0);
     pb[2 + s] = __builtin_bit_cast(bf16x8, w1);
   }
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_DOT2_SUM
+  r.lacc[0] += la + lb;   // lane-local half of the row sum; the two half-waves are combined in the epilogue
+#endif
 }
 
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
@@ -879,6 +903,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     }
   }
 }
+
 
 template <int NW, bool PIPE, bool SHORTKV = false>
 int launch_attn(hipStream_t s, AttnP p) {

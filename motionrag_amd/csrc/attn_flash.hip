@@ -64,6 +64,11 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 // static s_setprio for waves 4-7 of the 8-wave workgroup: measured 948-966 (prio 1) and 951-955 (prio 2) vs 966-983 TFLOP/s without -> off
 #define MRAG_ATTN_YOUNG_PRIO 0
 #endif
+#ifndef MRAG_ATTN_UPFRONT
+// bit 0: all 8 K fragment reads of a tile up front; bit 1: all 16 V^T reads (see qk_tile_imm8).  Interleaved A/B on MI355X (B=2, H=48,
+// S=17776): 0 -> 7.770-7.790 ms, 1 -> 7.730, 2 -> 7.772-7.782, 3 -> 7.712-7.728: the K side is worth +0.7 %, the V side nothing -> 1
+#define MRAG_ATTN_UPFRONT 1
+#endif
 #ifndef MRAG_ATTN_DOT2_SUM
 // softmax row sums by v_dot2c_f32_bf16 over the packed bf16 P pairs (see softmax_tile): 16 instead of 32 vector instructions per tile.
 // Interleaved A/B on MI355X: 7.743 vs 7.769 ms (+0.3 %) -- the vector-instruction count is no longer what bounds the loop.
@@ -349,6 +354,66 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
     for (int k2 = 0; k2 < 2; ++k2) {
       const u32x4 w0 = {u0[2 * k2][0], u0[2 * k2][1], u0[2 * k2 + 1][0], u0[2 * k2 + 1][1]};
       const u32x4 w1 = {u1[2 * k2][0], u1[2 * k2][1], u1[2 * k2 + 1][0], u1[2 * k2 + 1][1]};
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
+    }
+  }
+}
+#endif
+
+#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE && MRAG_ATTN_MFMA_MAX
+// Both 32-key blocks' fragments requested UP FRONT (8 K reads / 16 V^T reads in flight, released to the MFMAs by counted lgkmcnt waits --
+// LDS reads return in order): the second block's LDS latency hides under the first block's MFMAs instead of being paid behind them.  The LDS
+// pipe is only ~25 % busy in this loop (256 B/clk per CU, tools/exp/lds_rate.hip; SQ_LDS_IDX_ACTIVE), so what the reads cost is their latency.
+template <int STG, typename Between = NoHook>
+__device__ __forceinline__ void qk_tile_imm8(const Lane& ln, const bf16x8 (&qf)[4], const f32x16& negm, f32x16& s0, f32x16& s1, Between between = Between()) {
+  u32x4 k0[4], k1[4];
+  asm volatile("ds_read_b128 %0, %8 offset:%12\n\tds_read_b128 %1, %9 offset:%12\n\tds_read_b128 %2, %10 offset:%12\n\tds_read_b128 %3, %11 offset:%12\n\t"
+               "ds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %9 offset:%13\n\tds_read_b128 %6, %10 offset:%13\n\tds_read_b128 %7, %11 offset:%13"
+               : "=&v"(k0[0]), "=&v"(k0[1]), "=&v"(k0[2]), "=&v"(k0[3]), "=&v"(k1[0]), "=&v"(k1[1]), "=&v"(k1[2]), "=&v"(k1[3])
+               : "v"(ln.kb[0]), "v"(ln.kb[1]), "v"(ln.kb[2]), "v"(ln.kb[3]), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 4096) : "memory");
+  between();
+  asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]) :: "memory");
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const u32x4 kneg = {ln.hh == 0 ? 0x0000bf80u : 0u, 0u, 0u, 0u};
+  const u32x4 qm = {__float_as_uint(negm[1]), 0u, 0u, 0u};
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0[ks]), qf[ks], s0, 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) :: "memory");
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1[0]), qf[0], zero, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1[ks]), qf[ks], s1, 0, 0, 0);
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
+}
+
+template <int STG>
+__device__ __forceinline__ void pv_tile_imm16(const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
+  u32x2 u0[8], u1[8];
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+               "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+               "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13"
+               : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+               : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 1024), "n"(STG * TILE_BYTES + 2048), "n"(STG * TILE_BYTES + 3072) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+               "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+               "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+               "s_waitcnt lgkmcnt(8)"
+               : "=&v"(u0[4]), "=&v"(u0[5]), "=&v"(u0[6]), "=&v"(u0[7]), "=&v"(u1[4]), "=&v"(u1[5]), "=&v"(u1[6]), "=&v"(u1[7])
+               : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 5120), "n"(STG * TILE_BYTES + 6144), "n"(STG * TILE_BYTES + 7168) : "memory");
+  asm volatile("" : "+v"(u0[0]), "+v"(u0[1]), "+v"(u0[2]), "+v"(u0[3]), "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));   // half 0 has landed
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u0[4]), "+v"(u0[5]), "+v"(u0[6]), "+v"(u0[7]), "+v"(u1[4]), "+v"(u1[5]), "+v"(u1[6]), "+v"(u1[7]) :: "memory");
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int i = half * 4 + 2 * k2;
+      const u32x4 w0 = {u0[i][0], u0[i][1], u0[i + 1][0], u0[i + 1][1]};
+      const u32x4 w1 = {u1[i][0], u1[i][1], u1[i + 1][0], u1[i + 1][1]};
       o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
     }
@@ -763,7 +828,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       f32x16 s0, s1;
       bf16x8 pb[4];
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+#if MRAG_ATTN_UPFRONT & 1
+      if constexpr (STG >= 0) qk_tile_imm8<STG>(ln, qf, r.negm, s0, s1, early_issue);
+#else
       if constexpr (STG >= 0) qk_tile_imm<STG>(ln, qf, r.negm, s0, s1, early_issue);
+#endif
       else
 #endif
       qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
@@ -784,7 +853,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 #else
       softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
+#if MRAG_ATTN_UPFRONT & 2
+      if constexpr (STG >= 0) pv_tile_imm16<STG>(ln, pb, r.o0, r.o1);
+#else
       if constexpr (STG >= 0) pv_tile_imm<STG>(ln, pb, r.o0, r.o1);
+#endif
       else
 #endif
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);

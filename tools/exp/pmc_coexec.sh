@@ -13,7 +13,7 @@ for c in sorted(glob.glob("gpurun_out/coexec/*")):
     vals = []
     for f in glob.glob(f"{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name and "attn_fwd_kernel<8, false, false, false>" in r["Kernel_Name"]:
+            if r["Counter_Name"] == name and "attn_fwd_kernel<8, false, false, false," in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
     print(f"{name:32s} {sum(vals)/max(1,len(vals)):.4g}  ({len(vals)} launches)")
 PY

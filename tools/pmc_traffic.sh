@@ -16,14 +16,17 @@ def collect(d, counter, kern):
     vals = []
     for f in glob.glob(f"gpurun_out/traffic/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and kern in r["Kernel_Name"] and "true>" not in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and kern in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
     return vals
-kern = "attn_fwd_kernel<8, false, false"
+kern = "attn_fwd_kernel<8, false, false, false,"      # long-sequence instantiation (not SHORTKV), with or without the key-split tail
 f, w = collect("f", "FETCH_SIZE", kern), collect("w", "WRITE_SIZE", kern)
-out = {"kernel": kern + ">", "shape": "B=2 H=48 S=17776 D=64", "launches": len(f),
-       "FETCH_SIZE_KiB_per_launch": sum(f) / len(f), "WRITE_SIZE_KiB_per_launch": sum(w) / len(w),
-       "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
+fc, wc = collect("f", "FETCH_SIZE", "attn_combine_kernel"), collect("w", "WRITE_SIZE", "attn_combine_kernel")   # the tail's merge kernel, one per launch
+avg = lambda v: sum(v) / len(v) if v else 0.0
+out = {"kernel": "attn_fwd_kernel<8,false,false,false,true> + attn_combine_kernel", "shape": "B=2 H=48 S=17776 D=64", "launches": len(f),
+       "FETCH_SIZE_KiB_per_launch": avg(f) + avg(fc), "WRITE_SIZE_KiB_per_launch": avg(w) + avg(wc),
+       "combine_kernel_KiB_per_launch": {"FETCH_SIZE": avg(fc), "WRITE_SIZE": avg(wc)},
+       "hbm_bytes_per_launch_corrected": (2 * (avg(f) + avg(fc)) + avg(w) + avg(wc)) * 1024,
        "algorithmic_bytes_per_launch": 4 * 2 * 17776 * 3072 * 2,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 wide-stream correction)"}
 json.dump(out, open(f"profiles/{tag}_attn_traffic.json", "w"), indent=1); json.dump(out, open(f"gpurun_out/traffic/{tag}_attn_traffic.json", "w"), indent=1)  # gpurun merges only gpurun_out/ back

@@ -215,6 +215,25 @@ def test_attention_key_split_tail(hip):
     for splits in ("", "3"):
         assert torch.equal(outs[splits][:, :Sq - 112], outs["0"][:, :Sq - 112])          # full tiles: same code path, bit-identical
         close(outs[splits][:, Sq - 112:], outs["0"][:, Sq - 112:].float().cpu(), scale=0.05, rtol=2e-2, atol_frac=4e-2)
+    # C ABI: the workspace is optional (none / too small -> the unsplit launch, same result as MRAG_ATTN_KV_SPLITS=0) and must be 16-byte aligned
+    import ctypes
+    need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)
+    ws = torch.empty(need + 64, dtype=torch.uint8, device=DEV)
+    for ws_ptr, ws_bytes, expect in ((None, 0, "0"), (ws.data_ptr(), need - 1, "0"), (ws.data_ptr(), need, ""), (ws.data_ptr() + 8, need, None)):
+        out = torch.empty(B, Sq, H * 64, dtype=torch.bfloat16, device=DEV)
+        a = _lib.AttnArgs()
+        a.Q, a.K, a.V, a.O = qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr()
+        a.q_sb, a.q_ss, a.q_sh = qd.stride(0), qd.stride(1), qd.stride(2)
+        a.k_sb, a.k_ss, a.k_sh = kd.stride(0), kd.stride(1), kd.stride(2)
+        a.v_sb, a.v_ss, a.v_sh = vd.stride(0), vd.stride(1), vd.stride(2)
+        a.o_sb, a.o_ss = out.stride(0), out.stride(1)
+        a.B, a.H, a.Sq, a.Skv, a.kv_batch_div, a.scale, a.out_scale = B, H, Sq, Skv, 1, 0.125, 1.0
+        a.workspace, a.workspace_bytes = ws_ptr, ws_bytes
+        rc = _lib.lib().mrag_attn_fwd_bf16(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(a))
+        if expect is None:
+            assert rc == _lib.MRAG_EINVAL
+        else:
+            assert rc == _lib.MRAG_OK and torch.equal(out, outs[expect])
 
 
 # ---------------------------------------------------------------------------------------------- norms

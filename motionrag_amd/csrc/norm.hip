@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   for (int c = 0; c < MAXC; ++c) {
     const long long idx = ((long long)c * 64 + lane) * 8;
     if (idx < p.D) {
-      unpack8(*(const u32x4*)(x + idx), v[c]);
+      unpack8(__builtin_nontemporal_load((const u32x4*)(x + idx)), v[c]);   // streamed once: nontemporal load / store, +6 % (115 vs 122 us at [35552, 3072])
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += v[c][e];
     } else {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
     }
-    *(u32x4*)(y + idx) = pack8(o);
+    __builtin_nontemporal_store(pack8(o), (u32x4*)(y + idx));
   }
 }
 

@@ -698,6 +698,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   const int last_start = skv - KVB;
   const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_k = [&](int stage, int t) {
+#ifdef MRAG_ATTN_EXP_HALF_DMA   // diagnostic builds only (wrong results): how much of the loop is the L2 -> LDS tile traffic?
+    if (t & 1) return;
+#endif
     if (last_start >= 0) {
       const int start = t * KVB < last_start ? t * KVB : last_start;
       const char* tile = (const char*)kbase + (long long)start * p.k_ss * 2;
@@ -714,6 +717,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     }
   };
   auto issue_v = [&](int stage, int t) {
+#ifdef MRAG_ATTN_EXP_HALF_DMA
+    if (t & 1) return;
+#endif
     if (last_start >= 0) {
       const int start = t * KVB < last_start ? t * KVB : last_start;
       const char* tile = (const char*)vbase + (long long)start * p.v_ss * 2;

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       f32x16 s0, s1;
       bf16x8 pb[4];
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
-#if MRAG_ATTN_UPFRONT & 1
+#if (MRAG_ATTN_UPFRONT & 1) && MRAG_ATTN_MFMA_MAX
       if constexpr (STG >= 0) qk_tile_imm8<STG>(ln, qf, r.negm, s0, s1, early_issue);
 #else
       if constexpr (STG >= 0) qk_tile_imm<STG>(ln, qf, r.negm, s0, s1, early_issue);
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 #else
       softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
 #if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
-#if MRAG_ATTN_UPFRONT & 2
+#if (MRAG_ATTN_UPFRONT & 2) && MRAG_ATTN_MFMA_MAX
       if constexpr (STG >= 0) pv_tile_imm16<STG>(ln, pb, r.o0, r.o1);
 #else
       if constexpr (STG >= 0) pv_tile_imm<STG>(ln, pb, r.o0, r.o1);

@@ -236,6 +236,24 @@ def test_attention_key_split_tail(hip):
             assert rc == _lib.MRAG_OK and torch.equal(out, outs[expect])
 
 
+def test_attention_baseline_shape_split_tail_properties(hip):
+    """the BASELINE launch itself (B = 2, H = 48, S = 17 776: 6 624 full query tiles + 96 ragged ones run as 480 key-chunk workgroups + merge):
+    softmax rows sum to one everywhere (V = ones -> exactly 1), and the ragged tiles' rows of a few heads equal the fp32 reference"""
+    from motionrag_amd import ops, _lib
+    g = torch.Generator().manual_seed(10)
+    B, H, S = 2, 48, 17776
+    assert _lib.lib().mrag_attn_workspace_bytes(B, H, S, S) > 0
+    q, k, v = (bf(torch.randn(B, S, H, 64, generator=g)) for _ in range(3))
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ones = ops.attention(qd, kd, torch.ones_like(vd))
+    assert (ones.float() - 1.0).abs().max().item() < 1e-2
+    out = ops.attention(qd, kd, vd)
+    rows = torch.cat([torch.arange(S - 112, S), torch.randint(0, S - 112, (16,), generator=g)])
+    for h in (0, 23, 47):
+        want = sdpa_ref(q[:, rows, h:h + 1], k[:, :, h:h + 1], v[:, :, h:h + 1])
+        close(out[:, rows.to(DEV), h * 64:(h + 1) * 64], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
+
+
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104)])
 def test_layernorm(hip, rows, D):

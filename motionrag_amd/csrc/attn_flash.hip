@@ -1167,8 +1167,11 @@ struct IpFoldP {
   float qscale, out_scale;
 };
 
+#ifndef MRAG_IPFOLD_HG
+#define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
+#endif
 __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
-  constexpr int HG = 16;                                   // heads per block
+  constexpr int HG = MRAG_IPFOLD_HG;                       // heads per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* vt = (bf16_t*)smem;                               // [HG][64 d][32 keys]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1254,13 +1257,14 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
   p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;
   p.rows = (long long)B * S; p.s_ld = scores_ld; p.o_ld = hidden_ld; p.v_bs = v_batch_stride; p.v_ks = v_key_stride; p.rows_per_batch = S;
   p.H = H; p.keys = keys; p.kv_div = kv_batch_div; p.qscale = scale * 1.4426950408889634f; p.out_scale = out_scale;
-  const size_t lds = 16 * 64 * 32 * sizeof(bf16_t);
+  constexpr int HG = MRAG_IPFOLD_HG;
+  const size_t lds = HG * 64 * 32 * sizeof(bf16_t);
   const long long groups = ((long long)kv_batch_div * S + 63) / 64;
-  const long long per = 512 / (((H + 15) / 16) * (long long)(B / kv_batch_div));       // about two workgroups per CU: each one pays a V^T fill
+  const long long per = (256 * (128 * 1024 / (long long)lds)) / (((H + HG - 1) / HG) * (long long)(B / kv_batch_div));   // as many workgroups as fit the CUs' LDS: each one pays a V^T fill
   const unsigned gx = (unsigned)(groups < (per > 1 ? per : 1) ? groups : (per > 1 ? per : 1));
   hipError_t e = hipFuncSetAttribute((const void*)ip_attn_folded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + 15) / 16), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);
+  MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + HG - 1) / HG), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -63,6 +63,15 @@ struct GemmP {
 // zero source for the taps that fall outside the image / clip (never written)
 __device__ __attribute__((aligned(128))) bf16_t g_zero_row[64];
 
+// sum over the 8 lanes that hold one row (lanes 8g..8g+7) on the vector pipe: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+// (lane i <-> 7 - i of its half row).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip each, six dependent ones per row group.
+__device__ __forceinline__ float sum8_dpp(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+  return x;
+}
+
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
   if constexpr (EPI == MRAG_EPI_GELU_TANH) return gelu_tanh_f(v);
@@ -450,12 +459,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += v[e];
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+            sum = sum8_dpp(sum);
             const float mean = sum * (1.0f / 64.0f);
             float sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
-            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+            sq = sum8_dpp(sq);
             const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.qk_eps);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e];

@@ -129,11 +129,16 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
                 kv0 = ops.linear(ip, wkv)                                         # :251-252 (one GEMM)
                 Bp, nk = ip.size(0), ip.size(1)
                 wq_t = proc.to_q_ip[0].weight.detach().t().contiguous()           # [D_in, D_out]: the contraction index (h, d) must be contiguous
-                M = torch.zeros(Bp, H * 32, D, dtype=torch.bfloat16, device=ip.device)
-                k4 = kv0[..., :D].unflatten(-1, (H, 64))
+                # all heads in ONE GEMM per sample: the keys as a block-diagonal [32 H, D] operand (head h's keys in rows 32 h.., columns
+                # 64 h..; zeros elsewhere add exact zeros to the fp32 accumulators, so every M_h is what its own [nk, 64] x [64, D] product
+                # gives) -- 48x the flops of the per-head products, 2.5 ms per clip on the DiT, instead of 96 launches per layer
+                k4 = kv0[..., :D].unflatten(-1, (H, 64))                          # [B', nk, H, 64]
+                A = torch.zeros(Bp, H, 32, H, 64, dtype=torch.bfloat16, device=ip.device)
+                hidx = torch.arange(H, device=ip.device)
+                A[:, hidx, :nk, hidx] = k4.permute(2, 0, 1, 3)                    # advanced indices split by a slice come first: [H, B', nk, 64]
+                M = torch.empty(Bp, H * 32, D, dtype=torch.bfloat16, device=ip.device)
                 for bp in range(Bp):
-                    for h in range(H):
-                        ops.linear(k4[bp, :, h], wq_t[:, h * 64:(h + 1) * 64], out=M[bp, h * 32:h * 32 + nk])
+                    ops.linear(A[bp].view(H * 32, D), wq_t, out=M[bp])
                 return M, kv0[..., D:]
             # cache hit only for the SAME tensor object at the same version: the entry keeps a reference to `ip`, so its address cannot be
             # recycled for another clip's tokens while the entry lives (a data_ptr key alone would go stale silently)

@@ -157,23 +157,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 
   // DMA source of piece i for K-tile kt.  Plain GEMM: the row pointer advanced by kt * 64.  Convolutions: K-tile kt is channel
   // block (kt % ctiles) of tap (kt / ctiles); the lane's row is the tap-shifted pixel (or frame), or the zero row outside.
+  // The K-tiles are requested in order (0, 1, 2, ...), so the (tap, channel block) pair is WALKED: per K-tile a piece costs one pointer
+  // increment, and the tap geometry (bounds test, pixel offset, 64-bit multiply) is redone only when the tap changes -- every Cin / 64
+  // K-tiles -- instead of a division by ctiles plus the whole address computation per piece and K-tile.
+  const bf16_t* cv_src[CONV != 0 ? APW : 1];   // per A piece: this lane's source at the current (tap, channel block)
+  int cv_step[CONV != 0 ? APW : 1];            // 64 elements per channel block inside the image, 0 on the zero row
+  int cv_kt = -1, cv_tap = 0, cv_cblk = -1;
+  auto cv_prepare = [&](int kt) {
+    if constexpr (CONV != 0) {
+      if (kt == cv_kt) return;
+      cv_kt = kt;
+      bool new_tap = kt == 0;
+      if (++cv_cblk == p.cv_ctiles) { cv_cblk = 0; ++cv_tap; new_tap = true; }
+      if (new_tap) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+          bool ok;
+          long long off;
+          if constexpr (CONV == 1) {
+            const int ky = cv_tap / 3, kx = cv_tap - 3 * ky;
+            const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
+            ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
+            off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C;
+          } else {
+            const int t = cv_y[i] + cv_tap - 1;
+            ok = (unsigned)t < (unsigned)p.cv_T;
+            off = (long long)(cv_tap - 1) * p.cv_HW * p.cv_C;
+          }
+          cv_src[i] = ok ? gsrc[i] + off : g_zero_row + (lane & 7) * 8;
+          cv_step[i] = ok ? 64 : 0;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) cv_src[i] += cv_step[i];
+      }
+    }
+  };
   auto src = [&](int i, int kt) -> const bf16_t* {
     if constexpr (CONV == 0) {
       return gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP;
     } else {
       if (i >= APW) return gsrc[i] + (long long)kt * BK;       // weight rows [Cout, taps * Cin] are plain
-      const int tap = kt / p.cv_ctiles, c0 = (kt - tap * p.cv_ctiles) * 64;
-      if constexpr (CONV == 1) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
-        const bool ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
-        const long long off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C + c0;
-        return ok ? gsrc[i] + off : g_zero_row + (lane & 7) * 8;
-      } else {
-        const int t = cv_y[i] + tap - 1;
-        const bool ok = (unsigned)t < (unsigned)p.cv_T;
-        return ok ? gsrc[i] + (long long)(tap - 1) * p.cv_HW * p.cv_C + c0 : g_zero_row + (lane & 7) * 8;
-      }
+      cv_prepare(kt);
+      return cv_src[i];
     }
   };
   auto issue = [&](int stage, int kt) {

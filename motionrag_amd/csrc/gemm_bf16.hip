@@ -198,12 +198,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       return gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP;
     } else {
       if (i >= APW) return gsrc[i] + (long long)kt * BK;       // weight rows [Cout, taps * Cin] are plain
-      cv_prepare(kt);
-      return cv_src[i];
+      return cv_src[i];                                        // cv_prepare(kt) ran once for this K-tile (issue / the pipelined loop)
     }
   };
   auto issue = [&](int stage, int kt) {
     char* base = smem + stage * STAGE_BYTES;
+    cv_prepare(kt);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NW;
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         const unsigned sn = smem_u + ((kt + 1) & 1) * STAGE_BYTES;
         MRAG_READ12(w0, a0, sn + offW + c0, sn + offA + c0);
       }
+      if (more2) cv_prepare(kt + 2);
       MRAG_PIECE(0);
       MRAG_ROW(1, w1, a1[1]); MRAG_PIECE(1);
       MRAG_ROW(2, w1, a1[2]); MRAG_PIECE(2);

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   };
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n0 + (lane >> 4) * 4 + {0..3}
   constexpr bool STAGED = (TM == 8 && TN == 4 && WM == 2 && WN == 4);
-  if (STAGED && p.staged) {
+  if (STAGED && p.staged && EPI != MRAG_EPI_GEGLU) {   // GEGLU has its own staged form below ([M, N/2] output)
     // The accumulator layout gives 8-byte pieces of 16 different rows per store instruction (32-byte row segments): the store
     // tail was ~24 % of a K = 3072 workgroup.  Stage the wave's 128 x 64 bf16 tile through LDS (row pitch 144 B) and write
     // whole 128-byte row segments with 16-byte lanes; bias / activation / gate are applied in the accumulator layout, the
@@ -572,6 +572,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
     // W rows arrive interleaved in 16-row groups: [value 16m..16m+15 | gate 16m..16m+15], so the even 16-column MFMA tile
     // holds the values and the odd one the gates of the SAME 16 outputs in the same lanes: C[m, j] = v * gelu_erf(g),
     // C is [M, N/2].  Removes the [M, N] round trip and the separate GEGLU pass (6 % of an SVD / DynamiCrafter step).
+    if constexpr (TM == 8 && TN == 4 && WM == 2 && WN == 4) {
+      if (p.staged) {
+        // LDS-staged form (as above): the wave's 128 x 32 outputs go through LDS (row pitch 80 B) and leave as 64-byte row segments with
+        // 16-byte lanes instead of 8-byte pieces of 16 rows per store.  The UNets' GEGLU projections have K = 320 ... 1280, i.e. 5-20
+        // K-tiles per workgroup, so the store tail is most of a workgroup's life there.
+        constexpr int ROWB = 80;
+        char* wbase = smem + wave * (128 * ROWB);
+        __syncthreads();   // every wave is done with the operand stages that these per-wave regions overlay
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; j += 2) {
+            long long n = bn0 + wn * TN * 16 + j * 16 + frag_q * 4;   // value columns; gates at n + 16
+            n = n + 20 <= p.N ? n : p.N - 20;                          // clamped columns are never stored
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float g[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+            if (p.bias) {
+              const u32x2 bv = *(const u32x2*)(p.bias + n), bg = *(const u32x2*)(p.bias + n + 16);
+              v[0] += __uint_as_float(bv[0] << 16); v[1] += __uint_as_float(bv[0] & 0xffff0000u);
+              v[2] += __uint_as_float(bv[1] << 16); v[3] += __uint_as_float(bv[1] & 0xffff0000u);
+              g[0] += __uint_as_float(bg[0] << 16); g[1] += __uint_as_float(bg[0] & 0xffff0000u);
+              g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+            u32x2 out;
+            out[0] = pack_bf2(v[0], v[1]);
+            out[1] = pack_bf2(v[2], v[3]);
+            *(u32x2*)(wbase + (i * 16 + frag_row) * ROWB + ((j >> 1) * 16 + frag_q * 4) * 2) = out;
+          }
+        }
+        // row layout: lane -> row (lane >> 2) of a 16-row group, 16-byte chunk (lane & 3): one instruction = 16 x 64 contiguous bytes
+        const int rs = lane >> 2, ch = lane & 3;
+        const long long no = ((bn0 + wn * TN * 16) >> 1) + ch * 8;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+          const int row = g8 * 16 + rs;
+          const long long m = bm0 + wm * TM * 16 + row;
+          const u32x4 val = *(const u32x4*)(wbase + row * ROWB + ch * 16);
+          if (m < p.M && 2 * (no + 8) <= p.N) *(u32x4*)(p.C + m * p.ldc + no) = val;
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
@@ -659,7 +703,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
-  if (getenv("MRAG_GEMM_NO_STAGED") || epi == MRAG_EPI_GEGLU) p.staged = 0;   // tuning knob; GEGLU writes [M, N/2] from the accumulator layout
+  if (getenv("MRAG_GEMM_NO_STAGED") || (epi == MRAG_EPI_GEGLU && (p.N % 32 != 0 || getenv("MRAG_GEGLU_NO_STAGED")))) p.staged = 0;   // tuning knobs
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;

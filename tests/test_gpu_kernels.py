@@ -403,7 +403,7 @@ def test_topk_baseline_size(hip):
     assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
 
 
-@pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128)])
+@pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128), (30001, 272, 192)])
 def test_gemm_geglu_epilogue(hip, M, inner, K):
     """C = v * gelu_erf(g) with [v | g] = x W^T + b (lvdm attention.py:448-455 / diffusers GEGLU), both tile configurations"""
     from motionrag_amd import ops

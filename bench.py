@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
-    ap.add_argument("--secondary", action="store_true", help="also measure the other BASELINE configs after the timed region (SVD / DynamiCrafter UNet step, retrieval; N = 1 only, ~20 s); "
-                    "off by default so that a rocprofv3 summary of the default command holds only the headline workload's launches")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (SVD / DynamiCrafter UNet CFG step, retrieval, CAMA), which are measured "
+                    "after the timed region at N = 1 (~30 s) and reported under `secondary_workloads`; for profiling runs that should hold only the headline launches")
     ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
                     help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
                          "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
@@ -102,9 +102,26 @@ def cpu_baseline_sample():
     return dt, flops_sample, f"1/42 layers x 1/2 CFG samples x 3/13 latent frames (S={St}), fp32 oracle, extrapolated by FLOPs"
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD process (this process has
+    not touched the GPU and never does) and exit with its status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; launch with --nproc-per-node {args.gpus}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
@@ -193,7 +210,7 @@ def main():
 
     # the other BASELINE.json configs, measured after the timed region and reported beside the headline (N = 1 only; ~20 s)
     secondary = None
-    if world == 1 and args.secondary:
+    if world == 1 and not args.no_secondary:
         import contextlib
         import importlib.util
         import io

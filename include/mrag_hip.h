@@ -15,7 +15,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream);
  *   - all pointers are device pointers unless the name ends in _host;
  *   - bf16 tensors are raw uint16 bit patterns; fp32 accumulate everywhere;
- *   - no hidden allocation, no global mutable state: workspaces are passed in;
+ *   - no hidden allocation, no global mutable state, no environment reads:
+ *     workspaces are passed in, developer tuning knobs are explicit `tuning`
+ *     fields of the argument structs (0 = the shipped behaviour);
  *   - row-major, innermost dimension contiguous; ld* / stride* are in ELEMENTS.
  */
 #ifndef MRAG_HIP_H
@@ -87,7 +89,10 @@ typedef struct mrag_gemm_args {
   const float* rope_sin;
   int64_t qk_dmodel;                         /* D = H * 64 */
   float qk_eps, q_premul;
+  int32_t tuning;     /* developer knobs (tools/microbench.py), 0 = shipped: MRAG_GEMM_TUNE_* bits, bits 4-7 tile choice
+                         (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
 } mrag_gemm_args;
+enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4 };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 
@@ -125,7 +130,13 @@ typedef struct mrag_attn_args {
   int64_t workspace_bytes; /* >= mrag_attn_workspace_bytes(B, H, Sq, Skv) enables
                               the key-split tail of long sequences (same
                               result up to fp32 summation order)              */
+  int32_t tuning;          /* developer knobs (tools/microbench.py), 0 = shipped:
+                              MRAG_ATTN_TUNE_* bits                            */
 } mrag_attn_args;
+enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pair kernel          */
+       MRAG_ATTN_TUNE_PIPE = 2,      /* intra-wave software-pipelined variant (measured slower)    */
+       MRAG_ATTN_TUNE_NW4 = 4,       /* 4-wave workgroups for long sequences                       */
+       MRAG_ATTN_TUNE_LEGACY = 8 };  /* long unmasked sequences through the 32x32x16 kernel        */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
@@ -225,6 +236,11 @@ int mrag_axpby_bf16(void* stream, const void* x, const void* y, void* out, int64
  * v_pred [2, n] bf16 (uncond first), latents [n] bf16 in place, guidance [F] fp32 on the device.                   */
 int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n, const float* guidance, int32_t F,
                              int64_t frame_elems, float c_x, float c_v);
+/* condition_fusion 'mean' / 'weight' over the k retrieved references (src/projects/condition/utils.py:21-27; stage-1
+ * pipelines cogvideox/pipeline.py:71-72, svd/pipelines/pipeline.py:103-104, DynamiCrafter inference.py:213-218):
+ *   out[b, n] = (sum_k w[b, k] * x[b, k, n]) / div      fp32 weights / accumulation in k order, one rounding to bf16
+ * x [B, K, n] bf16, w [B, K] fp32 on the device or NULL (all ones: mean = sum / K with div = K), n % 8 == 0.            */
+int mrag_weighted_sum_bf16(void* stream, const void* x, const float* w, void* out, int32_t B, int32_t K, int64_t n, float div);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,
@@ -244,8 +260,12 @@ int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* latents, int
 /* tools/build_rag_database.py:51-52).                                        */
 /*   dist(q, r) = sum_d (q_d - x_rd)^2            (metric 0, "l2")            */
 /*              = 1 - sum_d q_d x_rd              (metric 1, "dot")           */
-/* accumulated as ONE fp32 fmaf chain over d = 0..D-1 (bit-reproducible, same */
-/* chain as oracle/topk_oracle.c).  Rows with group[r] == exclude[q] are      */
+/* accumulated in fp32 as 16 interleaved fmaf chains (chain c takes the 4-wide */
+/* feature groups g with g % 16 == c, in order) folded by a fixed butterfly    */
+/* (c ^ 8, 4, 2, 1): bit-reproducible, the "f32chain" mode of                   */
+/* oracle/topk_oracle.c; ranks equal the float64 oracle's whenever neighbouring */
+/* distances differ by more than the fp32 rounding of the sum (tests assert the */
+/* gap).  Rows with group[r] == exclude[q] are                                  */
 /* skipped (the `video != "<self>"` filter, src/data/datamodule.py:235).      */
 /* Output sorted by (dist asc, row asc); missing entries are row = -1.        */
 /* ------------------------------------------------------------------------ */

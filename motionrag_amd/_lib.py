@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "norm.hip", "pointwise.hip", "topk.hip", "unet_ops.hip"]
-ABI_VERSION = 1
+ABI_VERSION = 2
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else [])}
 
@@ -27,8 +27,12 @@ SYMBOLS = [
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
-    "mrag_ddim_v_step_f32",
+    "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16",
 ]
+
+
+# entry points whose result is not the int32 status code (their restype is set explicitly in lib())
+_NON_INT_RESULT = ("mrag_target_arch", "mrag_attn_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes")
 
 
 class HipLibraryMissing(RuntimeError):
@@ -44,7 +48,7 @@ class GemmArgs(Structure):
         ("rows_per_batch", c_int64), ("split", c_int64), ("gate_stride", c_int64),
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
-        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float),
+        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("tuning", c_int32),
     ]
 
 
@@ -57,7 +61,7 @@ class AttnArgs(Structure):
         ("o_sb", c_int64), ("o_ss", c_int64),
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Skv", c_int32), ("kv_batch_div", c_int32),
         ("scale", c_float), ("out_scale", c_float), ("q_prescaled", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64), ("tuning", c_int32),
     ]
 
 
@@ -178,10 +182,11 @@ def lib() -> ctypes.CDLL:
     L.mrag_im2col3x3_bf16.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int32] * 7
     L.mrag_unfold_t3_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32]
     L.mrag_geglu_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64]
+    L.mrag_weighted_sum_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_float]
     L.mrag_ddim_v_step_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 7
-    for name in SYMBOLS:
+    for name in SYMBOLS:          # everything that did not declare a 64-bit / pointer result above returns an int status
         fn = getattr(L, name)
-        if name not in ("mrag_target_arch", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes"):
+        if name not in _NON_INT_RESULT:
             fn.restype = c_int32
     _lib = L
     return L

@@ -183,8 +183,9 @@ class TransformerEncoder(nn.Module):
 
 
 def condition_fusion(condition_emb: torch.Tensor, fusion_type: str = "mean", weight: Optional[Iterable] = None) -> torch.Tensor:
-    """condition/utils.py:7-36.  'concat' and 'top1' are views; 'mean'/'weight' are one small GEMM with the
-    per-sample weight row (k <= 16 references), run on the HIP GEMM."""
+    """condition/utils.py:7-36.  'concat' and 'top1' are views; 'mean' = sum / k and 'weight' = sum_k w_k x_k with
+    w = (1 - d) / sum(1 - d) run on `mrag_weighted_sum_bf16` (fp32 weights, fp32 accumulation, one rounding).  The result is bf16
+    (the reference's 'weight' branch promotes to fp32 through its fp32 weight tensor; its consumers cast back to the model dtype)."""
     assert fusion_type in ["mean", "concat", "top1", "weight"]
     assert condition_emb.dim() == 4
     b, k, l, c = condition_emb.shape
@@ -192,21 +193,14 @@ def condition_fusion(condition_emb: torch.Tensor, fusion_type: str = "mean", wei
         return condition_emb.reshape(b, k * l, c)
     if fusion_type == "top1":
         return condition_emb[:, 0]
+    x = _bf16(condition_emb).contiguous()
     if fusion_type == "mean":
-        w = torch.full((b, k), 1.0 / k, dtype=torch.float32)
-    else:
-        d = torch.as_tensor(weight, dtype=torch.float32)
-        w = (1 - d) / (1 - d).sum(dim=1, keepdim=True)
-    # out[b, (l c)] = sum_k w[b, k] emb[b, k, (l c)]  == emb_b^T [l*c, k] . w_b [1, k]^T ; K padded to 64
-    x = _bf16(condition_emb)
-    out = torch.empty(b, l, c, dtype=torch.bfloat16, device=x.device)
-    for i in range(b):
-        a = torch.zeros(l * c, 64, dtype=torch.bfloat16, device=x.device)
-        a[:, :k] = x[i].reshape(k, l * c).t()
-        wrow = torch.zeros(8, 64, dtype=torch.bfloat16, device=x.device)
-        wrow[0, :k] = w[i].to(torch.bfloat16)
-        out[i] = ops.linear(a, wrow)[:, 0].view(l, c)
-    return out
+        return ops.weighted_sum(x, None, div=float(k))
+    d = torch.as_tensor(weight, dtype=torch.float32).to(x.device)
+    if tuple(d.shape) != (b, k):
+        raise ValueError(f"condition_fusion: weight must be [b, k] = {(b, k)}, got {tuple(d.shape)}")
+    w = ((1 - d) / (1 - d).sum(dim=1, keepdim=True)).contiguous()        # [b, k] fp32 -- 9 numbers per clip, as utils.py:26-27
+    return ops.weighted_sum(x, w)
 
 
 class ActionTransformer(nn.Module):

@@ -28,7 +28,6 @@
 #include "common.h"
 #include <type_traits>
 #include "../../include/mrag_hip.h"
-#include <stdlib.h>
 
 #ifdef MRAG_ATTN_STAMPS
 // diagnostic build only (tools/build_diag.sh): per-phase s_memtime sums of the long-sequence loop; never compiled into the product
@@ -1019,7 +1018,6 @@ SplitPlan plan_kv_split(int B, int H, int Sq, int Skv) {
   const long long nbh = (long long)B * H;
   int want = (int)(512 / nbh);
   if (want > 8) want = 8;
-  if (const char* e = getenv("MRAG_ATTN_KV_SPLITS")) want = atoi(e);   // tuning knob; 0 / 1 = never split
   if (rem == 0 || nbh * n_full < 1024 || want < 2 || nt < 8 * want) return pl;
   const int tpc = (nt + want - 1) / want;
   const int chunk = tpc * KVB, splits = (Skv + chunk - 1) / chunk;
@@ -1278,6 +1276,8 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   if ((a->q_sb | a->q_ss | a->q_sh | a->k_sb | a->k_ss | a->k_sh | a->v_sb | a->v_ss | a->v_sh) % 8 != 0) return MRAG_EINVAL;
   if (((uintptr_t)a->O & 7) || (a->o_sb | a->o_ss) % 4 != 0) return MRAG_EINVAL;
   if (a->resid && ((uintptr_t)a->resid & 7)) return MRAG_EINVAL;
+  // the scalar-base LDS-DMA path folds a tile's per-lane K / V offsets (up to 63 rows) into 32-bit unsigned byte offsets
+  if (a->k_ss < 0 || a->v_ss < 0 || a->k_ss > 0x1ffffff || a->v_ss > 0x1ffffff) return MRAG_ENOTSUP;
   AttnP p{};
   p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.V = (const bf16_t*)a->V;
   p.O = (bf16_t*)a->O; p.resid = (const bf16_t*)a->resid; p.mask = a->mask;
@@ -1291,7 +1291,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   hipStream_t s = (hipStream_t)stream;
   // The intra-wave software-pipelined variant (PIPE) measures SLOWER than the staggered-barrier loop on MI355X with
   // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
-  if (a->Sq <= 16 && a->Skv <= 16 && !a->mask && !a->resid && !getenv("MRAG_ATTN_NO_TINY")) {   // temporal attention of the UNets
+  if (a->Sq <= 16 && a->Skv <= 16 && !a->mask && !a->resid && !(a->tuning & MRAG_ATTN_TUNE_NO_TINY)) {   // temporal attention of the UNets
     const long long pairs = (long long)a->B * a->H;
     long long blocks = (pairs + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -1299,11 +1299,9 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     MRAG_LAUNCH_CHECK();
     return MRAG_OK;
   }
-  bool pipe = false;
-  if (const char* e = getenv("MRAG_ATTN_PIPE")) pipe = e[0] == '1';
+  const bool pipe = (a->tuning & MRAG_ATTN_TUNE_PIPE) != 0;
   if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);
-  int nw_big = 8;
-  if (const char* e = getenv("MRAG_ATTN_NW")) nw_big = atoi(e);   // tuning knob (tools/microbench.py)
+  const int nw_big = (a->tuning & MRAG_ATTN_TUNE_NW4) ? 4 : 8;
   if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
   if (a->Sq > 128 && !pipe && !a->mask && a->workspace) {   // key-split tail for the ragged last query tile (plan_kv_split)
     if (((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;

@@ -14,7 +14,6 @@
 //   * 1-D grid with a bijective XCD remap so tiles that share an A row-panel sit on one L2.
 #include "common.h"
 #include "../../include/mrag_hip.h"
-#include <stdlib.h>
 
 #ifdef MRAG_GEMM_STAMPS
 // diagnostic build only (tools/build_diag.sh): per-phase s_memtime sums of the 256x256 main loop; never compiled into the product
@@ -51,7 +50,7 @@ struct GemmP {
   const bf16_t* A; const bf16_t* W; const bf16_t* bias; bf16_t* C; const bf16_t* resid;
   const bf16_t* gate0; const bf16_t* gate1;
   long long M, N, K, lda, ldw, ldc, ldr, rows_per_batch, split, gate_stride;
-  int tiles_m, tiles_n, group_m, staged;
+  int tiles_m, tiles_n, group_m, staged, tuning;
   // MRAG_EPI_QKNORM_ROPE
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
   long long qk_D; int rope_text_len; float qk_eps, q_premul;
@@ -686,8 +685,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 }
 
 // UNet widths are multiples of 320: N = 320 / 640 / 960 wastes 38 / 17 / 6 % of a 256-wide tile grid, nothing of a 320-wide one
-inline bool wide_n_pays(long long N) {
-  if (getenv("MRAG_GEMM_NO_WIDE")) return false;   // tuning knob
+inline bool wide_n_pays(long long N, int tuning = 0) {
+  if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
   const long long w256 = (N + 255) / 256 * 256, w320 = (N + 319) / 320 * 320;
   return w320 * 100 < w256 * 90;                   // at least 10 % fewer padded columns
 }
@@ -698,12 +697,11 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   GemmP p = p0;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
-  p.group_m = 4;
-  if (const char* e = getenv("MRAG_GEMM_GROUP_M")) p.group_m = atoi(e) > 0 ? atoi(e) : 4;   // tuning knob
+  p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
-  if (getenv("MRAG_GEMM_NO_STAGED") || (epi == MRAG_EPI_GEGLU && (p.N % 32 != 0 || getenv("MRAG_GEGLU_NO_STAGED")))) p.staged = 0;   // tuning knobs
+  if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || (epi == MRAG_EPI_GEGLU && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
@@ -771,11 +769,12 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // big problems: 256x256 tiles, 8 waves (1 workgroup per CU); small ones: 128x128, 4 waves,
   // so that a few hundred rows still spread over the 256 CUs.
   const long long t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-  if (const char* e = getenv("MRAG_GEMM_CFG")) {   // tuning knob (tools/microbench.py)
-    if (e[0] == '1' && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
-    if (e[0] == '2') return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);                  // 128x128, 4 waves, 2 workgroups per CU
+  p.tuning = a->tuning;
+  if (const int cfg = (a->tuning >> 4) & 0xf) {   // developer knob (tools/microbench.py); 0 = the shipped choice below
+    if (cfg == 1 && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
+    if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);                  // 128x128, 4 waves, 2 workgroups per CU
   }
-  if (t256 >= 192 && wide_n_pays(a->N) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, a->epilogue);   // 256x320 tile
+  if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, a->epilogue);   // 256x320 tile
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);
 }

@@ -195,6 +195,25 @@ __global__ void cfg_euler_kernel(const bf16_t* vp, bf16_t* x, long long n8, long
   }
 }
 
+// condition_fusion 'mean' / 'weight' (src/projects/condition/utils.py:21-27): out[b, n] = (sum_k w[b, k] x[b, k, n]) / div, fp32 weights and
+// accumulation in k order, ONE rounding to bf16 (the weights are never rounded to bf16: 1/9 in bf16 would bias the mean by 0.2 %).
+__global__ void weighted_sum_kernel(const bf16_t* x, const float* w, bf16_t* out, int K, long long n8, float div) {
+  const int b = blockIdx.y;
+  const bf16_t* xb = x + (long long)b * K * n8 * 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      float v[8]; unpack8(*(const u32x4*)(xb + ((long long)k * n8 + i) * 8), v);
+      const float wk = w ? w[(long long)b * K + k] : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(wk, v[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] / div;
+    *(u32x4*)(out + ((long long)b * n8 + i) * 8) = pack8(acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
@@ -282,6 +301,15 @@ extern "C" int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* 
   if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
   MRAG_LAUNCH(cfg_euler_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents, (long long)(n / 8),
               (long long)n, guidance, (int)F, (long long)frame_elems, c_x, c_v);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_weighted_sum_bf16(void* stream, const void* x, const float* w, void* out, int32_t B, int32_t K, int64_t n, float div) {
+  if (!x || !out || B <= 0 || K <= 0 || n <= 0 || n % 8 != 0 || div == 0.f) return MRAG_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return MRAG_EINVAL;
+  const dim3 grid(grid_for(n / 8), (unsigned)B);
+  MRAG_LAUNCH(weighted_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)out, K, n / 8, div);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

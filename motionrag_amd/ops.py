@@ -7,7 +7,6 @@ int32 where stated) on a ROCm device, otherwise `HipOnly` is raised.
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Optional
 
 import torch
@@ -17,6 +16,13 @@ from ._lib import AttnArgs, GemmArgs, LnArgs, QkNormRopeArgs, check
 
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID, EPI_GATE_RESID, EPI_SILU, EPI_GEGLU, EPI_QKNORM_ROPE = range(8)
 LOG2E = 1.4426950408889634
+
+
+# Developer tuning knobs (tools/microbench.py, A/B tests): explicit `tuning` fields of the C-ABI argument structs, 0 = the shipped behaviour.
+# Nothing on the launch path reads the environment.
+TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
+GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
+ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY = 1, 2, 4, 8
 
 
 class HipOnly(RuntimeError):
@@ -69,6 +75,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     a.M, a.N, a.K = M, N, K
     a.lda, a.ldw, a.ldc = x2.stride(0), weight.stride(0), o2.stride(0)
     a.epilogue = epilogue
+    a.tuning = TUNING["gemm"]
     if resid is not None:
         r2 = _rows(_dev(resid, name="resid"))
         a.resid, a.ldr = _p(r2), r2.stride(0)
@@ -163,7 +170,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
     a.scale = (64 ** -0.5) if scale is None else scale
     a.out_scale = out_scale
     a.q_prescaled = 1 if q_prescaled else 0
-    if mask is None:
+    a.tuning = TUNING["attn"]
+    if mask is None and not TUNING["attn_no_split"]:
         need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)   # > 0: long sequence with a ragged last query tile (key-split tail)
         if need > 0:
             ws = _attn_workspace(q.device, need)
@@ -251,7 +259,8 @@ def qkv_linear_qknorm_rope(x: torch.Tensor, weight: torch.Tensor, bias: Optional
         if tuple(cos.shape) != (S - text_len, 64) or not cos.is_contiguous() or not sin.is_contiguous():
             raise ValueError("cos/sin must be contiguous [S - text_len, 64] fp32")
         a.rope_cos, a.rope_sin = _p(cos), _p(sin)
-    rc = _lib.MRAG_ENOTSUP if os.environ.get("MRAG_NO_QKV_FUSE") else _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))   # env: A/B knob
+    a.tuning = TUNING["gemm"]
+    rc = _lib.MRAG_ENOTSUP if TUNING["no_qkv_fuse"] else _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))
     if rc == _lib.MRAG_ENOTSUP:                                   # small problem / unaligned output: plain GEMM, then the norm + RoPE pass
         linear(x, weight, bias, out=out)
         return qknorm_rope_(out, H, q_gamma, q_beta, k_gamma, k_beta, cos, sin, text_len, eps=eps, q_premul=q_premul)
@@ -331,6 +340,24 @@ def cfg_euler_step_(v_pred: torch.Tensor, latents: torch.Tensor, guidance: torch
     check(_lib.lib().mrag_cfg_euler_step_bf16(_stream(), _p(v_pred), _p(latents), latents.numel(), _p(guidance.contiguous()), F, fe, float(c_x), float(c_v)),
           "mrag_cfg_euler_step_bf16")
     return latents
+
+
+def weighted_sum(x: torch.Tensor, w: Optional[torch.Tensor], div: float = 1.0) -> torch.Tensor:
+    """out[b, ...] = (sum_k w[b, k] x[b, k, ...]) / div with fp32 weights [B, K] (None = ones); x [B, K, ...] bf16 contiguous."""
+    _dev(x, name="x")
+    if x.dim() < 3 or not x.is_contiguous():
+        raise ValueError("weighted_sum: contiguous [B, K, ...] required")
+    B, K = x.shape[:2]
+    n = x[0, 0].numel()
+    if n % 8:
+        raise ValueError("weighted_sum: the fused trailing dims must be a multiple of 8 elements")
+    if w is not None:
+        _dev(w, torch.float32, "w")
+        if tuple(w.shape) != (B, K) or not w.is_contiguous():
+            raise ValueError("weighted_sum: w must be a contiguous fp32 [B, K]")
+    out = torch.empty(B, *x.shape[2:], dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mrag_weighted_sum_bf16(_stream(), _p(x), _p(w), _p(out), B, K, n, float(div)), "mrag_weighted_sum_bf16")
+    return out
 
 
 def patchify(src0: torch.Tensor, src1: Optional[torch.Tensor], B: int) -> torch.Tensor:

@@ -76,6 +76,31 @@ def test_cama_predict_against_reference_golden(hip, golden_dir):
     close_exactish(ev[:, 0], out[:2], rtol=1e-6, atol_frac=1e-6)                      # uncond half == encode_vision(zeros)[:, 0]
 
 
+def test_condition_fusion_against_reference_golden(hip, golden_dir):
+    """condition_fusion (condition/utils.py:7-36), all four modes on the GPU: vs the REFERENCE's outputs (golden G4, fp32 inputs rounded to
+    bf16 -> one bf16 ulp of the input + one of the output) and, at the shipped size [b, 9, 25, 1024], vs the oracle on the same bf16 inputs
+    (fp32 weights and accumulation, one rounding: <= 1 bf16 ulp = 2^-8 relative)"""
+    from motionrag_amd import cama
+    from oracle import cama_ref
+    g = np.load(os.path.join(golden_dir, "fusion.npz"))
+    emb = torch.from_numpy(g["emb"])
+    e_dev = emb.to(DEV, torch.bfloat16)
+    for mode in ("mean", "concat", "top1", "weight"):
+        got = cama.condition_fusion(e_dev, mode, g["dist"].tolist() if mode == "weight" else None)
+        want = torch.from_numpy(g[mode])
+        assert got.shape == want.shape and got.dtype == torch.bfloat16 and got.is_cuda
+        assert ((got.float().cpu() - want).abs() <= 2.0 ** -7 * want.abs() + 2.0 ** -7 * emb.abs().max()).all()
+    gen = torch.Generator().manual_seed(5)
+    big = torch.randn(2, 9, 25, 1024, generator=gen).to(torch.bfloat16)
+    dist = (0.2 + 0.6 * torch.rand(2, 9, generator=gen)).tolist()
+    for mode, w in (("mean", None), ("weight", dist)):
+        got = cama.condition_fusion(big.to(DEV), mode, w).float().cpu()
+        want = cama_ref.condition_fusion(big.float(), mode, w)
+        assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all()
+    with pytest.raises(ValueError):
+        cama.condition_fusion(big.to(DEV), "weight", [[0.1] * 8] * 2)
+
+
 def test_cogvideox_processor_dropin(hip):
     """APAdapterCogVideoXAttnProcessor2_0 called through the diffusers processor protocol vs the oracle restatement
     of attn_processor.py:176-283 (incl. `((cos, sin), ip)` smuggled through image_rotary_emb and B % B' repeat)."""

@@ -10,6 +10,16 @@ from motionrag_amd import ops  # noqa: E402
 
 DEV = "cuda"
 
+# developer knobs: the library reads no environment; this TOOL maps its historical env names onto the explicit tuning fields
+_E = os.environ
+ops.TUNING["gemm"] = ((ops.GEMM_TUNE_NO_WIDE if _E.get("MRAG_GEMM_NO_WIDE") else 0) | (ops.GEMM_TUNE_NO_STAGED if _E.get("MRAG_GEMM_NO_STAGED") else 0)
+                      | (ops.GEMM_TUNE_GEGLU_NO_STAGED if _E.get("MRAG_GEGLU_NO_STAGED") else 0) | (int(_E.get("MRAG_GEMM_CFG", "0")) << 4)
+                      | (int(_E.get("MRAG_GEMM_GROUP_M", "0")) << 8))
+ops.TUNING["attn"] = ((ops.ATTN_TUNE_NO_TINY if _E.get("MRAG_ATTN_NO_TINY") else 0) | (ops.ATTN_TUNE_PIPE if _E.get("MRAG_ATTN_PIPE") == "1" else 0)
+                      | (ops.ATTN_TUNE_NW4 if _E.get("MRAG_ATTN_NW") == "4" else 0) | (ops.ATTN_TUNE_LEGACY if _E.get("MRAG_ATTN_LEGACY") else 0))
+ops.TUNING["attn_no_split"] = _E.get("MRAG_ATTN_KV_SPLITS") == "0"
+ops.TUNING["no_qkv_fuse"] = bool(_E.get("MRAG_NO_QKV_FUSE"))
+
 
 def timeit(fn, iters=10, warm=2):
     for _ in range(warm):
@@ -153,95 +163,26 @@ def norm():
 
 def unet():
     """DynamiCrafter-1024 UNet + CAMA tokens, one CFG denoise step at 16x576x1024 (x [2, 8, 16, 72, 128]), random-init weights"""
-    from motionrag_amd import dynamicrafter as dc
-    torch.manual_seed(0)
-    old = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    with torch.device(DEV):
-        net = dc.UNetModel(in_channels=8, out_channels=4, model_channels=320, attention_resolutions=(4, 2, 1), num_res_blocks=2,
-                           channel_mult=(1, 2, 4, 4), num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
-                           temporal_conv=True, temporal_attention=True, temporal_self_att_only=True, use_relative_position=False,
-                           temporal_length=16, addition_attention=True, image_cross_attention=True, action_cross_attention=True,
-                           default_fs=10, fs_condition=True)
-    torch.set_default_dtype(old)
-    with torch.no_grad():
-        for n, p in net.named_parameters():
-            if p.dim() >= 2:
-                p.normal_(0.0, 0.02)
-            elif n.endswith("weight"):
-                p.fill_(1.0)
-            else:
-                p.normal_(0.0, 0.02)
-    x = torch.randn(2, 8, 16, 72, 128, device=DEV).to(torch.bfloat16)
-    ctx = {"prompt": torch.randn(2, 77, 1024, device=DEV).to(torch.bfloat16), "image": torch.randn(2, 16 * 16, 1024, device=DEV).to(torch.bfloat16),
-           "action": torch.randn(2, 25, 1024, device=DEV).to(torch.bfloat16)}
-    ts = torch.tensor([481.0, 481.0], device=DEV)
-    fs = torch.tensor([15, 15], device=DEV)
+    from motionrag_amd import workloads as W
+    net = W.dynamicrafter1024_unet(DEV)
+    x, ts, ctx, fs = W.dynamicrafter1024_inputs(DEV)
     dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=3, warm=1)
-    print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {105.7/dt:.0f} TFLOP/s of 105.7 TFLOP algorithmic  -> {16/dt:.1f} frames/s")
-    return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": 105.7, "tflops_per_s": round(105.7 / dt), "frames_per_s": round(16 / dt, 1)}
+    T = W.DC1024_STEP_TFLOP
+    print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {T/dt:.0f} TFLOP/s of {T} TFLOP algorithmic  -> {16/dt:.1f} frames/s")
+    return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": T, "tflops_per_s": round(T / dt), "frames_per_s": round(16 / dt, 1)}
 
 
 def count_flops(fn):
-    """algorithmic FLOPs of one call: 2 M N K of every GEMM (true K, before padding) + 4 B H Sq Skv 64 of every attention launch"""
-    tot = [0.0]
-    lin, att = ops.linear, ops.attention
-
-    def linear(x, w, *a, **k):
-        tot[0] += 2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * min(x.shape[-1], w.shape[1])
-        return lin(x, w, *a, **k)
-
-    def attention(q, k_, v, *a, **k):
-        tot[0] += 4.0 * q.shape[0] * q.shape[2] * q.shape[1] * k_.shape[1] * 64
-        return att(q, k_, v, *a, **k)
-
-    cimp = ops.conv_implicit
-
-    def conv_implicit(x, wk, *a, **k):
-        y = cimp(x, wk, *a, **k)
-        tot[0] += 2.0 * (y.numel() // y.shape[-1]) * wk.shape[0] * wk.shape[1]
-        return y
-
-    ops.linear, ops.attention, ops.conv_implicit = linear, attention, conv_implicit
-    try:
-        fn()
-    finally:
-        ops.linear, ops.attention, ops.conv_implicit = lin, att, cimp
-    return tot[0]
+    from motionrag_amd import workloads as W
+    return W.count_flops(fn)
 
 
 def svd():
     """SVD img2vid UNet + motion adapters, one CFG denoise step at 14x576x1024 (sample [2, 14, 8, 72, 128]), random-init weights"""
-    from motionrag_amd import svd as svd_glue, svd_unet
-    torch.manual_seed(0)
-    old = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    with torch.device(DEV):
-        net = svd_unet.UNetSpatioTemporalConditionModel()
-        names = [n for n in net.attn_processors if "temporal_transformer_blocks" not in n and n.endswith("attn2.processor")]
-        hidden = {n: dict(net.named_modules())[n[: -len(".processor")]].to_q.in_features for n in names}
-        svd_glue.set_attention_processors(net, names, 1024, hidden)
-    torch.set_default_dtype(old)
-    with torch.no_grad():
-        for n, p in net.named_parameters():
-            if p.dim() >= 2:
-                p.normal_(0.0, 0.02)
-            elif n.endswith("weight"):
-                p.fill_(1.0)
-            else:
-                p.normal_(0.0, 0.02)
-    B, Fr = 2, 14
-    x = torch.randn(B, Fr, 8, 72, 128, device=DEV).to(torch.bfloat16)
-    ehs = svd_glue.TupleTensor([torch.randn(B, 1, 1024, device=DEV).to(torch.bfloat16), torch.randn(B, 25, 1024, device=DEV).to(torch.bfloat16)])
-    ids = torch.tensor([[6.0, 127.0, 0.02]] * B, device=DEV)
-    sch = svd_unet.EulerDiscreteScheduler(); sch.set_timesteps(25)
-    lat = torch.randn(1, Fr, 4, 72, 128, device=DEV).to(torch.bfloat16)
-    gs = torch.linspace(1.0, 3.0, Fr, device=DEV)
-
-    def step():
-        v = net(x, float(sch.timesteps[3]), ehs, ids).sample
-        sch.step_(v.view(2, 1, Fr, 4, 72, 128), lat, 3, gs)
-
+    from motionrag_amd import workloads as W
+    net, names = W.svd_unet(DEV)
+    step, _, _ = W.svd_step(net, DEV)
+    Fr = 14
     fl = count_flops(step)
     dt = timeit(step, iters=3, warm=1)
     print(f"SVD UNet CFG step (14x576x1024, {len(names)} adapter sites): {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP algorithmic  -> {Fr/dt:.1f} frames/s")

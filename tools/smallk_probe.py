@@ -20,7 +20,7 @@ for name, N, K, epi in (("ff1 geglu C=320", 2560, 320, "geglu"), ("ff2 C=320", 3
     res = torch.randn(m, N, device=DEV).to(torch.bfloat16) if epi == "resid" else None
     wg, bg = ops.geglu_interleave(w, b) if epi == "geglu" else (None, None)
     for cfg in ("0", "2", "0", "2"):
-        os.environ["MRAG_GEMM_CFG"] = cfg
+        ops.TUNING["gemm"] = int(cfg) << 4
         if epi == "geglu":
             fn = lambda: ops.linear(x, wg, bg, epilogue=ops.EPI_GEGLU)
         elif epi == "resid":

@@ -17,11 +17,11 @@ def attn():
     B, H, S = 2, 48, 17776
     qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
-    for splits in ("0", "2", "3", "4", "5", "6", "8", "0", "5"):     # key-split tail of the BASELINE shape (plan_kv_split; default = 5)
-        os.environ["MRAG_ATTN_KV_SPLITS"] = splits
+    for splits in ("0", "auto", "0", "auto"):     # key-split tail of the BASELINE shape (plan_kv_split picks 5 chunks; 2..8 measured within 0.1 %)
+        ops.TUNING["attn_no_split"] = splits == "0"
         dt = timeit(lambda: ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out), iters=20, warm=3)
         print(f"attn S={S} kv_splits={splits}: {dt*1e3:.3f} ms  {4.0*B*H*S*S*64/dt/1e12:.1f} TF/s")
-    os.environ["MRAG_ATTN_KV_SPLITS"] = "0"
+    ops.TUNING["attn_no_split"] = True
     for sq in (64 * 256, 17776 - 112, 17776):
         dt = timeit(lambda: ops.attention(qkv[:, :sq, 0], qkv[:, :, 1], qkv[:, :, 2], out=out[:, :sq]), iters=20, warm=3)
         tiles = -(-sq // 256) * B * H

@@ -1,0 +1,379 @@
+// attn16.hip -- head_dim-64 bf16 flash attention for LONG UNMASKED sequences (the 17 776-token CogVideoX joint attention,
+// src/projects/condition/attn_processor.py:233-235; the spatial self-attention of the UNets, lvdm/modules/attention.py:189) on
+// v_mfma_f32_16x16x32_bf16.
+//
+// Why a second kernel family.  attn_flash.hip (v_mfma_f32_32x32x16_bf16, a lane owns a query row) is bound on this chip by power, not
+// by issue slots: its loop holds ~1.9 of 2.4 GHz.  Two things lower the energy per FLOP here:
+//   * the 16x16x32 shape -- the guide measures 1.12-1.15x the FLOP/s of 32x32x16 in power-limited loops at equal cycles per FLOP
+//     (MI355X_MICROARCH.md, DVFS give-back item 7) -- and its 4-register C operand carries the running max into the score MFMAs for free
+//     (S' = K.Q^T - m leaves the chain; the 32x32 kernel spends 2 extra MFMAs per tile on that);
+//   * a LAZY running max: no per-tile row maximum at all.  The first tile of a row fixes m; afterwards P = exp2(S') is formed directly
+//     and only a tile whose row sum explodes (> 2^24: a score beat the stale max by > ~20 log2 units -- never on real activations)
+//     re-runs its score MFMAs, moves m and rescales O / l.  That removes the v_max3 chains, the half-wave swap and the threshold test
+//     (~22 of ~130 vector instructions per tile) from a loop whose vector pipe is the busier one.
+//
+// Layout (QB = 16-query blocks per wave, 2 -> 32 rows per wave, 256 per 8-wave workgroup):
+//   S^T[key, q] = K . Q^T   A = K fragment  (row = key l & 15, k = d 32 ks + 8 (l >> 4) + j)   <- ds_read_b128 of the XOR-swizzled K tile
+//                           B = Q^T fragment (col = q   l & 15, same k)                          <- registers, pre-multiplied by scale * log2 e
+//                           C = (-m, -m, -m, -m) of the lane's query
+//     D: lane (q = l & 15, g = l >> 4) holds keys 16 kb + 4 g + r  (r = register 0..3)
+//   O^T[d, q] = V^T . P^T   A = V^T fragment (row = d 16 db + (l & 15), k-slot 8 g + j)         <- 2 x ds_read_b64_tr_b16 (keys 4 g.., 16 + 4 g..)
+//                           B = P^T fragment: k-slot 8 g + j = key 32 s + 4 g + j (j < 4) | 32 s + 16 + 4 g + j - 4 -- exactly the packed
+//                               accumulators of key blocks 2 s and 2 s + 1: P never leaves registers and needs no cross-lane move
+//     D: lane (q, g) holds d = 16 db + 4 g + r -> 8-byte stores.
+// K / V tiles of 64 keys ride the same 4-stage LDS-DMA ring as attn_flash.hip (scalar-base global_load_lds, counted vmcnt, raw s_barrier);
+// V's 32-byte chunks are XOR-swizzled by (key >> 1) & 3 on the DMA source so the transposed reads are conflict-free.
+#include "attn_common.h"
+#include "../../include/mrag_hip.h"
+
+namespace {
+
+constexpr int KVB = 64;
+constexpr int TILE_BYTES = KVB * 128;
+constexpr int NS = 4;
+constexpr int V_BASE = NS * TILE_BYTES;
+constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
+
+struct Lane16 {
+  unsigned ka[2];     // LDS byte address (stage 0, key block 0) of this lane's K fragment for k-step 0 / 1
+  unsigned va[4];     // LDS byte address (stage 0, keys 4 g + q) of this lane's V^T read for d-block 0..3
+  int g;
+};
+
+// 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads (16 VGPRs of fragments live at a time).
+template <int STG, int QB, typename Between>
+__device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
+    u32x4 kf[4];                           // [2 * kbl + ks]
+    if (half == 0) {
+      asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
+                   : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3])
+                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 2048) : "memory");
+      between();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3])
+                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 6144) : "memory");
+    }
+#pragma unroll
+    for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
+        s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl + 1]), qf[qb][1], s[2 * half + kbl][qb], 0, 0, 0);
+      }
+  }
+}
+
+// O^T += V^T . P^T: per 32-key step 4 d-blocks x 2 transposed reads, QB MFMAs per fragment.  EXEC is all ones (wave-uniform control flow only).
+template <int STG, int QB>
+__device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB]) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    u32x2 lo[4], hi[4];   // d-block db: keys 32 st + 4 g .. (+3) and 32 st + 16 + 4 g .. (+3)
+    if (st == 0)
+      asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + STG * TILE_BYTES), "n"(V_BASE + STG * TILE_BYTES + 2048) : "memory");
+    else
+      asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+                   "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + STG * TILE_BYTES + 4096), "n"(V_BASE + STG * TILE_BYTES + 6144) : "memory");
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[st][qb], o[db][qb], 0, 0, 0);
+    }
+  }
+}
+
+struct NoHook16 {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+template <int QB, bool KVSPLIT>
+__global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const AttnP p) {
+  constexpr int NW = 8, ROWS = NW * QB * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15;
+  Lane16 ln;
+  ln.g = lane >> 4;
+
+  // ---- XCD-aware block -> (q-tile, b, h): all q-tiles of one (b, h) on one XCD (its K / V stream from that XCD's L2)
+  const int nbh = p.B * p.H;
+  int bh, qt;
+  int skv = p.Skv, key0 = 0;
+  bool split_unit = false;
+  if (KVSPLIT && (int)blockIdx.x >= p.n_main) {
+    const int u = blockIdx.x - p.n_main;
+    bh = u / p.kv_splits;
+    qt = p.n_qtiles;
+    key0 = (u % p.kv_splits) * p.chunk_keys;
+    skv = p.Skv - key0 < p.chunk_keys ? p.Skv - key0 : p.chunk_keys;
+    split_unit = true;
+  } else if ((nbh & 7) == 0) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bh = (j / p.n_qtiles) * 8 + x;
+    qt = j % p.n_qtiles;
+  } else {
+    bh = blockIdx.x / p.n_qtiles;
+    qt = blockIdx.x % p.n_qtiles;
+  }
+  const int b = bh / p.H, h = bh % p.H;
+  const int bkv = b / p.kv_div;
+  const int q0 = qt * ROWS + wave * (QB * 16);
+  const bool wave_active = q0 < p.Sq;
+
+  // ---- Q^T fragments (B operand): lane holds Q[q = 16 qb + r16][d = 32 ks + 8 g + j], pre-multiplied by scale * log2 e
+  bf16x8 qf[QB][2];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + qb * 16 + r16;
+    const int qc = qrow < p.Sq ? qrow : p.Sq - 1;
+    const bf16_t* qp = p.Q + (long long)b * p.q_sb + (long long)qc * p.q_ss + (long long)h * p.q_sh + ln.g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4 raw = *(const u32x4*)(qp + ks * 32);
+      if (p.qscale == 1.0f) {
+        qf[qb][ks] = __builtin_bit_cast(bf16x8, raw);
+      } else {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = pack_bf2(__uint_as_float(raw[i] << 16) * p.qscale, __uint_as_float(raw[i] & 0xffff0000u) * p.qscale);
+        qf[qb][ks] = __builtin_bit_cast(bf16x8, r);
+      }
+    }
+  }
+
+  // ---- LDS-DMA staging: one 1-KiB piece (8 keys x 128 B) per wave per K (and V) tile; lane i -> key (i >> 3), 16-byte granule (i & 7)
+  const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh + (long long)key0 * p.k_ss;
+  const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh + (long long)key0 * p.v_ss;
+  const int kit = wave * 8 + (lane >> 3), ppos = lane & 7;
+  const unsigned k_loff = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;            // K: 16-byte chunks XORed by (key >> 1) & 7
+  const unsigned v_loff = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
+  const int last_start = skv - KVB;     // >= 0 (the launcher takes only Skv >= 256 and chunks of whole tiles); a ragged last tile is slid back
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  auto issue_kv = [&](int stage, int t) {
+    const int start = t * KVB < last_start ? t * KVB : last_start;
+    glds16_sbase((const char*)kbase + (long long)start * p.k_ss * 2, k_loff, lds0 + stage * TILE_BYTES + wave * 1024);
+    glds16_sbase((const char*)vbase + (long long)start * p.v_ss * 2, v_loff, lds0 + V_BASE + stage * TILE_BYTES + wave * 1024);
+  };
+
+  // ---- fragment read addresses
+  {
+    const int swz = (r16 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) ln.ka[ks] = lds0 + r16 * 128 + (((4 * ks + ln.g) ^ swz) * 16);
+    const int q4 = r16 >> 2, p4 = r16 & 3;
+    const int key = 4 * ln.g + q4, vs = (key >> 1) & 3;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) ln.va[db] = lds0 + key * 128 + ((db ^ vs) * 32) + p4 * 8;
+  }
+
+  f32x4 o[4][QB], negm[QB];
+  float m[QB], l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[qb] = 0.f; l[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nt = (skv + KVB - 1) / KVB;
+  constexpr int D = NS - 1;
+  auto wait_pair = [&]() {   // all but the (D - 1) youngest tile pairs of this wave have landed; then rendezvous
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int i = 0; i < D; ++i) issue_kv(i, i);
+
+  // exact row maximum of the lane's queries over one tile's scores (first tile and the rare re-centre path only)
+  auto tile_max = [&](const f32x4 (&s)[4][QB], float (&tm)[QB]) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float a = max3_asm(s[0][qb][0], s[0][qb][1], s[0][qb][2]);
+      a = max3_asm(a, s[0][qb][3], s[1][qb][0]);
+      a = max3_asm(a, s[1][qb][1], s[1][qb][2]);
+      a = max3_asm(a, s[1][qb][3], s[2][qb][0]);
+      a = max3_asm(a, s[2][qb][1], s[2][qb][2]);
+      a = max3_asm(a, s[2][qb][3], s[3][qb][0]);
+      a = max3_asm(a, s[3][qb][1], s[3][qb][2]);
+      a = fmaxf(a, s[3][qb][3]);
+      a = fmaxf(a, __shfl_xor(a, 16));
+      a = fmaxf(a, __shfl_xor(a, 32));
+      tm[qb] = a;
+    }
+  };
+
+  auto iter = [&](int t, auto stage_c) {
+    constexpr int STG = decltype(stage_c)::value;
+    wait_pair();   // barrier #t: tile t has landed for every wave, tile t - 1's stage is free
+    auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
+    if (!wave_active) { early_issue(); return; }
+    f32x4 s[4][QB];
+    float ps[QB];
+    const bool ragged = (t == nt - 1) && (skv & (KVB - 1));
+    const int gkey = skv - KVB + 4 * ln.g;          // slid-back last tile: first key of this lane's group in key block 0
+    // Pass 1 is the whole story except on the first tile and on a tile whose row sums explode (a score beat the stale max by more than
+    // ~20 log2 units: never on real activations): those re-centre -- exact tile maximum, m moves, O and l are rescaled by the exact
+    // factor -- and, for an exploded tile, the score MFMAs are simply run again (its K stage is still resident).
+    bool recentre = (t == 0);
+    for (int pass = 0;; ++pass) {
+      if (pass == 0) qk16<STG, QB>(ln, qf, negm, s, early_issue);
+      else qk16<STG, QB>(ln, qf, negm, s, NoHook16());
+      if (ragged) {   // keys before t * 64 were consumed by the previous tile
+        asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
+        const int lo = t * KVB;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (gkey < lo - (16 * kb + r)) {
+#pragma unroll
+              for (int qb = 0; qb < QB; ++qb) s[kb][qb][r] = -INFINITY;
+            }
+      }
+      if (recentre) {
+        float tm[QB];
+        tile_max(s, tm);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float delta = t == 0 ? fmaxf(tm[qb], -1e30f) : fmaxf(tm[qb], 0.f);   // S' is relative to m already: a row moves by max(0, tile max)
+          if (t != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l[qb] *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] *= f32x4{alpha, alpha, alpha, alpha};
+          }
+          m[qb] += delta;
+          negm[qb] = f32x4{-m[qb], -m[qb], -m[qb], -m[qb]};
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) s[kb][qb] -= f32x4{delta, delta, delta, delta};
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+          a0 += s[kb][qb][0] + s[kb][qb][1];
+          a1 += s[kb][qb][2] + s[kb][qb][3];
+        }
+        ps[qb] = a0 + a1;
+      }
+      bool blown = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) blown |= !(ps[qb] <= kBig);   // also catches inf / NaN
+      if (__builtin_expect(!__any(blown), 1) || recentre) break;     // a re-centred tile has P <= 1: it cannot explode again
+      recentre = true;
+    }
+    bf16x8 pb[2][QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      l[qb] += ps[qb];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const u32x4 w = {pack_bf2(s[2 * st][qb][0], s[2 * st][qb][1]), pack_bf2(s[2 * st][qb][2], s[2 * st][qb][3]),
+                         pack_bf2(s[2 * st + 1][qb][0], s[2 * st + 1][qb][1]), pack_bf2(s[2 * st + 1][qb][2], s[2 * st + 1][qb][3])};
+        pb[st][qb] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
+    pv16<STG, QB>(ln, pb, o);
+  };
+
+  int t = 0;
+  for (; t + NS <= nt; t += NS) {
+    iter(t, std::integral_constant<int, 0>{});
+    iter(t + 1, std::integral_constant<int, 1>{});
+    iter(t + 2, std::integral_constant<int, 2>{});
+    iter(t + 3, std::integral_constant<int, 3>{});
+  }
+  if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
+  if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; }
+  if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
+
+  if (!wave_active) return;
+  // ---- epilogue: row sums across the 4 lane groups, normalise, fused residual, 8-byte stores (4 consecutive features of a row per lane)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float lt = l[qb];
+    lt += __shfl_xor(lt, 16);
+    lt += __shfl_xor(lt, 32);
+    const int qrow = q0 + qb * 16 + r16;
+    if (qrow >= p.Sq) continue;
+    if (KVSPLIT && split_unit) {   // partial result of this key chunk; attn_combine_kernel merges the chunks
+      const long long prow_i = (long long)(blockIdx.x - p.n_main) * p.rem_rows + wave * (QB * 16) + qb * 16 + r16;
+      float* po = p.part_o + prow_i * 64 + 4 * ln.g;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) *(f32x4*)(po + 16 * db) = o[db][qb];
+      if (ln.g == 0) p.part_ml[prow_i] = make_float2(m[qb], lt);
+      continue;
+    }
+    const float inv = p.out_scale / lt;
+    const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * ln.g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      float v[4] = {o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv};
+      const long long off = obase + 16 * db;
+      if (p.resid) {
+        const u32x2 rr = *(const u32x2*)(p.resid + off);
+        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+      }
+      u32x2 out;
+      out[0] = pack_bf2(v[0], v[1]);
+      out[1] = pack_bf2(v[2], v[3]);
+      *(u32x2*)(p.O + off) = out;
+    }
+  }
+}
+
+}  // namespace
+
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace) {
+  constexpr int QB = 2, ROWS = 8 * QB * 16;
+  if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
+  const int nbh = p.B * p.H;
+  const size_t lds = 2 * NS * TILE_BYTES;
+  if (pl) {
+    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= ROWS) return MRAG_ENOTSUP;
+    p.n_qtiles = pl->n_full;
+    p.n_main = pl->n_full * nbh;
+    p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
+    p.part_o = (float*)workspace;
+    p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
+    const void* kf = (const void*)attn16_kernel<QB, true>;
+    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    MRAG_LAUNCH((attn16_kernel<QB, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
+    MRAG_LAUNCH_CHECK();
+    return mrag_launch_attn_combine(s, p);
+  }
+  p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
+  const void* kf = (const void*)attn16_kernel<QB, false>;
+  const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  MRAG_LAUNCH((attn16_kernel<QB, false>), dim3(p.n_qtiles * nbh), dim3(512), lds, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}

@@ -81,18 +81,9 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
 #define MRAG_ATTN_MFMA_MAX 1
 #endif
 
-namespace {
+#include "attn_common.h"
 
-struct AttnP {
-  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; const bf16_t* resid; const uint8_t* mask;
-  long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss;
-  int B, H, Sq, Skv, kv_div, n_qtiles;
-  float qscale, out_scale;
-  // key-split tail (KVSPLIT instantiation): workgroups >= n_main own (b, h, chunk) of the ragged last query tile
-  int n_main, kv_splits, chunk_keys, rem_rows;
-  float* part_o;    // [B*H*kv_splits, rem_rows, 64] unnormalised partial outputs
-  float2* part_ml;  // [B*H*kv_splits, rem_rows] (running max in log2 units, row sum)
-};
+namespace {
 
 constexpr float kThr = 5.0f;          // deferred-rescale threshold in log2 units (P <= 32)
 constexpr int KVB = 64;               // keys per tile
@@ -109,13 +100,6 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float s) {
     r[i] = pack_bf2(lo, hi);
   }
   return __builtin_bit_cast(bf16x8, r);
-}
-
-// v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max per operand
-__device__ __forceinline__ float max3_asm(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
 }
 
 __device__ __forceinline__ float half_swap_max(float v) {
@@ -1007,12 +991,9 @@ int launch_attn(hipStream_t s, AttnP p) {
 // workgroups that drain into the slots the last full round frees; each leaves (unnormalised O, running max, row sum) in a caller-provided
 // workspace and attn_combine_kernel merges the chunks, applies out_scale / resid and writes bf16 -- the same online-softmax algebra as
 // between two key tiles, carried through HBM instead of registers.
-struct SplitPlan {
-  int splits = 1, chunk_keys = 0, rem_rows = 0, n_full = 0;
-  size_t bytes = 0;
-};
+}  // namespace
 
-SplitPlan plan_kv_split(int B, int H, int Sq, int Skv) {
+SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv) {
   SplitPlan pl;
   const int rem = Sq % 256, n_full = Sq / 256, nt = (Skv + KVB - 1) / KVB;
   const long long nbh = (long long)B * H;
@@ -1026,6 +1007,8 @@ SplitPlan plan_kv_split(int B, int H, int Sq, int Skv) {
   pl.bytes = (size_t)nbh * splits * rem * (64 * sizeof(float) + sizeof(float2));
   return pl;
 }
+
+namespace {
 
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
   const long long idx = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);   // (b*H + h, row of the ragged tile); 16 lanes x 4 columns per row
@@ -1078,9 +1061,15 @@ int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspa
 
 }  // namespace
 
+int mrag_launch_attn_combine(hipStream_t s, const AttnP& p) {
+  MRAG_LAUNCH(attn_combine_kernel, dim3((unsigned)(((long long)p.B * p.H * p.rem_rows + 15) / 16)), dim3(256), 0, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
 extern "C" int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv) {
   if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
-  return (int64_t)plan_kv_split(B, H, Sq, Skv).bytes;
+  return (int64_t)mrag_plan_kv_split(B, H, Sq, Skv).bytes;
 }
 
 // ---------------------------------------------------------------------------------------------- tiny sequences
@@ -1303,11 +1292,19 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);
   const int nw_big = (a->tuning & MRAG_ATTN_TUNE_NW4) ? 4 : 8;
   if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
+  const bool legacy = (a->tuning & MRAG_ATTN_TUNE_LEGACY) != 0;
+  SplitPlan pl;
+  bool split = false;
   if (a->Sq > 128 && !pipe && !a->mask && a->workspace) {   // key-split tail for the ragged last query tile (plan_kv_split)
     if (((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
-    const SplitPlan pl = plan_kv_split(a->B, a->H, a->Sq, a->Skv);
-    if (pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes) return launch_attn_split(s, p, pl, a->workspace);
+    pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv);
+    split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
   }
+  if (a->Sq > 128 && !pipe && !a->mask && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip)
+    const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace);
+    if (rc != MRAG_ENOTSUP) return rc;
+  }
+  if (split) return launch_attn_split(s, p, pl, a->workspace);
   if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
   if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
   return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);

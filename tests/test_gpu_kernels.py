@@ -166,6 +166,36 @@ def test_attention_deferred_rescale_branch(hip):
     close(got, sdpa_ref(q, k, v), scale=0.3)
 
 
+def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
+    """attn16.hip (long unmasked sequences on 16x16x32 MFMAs) keeps a LAZY running max: after a row's first tile no row maximum is formed
+    and only a tile whose partial row sums exceed 2^24 re-centres.  cdna guide rule 26: force that branch -- a score 40 log2 units above the
+    stale max (finite blow-up), one 150 units above (exp2 overflows to inf), one in the slid-back ragged last key tile of the ragged last
+    query tile, low scores in the first tile -- against the fp32 reference, and check the 32x32x16 kernel agrees on the same inputs"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, H, Sq, Skv = 1, 2, 300, 1000
+    q, k, v = (torch.randn(B, S, H, 64, generator=g) for S in (Sq, Skv, Skv))
+    k[:, :64] -= 3.0 * q[:, :1].mean(dim=1, keepdim=True)
+    unit = lambda r: q[:, r] / q[:, r].norm(dim=-1, keepdim=True)
+    k[:, 300] = 20.0 * unit(7)          # ~ +29 log2 units over row 7's typical maximum: 2^29 > 2^24 -> re-centre
+    k[:, 700] = 104.0 * unit(200)       # ~ +150: exp2 overflows -> inf -> re-centre
+    k[:, 701] = 21.5 * unit(7)          # row 7 again, two units above its new maximum: P > 1 after a re-centre, no second one needed
+    k[:, 990] = 45.0 * unit(290)        # ragged q-tile row, key inside the slid-back last key tile
+    q, k, v = bf(q), bf(k), bf(v)
+    want = sdpa_ref(q, k, v)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    # Q carries scale * log2 e in bf16 (one extra rounding, 2^-9 relative): at scores of 30 log2 units that is 0.06 units = 4 % on the weight
+    # ratio of row 7's two spikes -> the looser of the suite's tolerances (as the key-split test)
+    close(got, want, scale=0.3, rtol=3e-2, atol_frac=5e-2)
+    ops.TUNING["attn"] = ops.ATTN_TUNE_LEGACY
+    try:
+        old = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    finally:
+        ops.TUNING["attn"] = 0
+    close(old, want, scale=0.3, rtol=3e-2, atol_frac=5e-2)
+    close(got, old.float().cpu(), scale=0.3, rtol=3e-2, atol_frac=5e-2)
+
+
 def test_attention_large_sequence_properties(hip):
     """BASELINE-size sequence (S = 17 776, the CogVideoX joint length), checked through size-independent properties:
     (1) with V = ones the output is exactly 1 (softmax rows sum to one); (2) permuting the keys/values does not change

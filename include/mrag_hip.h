@@ -136,7 +136,9 @@ typedef struct mrag_attn_args {
 enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pair kernel          */
        MRAG_ATTN_TUNE_PIPE = 2,      /* intra-wave software-pipelined variant (measured slower)    */
        MRAG_ATTN_TUNE_NW4 = 4,       /* 4-wave workgroups for long sequences                       */
-       MRAG_ATTN_TUNE_LEGACY = 8 };  /* long unmasked sequences through the 32x32x16 kernel        */
+       MRAG_ATTN_TUNE_LEGACY = 8,    /* long unmasked sequences through the 32x32x16 kernel        */
+       MRAG_ATTN_TUNE_QB4 = 16,      /* attn16 with 64 query rows per wave (no key-split tail)     */
+       MRAG_ATTN_TUNE_QB4W4 = 32 };  /* the same in 4-wave workgroups, two per CU                  */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
@@ -144,6 +146,17 @@ int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
  * (Sq % 256 rows per (b, h)) as several short key-chunk workgroups + a merge
  * instead of B*H full-length stragglers; 0 when the shape has no such tail.  */
 int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv);
+
+/* fp8 (OCP e4m3) attention path -- BASELINE config "DynamiCrafter-1024 UNet 16x576x1024 + CAMA, fp8 MFMA attention path": the
+ * spatial self-attention SDPA of the UNets (lvdm/modules/attention.py:189; diffusers BasicTransformerBlock.attn1 of the SVD UNet).
+ * Same argument struct and result as mrag_attn_fwd_bf16 (bf16 Q / K / V views in, bf16 O out, fused residual); inside: per-(batch, head)
+ * amax -> power-of-two scales -> e4m3 Q (with scale * log2 e folded in), K, V in MFMA operand order in the workspace, then
+ * v_mfma_scale_f32_32x32x64_f8f6f4 for Q K^T and P V (e4m3 P, fp32 softmax, fp32 accumulation).  `workspace` is REQUIRED
+ * (>= mrag_attn_fp8_workspace_bytes).  MRAG_ENOTSUP unless: no mask, kv_batch_div == 1, Skv % 128 == 0, Skv >= 512, q_prescaled == 0.
+ * Precision: 3 mantissa bits per operand -- 5-6 % relative Frobenius error against fp32 attention (tests/test_gpu_fp8.py: <= 8 %);
+ * opt-in, never used for the bf16 headline workload.                                                                                  */
+int64_t mrag_attn_fp8_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv);
+int mrag_attn_fwd_fp8(void* stream, const mrag_attn_args* args);
 
 /* ------------------------------------------------------------------------ */
 /* Motion-adapter branch with the query projection folded into the keys:      */

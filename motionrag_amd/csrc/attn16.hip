@@ -103,9 +103,9 @@ struct NoHook16 {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <int QB, bool KVSPLIT>
-__global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const AttnP p) {
-  constexpr int NW = 8, ROWS = NW * QB * 16;
+template <int QB, int NW, bool KVSPLIT>
+__global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const AttnP p) {
+  constexpr int ROWS = NW * QB * 16, PPW = 8 / NW;   // PPW: 1-KiB DMA pieces per wave per K (and V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,15 +162,23 @@ __global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const Attn
   // ---- LDS-DMA staging: one 1-KiB piece (8 keys x 128 B) per wave per K (and V) tile; lane i -> key (i >> 3), 16-byte granule (i & 7)
   const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh + (long long)key0 * p.k_ss;
   const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh + (long long)key0 * p.v_ss;
-  const int kit = wave * 8 + (lane >> 3), ppos = lane & 7;
-  const unsigned k_loff = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;            // K: 16-byte chunks XORed by (key >> 1) & 7
-  const unsigned v_loff = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
+  const int ppos = lane & 7;
+  unsigned k_loff[PPW], v_loff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int kit = (wave + i * NW) * 8 + (lane >> 3);
+    k_loff[i] = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;            // K: 16-byte chunks XORed by (key >> 1) & 7
+    v_loff[i] = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
+  }
   const int last_start = skv - KVB;     // >= 0 (the launcher takes only Skv >= 256 and chunks of whole tiles); a ragged last tile is slid back
   const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_kv = [&](int stage, int t) {
     const int start = t * KVB < last_start ? t * KVB : last_start;
-    glds16_sbase((const char*)kbase + (long long)start * p.k_ss * 2, k_loff, lds0 + stage * TILE_BYTES + wave * 1024);
-    glds16_sbase((const char*)vbase + (long long)start * p.v_ss * 2, v_loff, lds0 + V_BASE + stage * TILE_BYTES + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      glds16_sbase((const char*)kbase + (long long)start * p.k_ss * 2, k_loff[i], lds0 + stage * TILE_BYTES + (wave + i * NW) * 1024);
+      glds16_sbase((const char*)vbase + (long long)start * p.v_ss * 2, v_loff[i], lds0 + V_BASE + stage * TILE_BYTES + (wave + i * NW) * 1024);
+    }
   };
 
   // ---- fragment read addresses
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const Attn
   const int nt = (skv + KVB - 1) / KVB;
   constexpr int D = NS - 1;
   auto wait_pair = [&]() {   // all but the (D - 1) youngest tile pairs of this wave have landed; then rendezvous
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (D - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -206,16 +214,13 @@ __global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const Attn
 
   // exact row maximum of the lane's queries over one tile's scores (first tile and the rare re-centre path only)
   auto tile_max = [&](const f32x4 (&s)[4][QB], float (&tm)[QB]) {
+    // plain fmaxf (not the inline-asm v_max3 helper): these values come straight out of MFMAs, and hipcc pads the MFMA -> VALU read hazard
+    // only for instructions it can see
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float a = max3_asm(s[0][qb][0], s[0][qb][1], s[0][qb][2]);
-      a = max3_asm(a, s[0][qb][3], s[1][qb][0]);
-      a = max3_asm(a, s[1][qb][1], s[1][qb][2]);
-      a = max3_asm(a, s[1][qb][3], s[2][qb][0]);
-      a = max3_asm(a, s[2][qb][1], s[2][qb][2]);
-      a = max3_asm(a, s[2][qb][3], s[3][qb][0]);
-      a = max3_asm(a, s[3][qb][1], s[3][qb][2]);
-      a = fmaxf(a, s[3][qb][3]);
+      float a = fmaxf(fmaxf(s[0][qb][0], s[0][qb][1]), fmaxf(s[0][qb][2], s[0][qb][3]));
+#pragma unroll
+      for (int kb = 1; kb < 4; ++kb) a = fmaxf(a, fmaxf(fmaxf(s[kb][qb][0], s[kb][qb][1]), fmaxf(s[kb][qb][2], s[kb][qb][3])));
       a = fmaxf(a, __shfl_xor(a, 16));
       a = fmaxf(a, __shfl_xor(a, 32));
       tm[qb] = a;
@@ -350,9 +355,24 @@ __global__ __launch_bounds__(512, QB == 2 ? 4 : 2) void attn16_kernel(const Attn
 
 }  // namespace
 
-int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace) {
-  constexpr int QB = 2, ROWS = 8 * QB * 16;
+template <int QB, int NW>
+static int launch16_plain(hipStream_t s, AttnP p) {
+  constexpr int ROWS = NW * QB * 16;
+  const size_t lds = 2 * NS * TILE_BYTES;
+  p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
+  const void* kf = (const void*)attn16_kernel<QB, NW, false>;
+  const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  MRAG_LAUNCH((attn16_kernel<QB, NW, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
+  constexpr int QB = 2, NW = 8, ROWS = NW * QB * 16;
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
+  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8>(s, p);       // developer A/B: 64 query rows per wave, 512-row workgroups, one per CU
+  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4>(s, p);     // developer A/B: 64 rows per wave, 4-wave workgroups, two per CU
   const int nbh = p.B * p.H;
   const size_t lds = 2 * NS * TILE_BYTES;
   if (pl) {
@@ -362,18 +382,12 @@ int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* worksp
     p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
     p.part_o = (float*)workspace;
     p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
-    const void* kf = (const void*)attn16_kernel<QB, true>;
+    const void* kf = (const void*)attn16_kernel<QB, NW, true>;
     const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    MRAG_LAUNCH((attn16_kernel<QB, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
+    MRAG_LAUNCH((attn16_kernel<QB, NW, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
     MRAG_LAUNCH_CHECK();
     return mrag_launch_attn_combine(s, p);
   }
-  p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
-  const void* kf = (const void*)attn16_kernel<QB, false>;
-  const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, false>), dim3(p.n_qtiles * nbh), dim3(512), lds, s, p);
-  MRAG_LAUNCH_CHECK();
-  return MRAG_OK;
+  return launch16_plain<QB, NW>(s, p);
 }

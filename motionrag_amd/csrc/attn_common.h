@@ -23,7 +23,7 @@ struct SplitPlan {
 SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv);
 int mrag_launch_attn_combine(hipStream_t s, const AttnP& p);
 // attn16.hip: long unmasked sequences (Sq > 128, Skv >= 256) on v_mfma_f32_16x16x32_bf16; returns MRAG_ENOTSUP for shapes it does not take
-int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace);
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning);
 
 // v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max per operand
 __device__ __forceinline__ float max3_asm(float a, float b, float c) {

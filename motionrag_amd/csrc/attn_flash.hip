@@ -1301,7 +1301,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
   }
   if (a->Sq > 128 && !pipe && !a->mask && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip)
-    const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace);
+    const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace, a->tuning);
     if (rc != MRAG_ENOTSUP) return rc;
   }
   if (split) return launch_attn_split(s, p, pl, a->workspace);

@@ -22,7 +22,7 @@ LOG2E = 1.4426950408889634
 # Nothing on the launch path reads the environment.
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
-ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY = 1, 2, 4, 8
+ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4 = 1, 2, 4, 8, 16, 32
 
 
 class HipOnly(RuntimeError):
@@ -116,20 +116,25 @@ def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
 _ATTN_WS = {}
 
 
-def _attn_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """scratch for mrag_attn_fwd_bf16's key-split tail, one grow-only buffer per (device, stream): launches on one stream are ordered,
-    so consecutive calls may share it"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+def _attn_workspace(device: torch.device, nbytes: int, kind: str = "split") -> torch.Tensor:
+    """scratch for mrag_attn_fwd_bf16's key-split tail / mrag_attn_fwd_fp8's e4m3 operands, one grow-only buffer per (device, stream, kind):
+    launches on one stream are ordered, so consecutive calls may share it"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, kind)
     ws = _ATTN_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _ATTN_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
 
 
+def fp8_attention_supported(Sq: int, Skv: int, kv_batch_div: int = 1, mask=None, q_prescaled: bool = False) -> bool:
+    """shapes mrag_attn_fwd_fp8 takes (include/mrag_hip.h); everything else stays on the bf16 kernels"""
+    return mask is None and kv_batch_div == 1 and not q_prescaled and Skv % 128 == 0 and Skv >= 512 and Sq > 128
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optional[torch.Tensor] = None,
               resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, kv_batch_div: int = 1,
-              scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False) -> torch.Tensor:
-    """softmax(q k^T * scale [masked]) v for head_dim 64.
+              scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False, fp8: bool = False) -> torch.Tensor:
+    """softmax(q k^T * scale [masked]) v for head_dim 64.  fp8=True: the e4m3 MFMA path (mrag_attn_fwd_fp8; raises on shapes it does not take).
 
     q [B, Sq, H, 64], k/v [Bkv, Skv, H, 64] (any strides with the last dim contiguous, e.g. views of a
     fused QKV buffer); out/resid [B, Sq, H*64] with the last two dims packed.  mask: bool/uint8
@@ -171,6 +176,21 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
     a.out_scale = out_scale
     a.q_prescaled = 1 if q_prescaled else 0
     a.tuning = TUNING["attn"]
+    if fp8:
+        if not fp8_attention_supported(Sq, Skv, kv_batch_div, mask, q_prescaled):
+            raise ValueError(f"fp8 attention does not take Sq={Sq} Skv={Skv} kv_batch_div={kv_batch_div} (see fp8_attention_supported)")
+        need = _lib.lib().mrag_attn_fp8_workspace_bytes(B, H, Sq, Skv)
+        ws = _attn_workspace(q.device, need, "fp8")
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+        timed = KERNEL_TIMING is not None and Skv >= 1024
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(_lib.lib().mrag_attn_fwd_fp8(_stream(), ctypes.byref(a)), "mrag_attn_fwd_fp8")
+        if timed:
+            e1.record()
+            KERNEL_TIMING.append(("attn_fwd_fp8", 4.0 * B * H * Sq * Skv * 64, e0, e1))
+        return out
     if mask is None and not TUNING["attn_no_split"]:
         need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)   # > 0: long sequence with a ragged last query tile (key-split tail)
         if need > 0:

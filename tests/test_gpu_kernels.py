@@ -184,16 +184,20 @@ def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
     q, k, v = bf(q), bf(k), bf(v)
     want = sdpa_ref(q, k, v)
     got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
-    # Q carries scale * log2 e in bf16 (one extra rounding, 2^-9 relative): at scores of 30 log2 units that is 0.06 units = 4 % on the weight
-    # ratio of row 7's two spikes -> the looser of the suite's tolerances (as the key-split test)
-    close(got, want, scale=0.3, rtol=3e-2, atol_frac=5e-2)
+    # Q carries scale * log2 e in bf16 (one extra rounding, 2^-9 relative, documented in attn_flash.hip / DESIGN.md section 4): with keys of
+    # norm 20-100 in the set that is up to 0.1 log2 units on a score.  So: the standard tolerance against the fp32 reference evaluated on
+    # that rounded Q, and a looser absolute one (0.045) against the plain fp32 reference -- a CPU emulation of the kernel's roundings
+    # (bf16 Q', bf16 P) lands at max |err| 0.0345 on these inputs, exactly what the kernels return
+    q_r = bf(q * (0.125 * 1.4426950408889634)) / (0.125 * 1.4426950408889634)
+    close(got, sdpa_ref(q_r, k, v), scale=0.3)
+    close(got, want, scale=0.3, rtol=3e-2, atol_frac=0.15)
     ops.TUNING["attn"] = ops.ATTN_TUNE_LEGACY
     try:
         old = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     finally:
         ops.TUNING["attn"] = 0
-    close(old, want, scale=0.3, rtol=3e-2, atol_frac=5e-2)
-    close(got, old.float().cpu(), scale=0.3, rtol=3e-2, atol_frac=5e-2)
+    close(old, sdpa_ref(q_r, k, v), scale=0.3)
+    close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)
 
 
 def test_attention_large_sequence_properties(hip):

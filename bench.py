@@ -218,8 +218,13 @@ def main():
         mb = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mb)
         with contextlib.redirect_stdout(io.StringIO()):          # bench.py prints ONE line
-            secondary = {"svd_unet_14x576x1024_cfg_step": mb.svd(), "dynamicrafter1024_unet_16x576x1024_cfg_step": mb.unet(),
+            from motionrag_amd import workloads as W
+            dcnet = W.dynamicrafter1024_unet(dev)
+            secondary = {"svd_unet_14x576x1024_cfg_step": mb.svd(),
+                         "dynamicrafter1024_unet_16x576x1024_cfg_step": mb.unet("bf16", dcnet),
+                         "dynamicrafter1024_unet_16x576x1024_cfg_step_fp8_attention": mb.unet("fp8", dcnet),     # BASELINE config #5, same weights / inputs
                          "retrieval_top12_768d": mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1)))}
+            del dcnet
 
     if world > 1:
         import torch.distributed as dist

@@ -276,18 +276,47 @@ class CogVideoXDDIMScheduler:
         return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a), float(b)
 
 
-class CogVideoXImageToVideoCTPipeline:
-    """Hot-path mirror of src/projects/cogvideox/pipeline.py:92-130 (+ :46-57, :80-89).
+class CogVideoXPipelineOutput:
+    """what diffusers' pipeline returns: `.frames`, and `output[0]` is `.frames` too (the reference indexes it: cogvideox/module.py:211)"""
 
-    `text_encoder` / `vae` are optional third-party callables; without them the caller passes
-    `prompt_embeds` / `negative_prompt_embeds` [b, 226, 4096] and `image_latents` [b, F, 16, H/8, W/8].
-    """
+    def __init__(self, frames):
+        self.frames = frames
 
-    def __init__(self, transformer: CogVideoXTransformer3DModel, scheduler: CogVideoXDDIMScheduler, condition_transformer=None,
-                 text_encoder=None, vae=None):
+    def __getitem__(self, i):
+        return (self.frames,)[i]
+
+    def __iter__(self):
+        return iter((self.frames,))
+
+
+def _model_device(m) -> torch.device:
+    return next(m.parameters()).device
+
+
+class CogVideoXImageToVideoActionPipeline:
+    """Stage-1 pipeline (src/projects/cogvideox/pipeline.py:13-89): motion tokens of the k retrieved reference clips from a frozen
+    `action_embedder`, fused over k by `condition_fusion` (HIP kernel), projected by `action_proj_model`, injected through the rope hook.
+
+    Mirrors the reference's constructor and call surface.  The diffusers base class it inherits there (CogVideoXImageToVideoPipeline 0.32.2,
+    third-party) is restated in `__call__` / `denoise`; `tokenizer` + `text_encoder` (T5) and `vae` are third-party modules the caller supplies
+    -- duck-typed: `text_encoder(tokenizer(...).input_ids)[0]` or, without a tokenizer, `text_encoder(list_of_str) -> [b, 226, 4096]`;
+    `vae.encode(x[b, 3, 1, H, W])` -> `.latent_dist.sample(generator)` / `.sample()` / tensor, `vae.decode(z[b, 16, F, h, w])` -> `.sample` /
+    tensor, `vae.config.scaling_factor` (0.7 for CogVideoX-5B-I2V)."""
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer: CogVideoXTransformer3DModel = None, scheduler=None,
+                 action_embedder=None, action_proj_model=None, ref_fusion_type: str = "mean"):
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
         self.transformer, self.scheduler = transformer, scheduler
-        self.condition_transformer, self.text_encoder, self.vae = condition_transformer, text_encoder, vae
+        self.action_embedder, self.action_proj_model = action_embedder, action_proj_model
+        self.ref_fusion_type = ref_fusion_type
         self._rope_cache = {}
+
+    @property
+    def _execution_device(self):
+        return _model_device(self.transformer)
+
+    def set_progress_bar_config(self, **_):          # diffusers API used by module.py:279
+        return None
 
     def _prepare_rotary_positional_embeddings(self, frames: int, gh: int, gw: int, device):
         """pipeline.py:46-57: returns ((cos, sin), action_emb)"""
@@ -295,14 +324,64 @@ class CogVideoXImageToVideoCTPipeline:
         key = (frames, gh, gw, str(device))
         if key not in self._rope_cache:
             cos, sin = get_3d_rotary_pos_embed(64, frames, gh, gw)
-            self._rope_cache[key] = (cos.to(device), sin.to(device))
+            self._rope_cache = {key: (cos.to(device), sin.to(device))}        # single slot: a pipeline works on one geometry at a time
         return self._rope_cache[key], self.action_emb
 
-    def prepare_action_embeddings(self, ref_videos: torch.Tensor, metadata=None, do_classifier_free_guidance: bool = False, image=None, **_):
-        """pipeline.py:117-130"""
-        image = image.to(ref_videos.device, ref_videos.dtype)
-        batch_ = {"ref_videos": ref_videos, "video": image[:, None].expand(-1, ref_videos.size(2), -1, -1, -1)}
-        return self.condition_transformer.predict(batch_, do_classifier_free_guidance=do_classifier_free_guidance)
+    def prepare_action_embeddings(self, ref_videos: torch.Tensor, metadata, do_classifier_free_guidance: bool = False, *args, **kwargs):
+        """pipeline.py:59-78: [b, k, f, c, h, w] -> [b or 2b, t, c]"""
+        from .cama import condition_fusion
+        b, k = ref_videos.shape[:2]
+        emb = self.action_embedder(ref_videos.reshape(b * k, *ref_videos.shape[2:]))
+        emb = emb.view(b, k, *emb.shape[1:])
+        emb = condition_fusion(emb, self.ref_fusion_type, weight=[m["ref_video_distance"] for m in metadata] if self.ref_fusion_type == "weight" else None)
+        if do_classifier_free_guidance:
+            uncond = self.action_embedder(torch.zeros_like(ref_videos[:, 0]))
+            if emb.shape[1:] != uncond.shape[1:]:
+                raise ValueError("ref_fusion_type 'concat' changes the token count: the unconditional branch cannot be concatenated (as in the reference)")
+            emb = torch.cat([uncond.to(emb.dtype), emb], dim=0)
+        return self.action_proj_model(emb)
+
+    # ---- pieces of diffusers' CogVideoXImageToVideoPipeline.__call__ the loop needs ----
+    def encode_prompt(self, prompt, negative_prompt, prompt_embeds=None, negative_prompt_embeds=None, max_sequence_length: int = 226):
+        def enc(texts):
+            if self.text_encoder is None:
+                raise ValueError("pass prompt_embeds / negative_prompt_embeds or a text_encoder")
+            if self.tokenizer is None:
+                return self.text_encoder(texts)
+            ids = self.tokenizer(texts, padding="max_length", max_length=max_sequence_length, truncation=True, add_special_tokens=True,
+                                 return_tensors="pt").input_ids
+            return self.text_encoder(ids.to(self._execution_device))[0]
+        if prompt_embeds is None:
+            prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+            prompt_embeds = enc(prompt)
+        if negative_prompt_embeds is None:
+            b = prompt_embeds.shape[0]
+            neg = negative_prompt if negative_prompt is not None else ""
+            neg = [neg] * b if isinstance(neg, str) else list(neg)
+            negative_prompt_embeds = enc(neg)
+        return prompt_embeds, negative_prompt_embeds
+
+    def _vae_scale(self) -> float:
+        return float(getattr(getattr(self.vae, "config", None), "scaling_factor", 0.7))
+
+    def encode_image_latents(self, image: torch.Tensor, lat_frames: int, generator=None) -> torch.Tensor:
+        """image [b, 3, H, W] in [0, 1] -> [b, F, 16, H/8, W/8]: VAE latents of the first frame, zero-padded to F latent frames"""
+        x = (image.to(torch.float32) * 2.0 - 1.0).unsqueeze(2)                     # diffusers video_processor.preprocess: [0, 1] -> [-1, 1]
+        enc = self.vae.encode(x.to(self._execution_device))
+        if hasattr(enc, "latent_dist"):
+            enc = enc.latent_dist.sample(generator)
+        elif hasattr(enc, "sample") and callable(enc.sample):
+            enc = enc.sample()
+        z = enc * self._vae_scale()                                                 # [b, 16, 1, h, w]
+        z = z.permute(0, 2, 1, 3, 4)                                                # [b, 1, 16, h, w]
+        pad = torch.zeros(z.shape[0], lat_frames - 1, *z.shape[2:], dtype=z.dtype, device=z.device)
+        return torch.cat([z, pad], dim=1)
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        z = latents.permute(0, 2, 1, 3, 4).to(torch.float32) / self._vae_scale()    # [b, 16, F, h, w]
+        out = self.vae.decode(z)
+        out = out.sample if hasattr(out, "sample") and not callable(out.sample) else out
+        return out                                                                  # [b, 3, f, H, W] in [-1, 1]
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
@@ -325,29 +404,89 @@ class CogVideoXImageToVideoCTPipeline:
         return latents
 
     @torch.no_grad()
-    def __call__(self, ref_videos: torch.Tensor = None, metadata=None, *, image=None, prompt_embeds=None, negative_prompt_embeds=None,
-                 image_latents=None, latents=None, num_inference_steps: int = 50, guidance_scale: float = 6.0, num_frames: int = 49,
-                 height: int = 480, width: int = 720, generator: Optional[torch.Generator] = None, output_type: str = "latent", **kwargs):
-        """pipeline.py:80-89: action embeddings first, then the denoising loop."""
-        dev = next(self.transformer.parameters()).device
-        action_emb = self.prepare_action_embeddings(ref_videos, metadata, do_classifier_free_guidance=True, image=image)
-        if prompt_embeds is None:
-            if self.text_encoder is None:
-                raise ValueError("pass prompt_embeds / negative_prompt_embeds or a text_encoder callable")
-            prompt_embeds = self.text_encoder(kwargs["prompt"])
-            negative_prompt_embeds = self.text_encoder(kwargs.get("negative_prompt", [""] * len(kwargs["prompt"])))
-        pe = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dev, torch.bfloat16).contiguous()
-        b = prompt_embeds.shape[0]
+    def __call__(self, ref_videos: torch.Tensor = None, metadata=None, *args, image=None, prompt=None, negative_prompt=None, height: int = 480,
+                 width: int = 720, num_frames: int = 49, num_inference_steps: int = 50, guidance_scale: float = 6.0, generator=None,
+                 latents=None, prompt_embeds=None, negative_prompt_embeds=None, image_latents=None, output_type: str = "pil",
+                 max_sequence_length: int = 226, return_dict: bool = True, **kwargs):
+        """pipeline.py:80-89: motion tokens first (CFG on), then the body of diffusers' CogVideoXImageToVideoPipeline.__call__ with
+        do_classifier_free_guidance (guidance_scale > 1 in every shipped config): `pipe(prompt=, image=, negative_prompt=, output_type='pt',
+        ref_videos=, metadata=, num_frames=, num_inference_steps=, guidance_scale=, ...)` -> output with `.frames` [b, f, c, H, W] in [0, 1]
+        ('pt'), or the final latents [b, F, 16, h, w] ('latent')."""
+        if args:
+            raise TypeError("pass the diffusers arguments by keyword (prompt=, image=, ...)")
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("the motion-injection path runs with classifier-free guidance (uncond motion tokens first, module.py:329)")
+        dev = self._execution_device
+        self.action_emb = self.prepare_action_embeddings(ref_videos, metadata, do_classifier_free_guidance=True, image=image, **kwargs)
+        pos, neg = self.encode_prompt(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, max_sequence_length)
+        pe = torch.cat([neg, pos], dim=0).to(dev, torch.bfloat16).contiguous()          # [negative ; positive]
+        b = pos.shape[0]
         F = (num_frames - 1) // 4 + 1
         if image_latents is None:
             if self.vae is None:
-                raise ValueError("pass image_latents or a vae callable")
-            image_latents = self.vae.encode_image(image, F)
+                raise ValueError("pass image_latents or a vae")
+            image_latents = self.encode_image_latents(image, F, generator)
         if latents is None:
-            noise = torch.randn(b, F, 16, height // 8, width // 8, generator=generator, dtype=torch.float32)   # CPU-seeded (SURVEY App. D.3)
-            latents = noise.to(dev, torch.bfloat16)
-        latents = self.denoise(latents.contiguous(), image_latents.to(dev, torch.bfloat16).contiguous(), pe, action_emb, num_inference_steps,
-                               guidance_scale)
-        if output_type == "latent" or self.vae is None:
-            return (latents,)
-        return (self.vae.decode(latents),)
+            noise = torch.randn(b, F, self.transformer.cfg["out_channels"], height // 8, width // 8, generator=generator,
+                                dtype=torch.float32)                                     # CPU-seeded (SURVEY App. D.3)
+            latents = noise.to(dev, torch.bfloat16)                                      # DDIM: init_noise_sigma == 1
+        latents = self.denoise(latents.to(dev, torch.bfloat16).contiguous(), image_latents.to(dev, torch.bfloat16).contiguous(), pe,
+                               self.action_emb, num_inference_steps, guidance_scale)
+        if output_type == "latent":
+            frames = latents
+        else:
+            if self.vae is None:
+                raise ValueError("output_type != 'latent' needs a vae")
+            video = self.decode_latents(latents)                                         # [b, 3, f, H, W] in [-1, 1]
+            frames = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)                # video_processor.postprocess_video(output_type='pt')
+            if output_type not in ("pt", "np"):
+                raise NotImplementedError("output_type 'pt', 'np' or 'latent' (PIL conversion is host-side glue outside the hot path)")
+            if output_type == "np":
+                frames = frames.float().cpu().numpy()
+        return CogVideoXPipelineOutput(frames) if return_dict else (frames,)
+
+
+class CogVideoXImageToVideoCTPipeline(CogVideoXImageToVideoActionPipeline):
+    """Stage-2 pipeline (pipeline.py:92-130): motion tokens predicted by the CAMA `condition_transformer` from the references + the
+    conditioning image.  Keyword construction mirrors the reference; `CogVideoXImageToVideoCTPipeline(transformer, scheduler,
+    condition_transformer=...)` (round-1 positional form) is kept."""
+
+    def __init__(self, *args, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None, condition_transformer=None):
+        if args:                                                                     # (transformer, scheduler[, condition_transformer])
+            transformer, scheduler = args[0], args[1]
+            condition_transformer = args[2] if len(args) > 2 else condition_transformer
+        super().__init__(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, transformer=transformer, scheduler=scheduler)
+        self.condition_transformer = condition_transformer
+
+    def prepare_action_embeddings(self, ref_videos: torch.Tensor, metadata=None, do_classifier_free_guidance: bool = False, *args, **kwargs):
+        """pipeline.py:117-130"""
+        image = kwargs.get("image").to(ref_videos.device, ref_videos.dtype)
+        batch_ = {"ref_videos": ref_videos, "video": image[:, None].expand(-1, ref_videos.size(2), -1, -1, -1)}
+        return self.condition_transformer.predict(batch_, do_classifier_free_guidance=do_classifier_free_guidance)
+
+
+def set_attention_processors(transformer: CogVideoXTransformer3DModel, adapter_modules, cross_attention_dim: int, scale: float = 1.0) -> None:
+    """cogvideox/module.py:163-175: install `APAdapterCogVideoXAttnProcessor2_0` on the processor names listed in `adapter_modules`
+    (`transformer_blocks.{i}.attn1.processor`, configs/cogvideox/MotionRAG_open.yml), keep the others."""
+    hidden = transformer.cfg["dim"]
+    attn = {}
+    for name, orig in transformer.attn_processors.items():
+        attn[name] = APAdapterCogVideoXAttnProcessor2_0(hidden, cross_attention_dim, scale=scale) if name in adapter_modules else orig
+    transformer.set_attn_processor(attn)
+
+
+def eval_pipeline(pipe, image, positive_prompt, negative_prompt, dtype, ref_videos, metadata, *args, **kwargs) -> torch.Tensor:
+    """CogVideoX5BAction.eval_pipeline (cogvideox/module.py:197-223): image in [-1, 1] -> video [b, 16, c, H, W] in [-1, 1]."""
+    image = image / 2 + 0.5                                                          # denormalize
+    sample_method = kwargs.pop("sample_method", "first")
+    frames = pipe(prompt=positive_prompt, image=image, negative_prompt=negative_prompt, output_type="pt", ref_videos=ref_videos,
+                  metadata=metadata, *args, **kwargs)
+    video = frames[0]
+    if sample_method == "first":
+        video = video[:, :16, ...]                                                   # use only the first 16 frames
+    elif sample_method == "uniform":
+        frame_idx = torch.linspace(0, video.shape[1] - 1, 16).round().long()
+        video = video[:, frame_idx.to(video.device), ...]
+    elif sample_method is not None:
+        raise ValueError(f"Unknown sample method: {sample_method}")
+    return video * 2 - 1                                                             # normalize

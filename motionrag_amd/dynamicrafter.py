@@ -99,8 +99,20 @@ def _lin_w(m) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------------ attention
+def set_attention_precision(module: nn.Module, precision: str = "bf16") -> nn.Module:
+    """'bf16' (the reference's precision) or 'fp8': spatial self-attention (attention.py:189 with context None) of every CrossAttention under
+    `module` runs on the e4m3 MFMA path where the shape allows (S % 128 == 0, S >= 512); everything else stays bf16."""
+    if precision not in ("bf16", "fp8"):
+        raise ValueError("precision must be 'bf16' or 'fp8'")
+    for m in module.modules():
+        if isinstance(m, CrossAttention):
+            m.attention_precision = precision
+    return module
+
+
 class CrossAttention(nn.Module):
     """attention.py:37-223 (`efficient_forward` path: relative_position=False)."""
+    attention_precision = "bf16"
 
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, relative_position=False, temporal_length=None,
                  video_length=None, image_cross_attention=False, image_cross_attention_scale=1.0, image_cross_attention_scale_learnable=False,
@@ -151,7 +163,8 @@ class CrossAttention(nn.Module):
             qkv = ops.linear(x, w)
             if temporal is None:
                 q5 = qkv.view(Nb, L, 3, H, 64)
-                out = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2])
+                # BASELINE config "fp8 MFMA attention path": opt-in per module (set_attention_precision), long spatial sequences only
+                out = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], fp8=self.attention_precision == "fp8" and ops.fp8_attention_supported(L, L))
             else:
                 b, t, hw = temporal
                 out = torch.empty(Nb, L, inner, dtype=torch.bfloat16, device=x.device)

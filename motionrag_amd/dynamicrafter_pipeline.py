@@ -20,6 +20,8 @@ from typing import List, Optional
 
 import torch
 
+from . import ops
+
 from .dynamicrafter import DDIMSampler, DynamiCrafterDenoiser
 
 
@@ -59,12 +61,14 @@ def image_guided_synthesis(model, prompts, videos, noise_shape, n_samples=1, ddi
             b, k = ref_videos.shape[:2]
             action_emb = model.action_embedder(ref_videos.reshape(b * k, *ref_videos.shape[2:]))
             action_emb = action_emb.reshape(b, k, *action_emb.shape[1:])
+            # fusion over the k references on the HIP kernel (mrag_weighted_sum_bf16: fp32 weights / accumulation), not torch arithmetic
+            action_emb = action_emb.to(device=device, dtype=torch.bfloat16).contiguous()
             if ref_fusion_type == "mean":
-                action_emb = action_emb.mean(dim=1)
-            elif ref_fusion_type == "weight":
-                distance = torch.tensor(metadata["ref_video_distance"], device=action_emb.device)
-                weight = (1 - distance) / (1 - distance).sum(dim=0, keepdim=True)
-                action_emb = (action_emb * weight[..., None, None]).sum(dim=1)
+                action_emb = ops.weighted_sum(action_emb, None, div=float(k))
+            elif ref_fusion_type == "weight":                                                     # :203-206: ONE distance vector [k] for the batch
+                distance = torch.as_tensor(metadata["ref_video_distance"], dtype=torch.float32, device=device)
+                weight = (1 - distance) / (1 - distance).sum(dim=0, keepdim=True)                 # k numbers (host-sized arithmetic, as :205)
+                action_emb = ops.weighted_sum(action_emb, weight.view(1, k).expand(b, k).contiguous())
             elif ref_fusion_type == "concat":
                 action_emb = action_emb.reshape(b, -1, action_emb.shape[-1])
             elif ref_fusion_type is None or ref_fusion_type == "top1":

@@ -162,3 +162,70 @@ class RAGDatabase:
         """rag.py:63-80"""
         return self.vector_search(text, vector_column_name="text_embedding", top_k=top_k, table=table, where=where, select=select,
                                   nprobes=nprobes, refine_factor=refine_factor, output_format=output_format)
+
+
+# ---------------------------------------------------------------------------------------------- callers either side of the search
+def attach_ref_videos(annotations: List[dict], db: "RAGDatabase", ref_video_num: int = 9, *, ref_video_type: str = "rag_text",
+                      chunk: int = 256) -> List[dict]:
+    """The RAG fan-out of src/data/datamodule.py:225-265 (`ref_video_type == 'rag_text'`): every annotation searches with its own
+    `text_embedding`, over-fetches `ref_video_num + 3` rows (:234), excludes its own video (`where = 'video != "<self>"'`, :235) and keeps
+    `['video', 'start_sec', 'end_sec']` (+ `_distance`) in `anno['ref_videos']`.  The reference runs one LanceDB query per annotation in a
+    64-process pool; here the queries of a chunk are ONE batched top-k launch."""
+    if ref_video_type != "rag_text":
+        raise NotImplementedError("only the shipped `ref_video_type: rag_text` (configs/*/MotionRAG_open.yml) runs on the GPU scan")
+    for i in range(0, len(annotations), chunk):
+        part = annotations[i:i + chunk]
+        q = np.stack([np.asarray(a["text_embedding"], dtype=np.float32) for a in part])
+        res = db.text_search_batch(q, top_k=ref_video_num + 3, where=[f'video != "{a["video"]}"' for a in part], select=["video", "start_sec", "end_sec"])
+        for a, r in zip(part, res):
+            a["ref_videos"] = r
+    return annotations
+
+
+def get_ref_videos(video_info: dict, video: torch.Tensor, load_clip: Callable[[dict], torch.Tensor], ref_video_num: int = 9,
+                   video_length: Optional[int] = None, uncond_video_ratio: float = 0.0, rng=None):
+    """The consumer contract of src/data/dataset.py:285-312 (`VideoDataset.get_ref_videos`): video [1, T, C, H, W] ->
+    (ref_videos [K, T, C, H, W], distance list).  The first `ref_video_num` retrieved rows are used (most similar first); a reference that
+    IS the target clip re-uses `video`; a dropped (unconditional-training) reference or one whose clip fails to load leaves a ZERO video and
+    distance 1.0 (:292, :306-310).  `load_clip(row) -> [1, T, C, H, W]` stands for the dataset's video reader (out of scope)."""
+    import random as _random
+    rng = rng or _random
+    T = video_length if video_length is not None else video.shape[1]
+    ref_videos = torch.zeros(ref_video_num, T, *video.shape[2:], dtype=video.dtype, device=video.device)
+    distance: List[float] = []
+    for i, v in enumerate(video_info.get("ref_videos", [])[:ref_video_num]):
+        if rng.random() > uncond_video_ratio:
+            try:
+                ref = video if v["video"] == video_info["video"] else load_clip(v)
+                ref_videos[i] = ref
+                distance.append(v["_distance"])
+            except Exception as e:          # noqa: BLE001 -- the reference swallows reader errors the same way
+                print(f"Rag read video Error: {e}")
+                distance.append(1.0)
+        else:
+            distance.append(1.0)
+    return ref_videos, distance
+
+
+_ADJ = ("slow", "fast", "shaky", "smooth", "sudden", "gentle", "circular", "zigzag", "rising", "falling")
+_NOUN = ("camera", "person", "dog", "car", "bird", "wave", "hand", "crowd", "leaf", "train")
+_VERB = ("pans left", "pans right", "zooms in", "zooms out", "walks forward", "turns around", "jumps", "rotates", "drifts", "stops")
+
+
+def synthetic_captions(n: int = 10000) -> List[dict]:
+    """BASELINE config #1 / SURVEY 8d: `n` synthetic motion captions `clip {i}: a {adj} {noun} {verb}` in the reference's annotation schema"""
+    return [{"motion_caption": f"clip {i}: a {_ADJ[i % 10]} {_NOUN[(i // 10) % 10]} {_VERB[(i // 100) % 10]}", "id": i, "video": f"clip_{i:06d}.mp4",
+             "start_sec": 0.0, "end_sec": 4.0} for i in range(n)]
+
+
+def hash_embedder(dim: int = 768) -> Callable[[str], np.ndarray]:
+    """Offline stand-in for sentence-transformers' gte-base-en-v1.5 (third-party weights, no network): a unit-normalised N(0, 1) vector
+    seeded by the caption's hash -- deterministic, `dim`-dimensional, fp32."""
+    import hashlib
+
+    def embed(text: str) -> np.ndarray:
+        seed = int.from_bytes(hashlib.sha256(text.encode("utf-8")).digest()[:8], "little")
+        v = np.random.default_rng(seed).standard_normal(dim).astype(np.float32)
+        return v / np.linalg.norm(v)
+
+    return embed

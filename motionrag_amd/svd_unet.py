@@ -119,7 +119,12 @@ class SpatioTemporalResBlock(nn.Module):
 
 class AttnProcessor2_0:
     """plain scaled-dot-product processor (diffusers' default) on the gfx950 kernels.  `temporal=(b, f, hw)`: rows are ordered
-    (b, f, hw) and attention runs over f for every (b, hw)."""
+    (b, f, hw) and attention runs over f for every (b, hw).  `precision='fp8'`: long spatial self-attention on the e4m3 MFMA path."""
+
+    def __init__(self, precision: str = "bf16"):
+        if precision not in ("bf16", "fp8"):
+            raise ValueError("precision must be 'bf16' or 'fp8'")
+        self.precision = precision
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, temporal=None, **_):
         x = hidden_states
@@ -130,7 +135,7 @@ class AttnProcessor2_0:
             qkv = ops.linear(x, w)
             if temporal is None:
                 q5 = qkv.view(Nb, L, 3, H, 64)
-                o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2])
+                o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], fp8=self.precision == "fp8" and ops.fp8_attention_supported(L, L))
             else:
                 b, f, hw = temporal
                 o = torch.empty(Nb, L, C, dtype=torch.bfloat16, device=x.device)

@@ -109,8 +109,11 @@ def test_fp8_attention_recentre_and_scale_ranges(hip):
     for h in range(H):
         sl = slice(64 * h, 64 * h + 64)
         assert rel_l2(got[..., sl], want[..., sl]) <= 0.08, h
+        if h == 0:
+            continue          # head 0's first tile is depressed on purpose: many of its rows re-centre later (by 16-key partial sums, which the
+                              # emulation does not model) -> fp32 check only
         rows = ok[0, :, h]
-        assert rel_l2(got[0, rows][:, sl], emu[0, rows][:, sl]) <= 0.012, h
+        assert rows.float().mean().item() > 0.95 and rel_l2(got[0, rows][:, sl], emu[0, rows][:, sl]) <= 0.012, h
     assert rel_l2(got[:, 77, :64], want[:, 77, :64]) <= 0.08
 
 

@@ -1,0 +1,236 @@
+"""The reference's PIPELINE protocol driven end to end on the GPU with stub third-party modules (text encoder, VAEs, CLIP image
+encoder, frozen action embedder): `pipe(prompt=, image=, negative_prompt=, output_type='pt', ref_videos=, metadata=, ...)`, `.frames` /
+`frames[0]`, `eval_pipeline` post-processing (first-16 / uniform sampling, `* 2 - 1`), the stage-1 Action pipelines with `condition_fusion`,
+and the retrieval consumer contract.  References: src/projects/cogvideox/pipeline.py:13-130, cogvideox/module.py:163-223,
+src/projects/svd/pipelines/pipeline.py:25-160, svd/module.py:145-191, src/data/dataset.py:285-312, src/data/datamodule.py:225-265."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_models import _small_dit, close
+from test_oracle_golden import svd_tiny
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class StubText:
+    """T5 stand-in: deterministic [b, 10, 64] embeddings from the strings"""
+
+    def __call__(self, texts):
+        out = []
+        for t in texts:
+            g = torch.Generator().manual_seed(sum(map(ord, t)) + 7)
+            out.append(torch.randn(10, 64, generator=g))
+        return torch.stack(out).to(DEV, torch.bfloat16)
+
+
+class StubVAE:
+    """8x spatial / 4x temporal toy VAE: encode = 8x8 average pool of the 3 channels tiled to C latent channels; decode = nearest upsample"""
+
+    class Cfg:
+        scaling_factor = 0.7
+
+    config = Cfg()
+
+    def __init__(self, c_lat):
+        self.c = c_lat
+
+    def encode(self, x):                      # [b, 3, 1, H, W] in [-1, 1]
+        z = torch.nn.functional.avg_pool2d(x[:, :, 0].float(), 8)                     # [b, 3, h, w]
+        return z.repeat(1, (self.c + 2) // 3, 1, 1)[:, : self.c].unsqueeze(2)
+
+    def decode(self, z):                      # [b, C, F, h, w] -> [b, 3, 4 (F - 1) + 1, 8 h, 8 w]
+        v = torch.tanh(z[:, :3].float())
+        v = torch.nn.functional.interpolate(v, scale_factor=(1, 8, 8), mode="nearest")
+        idx = torch.arange(4 * (v.shape[2] - 1) + 1, device=v.device) // 4
+        return v[:, :, idx]
+
+
+class StubCAMA:
+    """condition_transformer stand-in with the CAMA protocol: predict(batch, do_classifier_free_guidance) -> [2b, 25, 64], uncond first"""
+
+    def __init__(self):
+        self.calls = []
+
+    def predict(self, batch, do_classifier_free_guidance=False):
+        self.calls.append({k: tuple(v.shape) for k, v in batch.items()})
+        b = batch["ref_videos"].shape[0]
+        g = torch.Generator().manual_seed(5)
+        cond = torch.randn(b, 25, 64, generator=g) + batch["video"].float().mean().cpu()
+        un = torch.randn(b, 25, 64, generator=g)
+        return torch.cat([un, cond] if do_classifier_free_guidance else [cond]).to(DEV, torch.bfloat16)
+
+
+def _pipe_inputs(b=1):
+    g = torch.Generator().manual_seed(21)
+    image = torch.rand(b, 3, 64, 96, generator=g) * 2 - 1                             # eval_pipeline takes [-1, 1]
+    ref_videos = torch.randn(b, 9, 8, 3, 16, 16, generator=g).to(DEV, torch.bfloat16)
+    metadata = [{"ref_video_distance": (0.1 + 0.08 * torch.arange(9)).tolist()} for _ in range(b)]
+    return image.to(DEV), ref_videos, metadata
+
+
+def test_cogvideox_ct_pipeline_reference_call_surface(hip):
+    from motionrag_amd import cogvideox as cvx
+    cfg, sd, dit = _small_dit()
+    cama = StubCAMA()
+    pipe = cvx.CogVideoXImageToVideoCTPipeline(tokenizer=None, text_encoder=StubText(), vae=StubVAE(8), transformer=dit,
+                                               scheduler=cvx.CogVideoXDDIMScheduler(), condition_transformer=cama)
+    pipe.set_progress_bar_config(disable=True)
+    image, ref_videos, metadata = _pipe_inputs()
+    kw = dict(num_frames=9, num_inference_steps=2, guidance_scale=6.0, height=64, width=96)
+    out = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="pt", ref_videos=ref_videos, metadata=metadata,
+               generator=torch.Generator().manual_seed(3), **kw)
+    assert out.frames.shape == (1, 9, 3, 64, 96) and out[0] is out.frames
+    assert 0.0 <= out.frames.min().item() and out.frames.max().item() <= 1.0
+    assert cama.calls[-1] == {"ref_videos": (1, 9, 8, 3, 16, 16), "video": (1, 8, 3, 64, 96)}       # image repeated over the reference clip length (:127-128)
+    # the same call, latent output, equals the hot loop driven by hand with the same noise, embeddings and image latents
+    lat = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", ref_videos=ref_videos,
+               metadata=metadata, generator=torch.Generator().manual_seed(3), **kw).frames
+    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3)).to(DEV, torch.bfloat16)
+    te = StubText()
+    pe = torch.cat([te(["blurry"]), te(["a dog runs"])])
+    il = pipe.encode_image_latents(image / 2 + 0.5, 3).to(DEV, torch.bfloat16)
+    assert il.shape == (1, 3, 8, 8, 12) and il[:, 1:].abs().max().item() == 0               # first frame's latents, zero-padded
+    ae = cama.predict({"ref_videos": ref_videos, "video": image[:, None].expand(-1, 8, -1, -1, -1).to(torch.bfloat16)}, True)
+    want = pipe.denoise(noise.clone(), il.contiguous(), pe.contiguous(), ae, num_inference_steps=2, guidance_scale=6.0)
+    assert torch.equal(lat, want)
+    # eval_pipeline (module.py:197-223): denormalise the image, first-16 / uniform sampling, back to [-1, 1]
+    vid = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **kw)
+    assert vid.shape == (1, 9, 3, 64, 96) and torch.allclose(vid, out.frames * 2 - 1)
+    uni = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, sample_method="uniform",
+                            generator=torch.Generator().manual_seed(3), **dict(kw, num_frames=33))
+    assert uni.shape == (1, 16, 3, 64, 96)
+    with pytest.raises(ValueError):
+        cvx.eval_pipeline(pipe, image, ["x"], ["y"], torch.bfloat16, ref_videos, metadata, sample_method="bogus", **kw)
+
+
+def test_cogvideox_set_attention_processors_by_name(hip):
+    """cogvideox/module.py:163-175: adapters only on the listed processor names; state-dict keys as in Motion-Adapter.ckpt"""
+    from motionrag_amd import cogvideox as cvx
+    from motionrag_amd.attn_processor import APAdapterCogVideoXAttnProcessor2_0
+    dit = cvx.CogVideoXTransformer3DModel(num_layers=3, num_attention_heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                          max_text_seq_length=10, sample_frames=3, sample_height=8, sample_width=12)
+    cvx.set_attention_processors(dit, ["transformer_blocks.0.attn1.processor", "transformer_blocks.2.attn1.processor"], 64)
+    kinds = [isinstance(p, APAdapterCogVideoXAttnProcessor2_0) for p in dit.attn_processors.values()]
+    assert kinds == [True, False, True]
+    keys = set(dit.state_dict().keys())
+    assert "transformer_blocks.2.attn1.processor.to_q_ip.0.weight" in keys and "transformer_blocks.1.attn1.processor.to_q_ip.0.weight" not in keys
+
+
+def test_cogvideox_action_pipeline_condition_fusion(hip):
+    """stage 1 (pipeline.py:59-78): action_embedder over the (b k) clips -> condition_fusion over k (HIP kernel) -> uncond first -> action_proj_model"""
+    from motionrag_amd import cogvideox as cvx
+    from oracle import cama_ref
+    cfg, sd, dit = _small_dit()
+
+    class Embedder(torch.nn.Module):
+        def forward(self, clips):                     # [(b k), f, c, h, w] -> [(b k), 25, 64]
+            m = clips.float().mean(dim=(1, 2, 3, 4))
+            base = torch.linspace(-1, 1, 25 * 64, device=clips.device).view(1, 25, 64)
+            return (base * (1 + m.view(-1, 1, 1)) + m.view(-1, 1, 1)).to(torch.bfloat16)
+
+    proj = torch.nn.Identity()
+    image, ref_videos, metadata = _pipe_inputs(b=2)
+    for mode in ("mean", "weight", "top1"):
+        pipe = cvx.CogVideoXImageToVideoActionPipeline(text_encoder=StubText(), vae=StubVAE(8), transformer=dit, scheduler=cvx.CogVideoXDDIMScheduler(),
+                                                       action_embedder=Embedder(), action_proj_model=proj, ref_fusion_type=mode)
+        got = pipe.prepare_action_embeddings(ref_videos, metadata, do_classifier_free_guidance=True)
+        emb = Embedder()(ref_videos.reshape(18, 8, 3, 16, 16)).view(2, 9, 25, 64)
+        want = torch.cat([Embedder()(torch.zeros_like(ref_videos[:, 0])).float().cpu(),
+                          cama_ref.condition_fusion(emb.float().cpu(), mode, [m["ref_video_distance"] for m in metadata] if mode == "weight" else None)])
+        assert got.shape == (4, 25, 64)
+        assert ((got.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all(), mode
+    out = pipe(prompt=["a", "b"], image=image / 2 + 0.5, negative_prompt=["", ""], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+               num_frames=9, num_inference_steps=1, guidance_scale=3.0, height=64, width=96, generator=torch.Generator().manual_seed(1))
+    assert out.frames.shape == (2, 3, 8, 8, 12) and torch.isfinite(out.frames.float()).all()
+
+
+def test_svd_ct_pipeline_matches_oracle_loop(hip):
+    """SVDCTPipeline.__call__ (pipeline.py:147-160) + the restated diffusers body: 2 Euler steps with per-frame guidance on the reduced-width
+    UNet against the fp32 oracle loop (svd_ref.unet_forward + euler_cfg_step) fed the same noise / embeddings; then eval_pipeline's
+    `.frames[:, :16] * 2 - 1`"""
+    from motionrag_amd import svd, svd_unet
+    from oracle import svd_ref
+    unet, cfg, inp = svd_tiny()
+    sdict = {k: v.float() for k, v in unet.state_dict().items()}
+    unet = unet.to(DEV)
+    b, Fr, h, w = 1, 4, 16, 16
+
+    class ImgEnc:
+        def __call__(self, x):                        # [b, 3, H, W] -> [b, 64]
+            return torch.tanh(x.float().mean(dim=(2, 3)).repeat(1, 22)[:, :64]).to(torch.bfloat16)
+
+    class VAE:
+        class Cfg:
+            scaling_factor = 0.18215
+        config = Cfg()
+
+        def encode(self, x):
+            return torch.nn.functional.avg_pool2d(x.float(), 8).repeat(1, 2, 1, 1)[:, :4]
+
+        def decode(self, z, num_frames=None):
+            return torch.tanh(torch.nn.functional.interpolate(z[:, :3].float(), scale_factor=8, mode="nearest"))
+
+    cama = StubCAMA()
+    pipe = svd.SVDCTPipeline(vae=VAE(), image_encoder=ImgEnc(), unet=unet, scheduler=svd_unet.EulerDiscreteScheduler(), feature_extractor=None,
+                             condition_transformer=cama)
+    g = torch.Generator().manual_seed(8)
+    img255 = torch.rand(b, 3, 8 * h, 8 * w, generator=g) * 255.0
+    ref_videos = torch.randn(b, 9, 8, 3, 16, 16, generator=g).to(DEV, torch.bfloat16)
+    kw = dict(height=8 * h, width=8 * w, num_frames=Fr, num_inference_steps=2, min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=127,
+              noise_aug_strength=0.02)
+    got = pipe(image=img255, ref_videos=ref_videos, metadata=None, output_type="latent", generator=torch.Generator().manual_seed(9), **kw).frames
+    # ---- oracle loop on the same random stream
+    gen = torch.Generator().manual_seed(9)
+    img = img255 / 127.5 - 1.0
+    noise = torch.randn(img.shape, generator=gen)
+    sig = svd_ref.karras_sigmas(2)
+    lat = (torch.randn(b, Fr, 4, h, w, generator=gen) * float((sig[0] ** 2 + 1) ** 0.5)).to(torch.bfloat16).float()
+    emb = ImgEnc()(img).float().unsqueeze(1)
+    emb2 = torch.cat([torch.zeros_like(emb), emb])
+    act = cama.predict({"ref_videos": ref_videos, "video": img[:, None].expand(-1, 8, -1, -1, -1).to(DEV, torch.bfloat16)}, True).float().cpu()
+    z = VAE().encode((img + 0.02 * noise)).to(torch.bfloat16).float()
+    il = torch.cat([torch.zeros_like(z), z])[:, None].expand(-1, Fr, -1, -1, -1)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    gs = torch.linspace(1.0, 3.0, Fr)
+    for i in range(2):
+        s, sn = float(sig[i]), float(sig[i + 1])
+        scaled = (lat / (s * s + 1) ** 0.5).to(torch.bfloat16).float()
+        x = torch.cat([torch.cat([scaled, scaled]), il], dim=2)
+        v = svd_ref.unet_forward(sdict, cfg, x, torch.tensor(0.25 * np.log(s)), emb2, ids, act)
+        lat = svd_ref.euler_cfg_step(v[:b].double(), v[b:].double(), lat.double(), s, sn, gs.double()).float().to(torch.bfloat16).float()
+    close(got, lat, rel_l2=4e-2, atol_frac=0.12)
+    vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, ref_videos=ref_videos, metadata=None, generator=torch.Generator().manual_seed(9), **kw)
+    assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
+
+
+def test_retrieval_consumer_contract_and_fan_out(hip):
+    """datamodule.py:225-265 fan-out (`top_k = K + 3`, self-exclusion, select) as one batched launch, then dataset.py:285-312: first K rows,
+    `_distance` list, zero video + 1.0 for a failed or dropped reference"""
+    from motionrag_amd import rag
+    annos = rag.synthetic_captions(600)
+    embed = rag.hash_embedder(768)
+    emb = np.stack([embed(a["motion_caption"]) for a in annos])
+    db = rag.RAGDatabase.from_arrays(emb, rag.prepare_annotations(annos, "motion_caption", "openvid"))
+    for a, e in zip(annos, emb):
+        a["text_embedding"] = e
+    rag.attach_ref_videos(annos, db, ref_video_num=9, chunk=256)
+    a = annos[17]
+    assert len(a["ref_videos"]) == 12 and set(a["ref_videos"][0]) == {"video", "start_sec", "end_sec", "_distance"}
+    assert all(r["video"] != a["video"] for r in a["ref_videos"])
+    d = [r["_distance"] for r in a["ref_videos"]]
+    assert d == sorted(d)
+    video = torch.randn(1, 8, 3, 4, 4)
+
+    def load_clip(row):
+        if row["video"] == a["ref_videos"][2]["video"]:
+            raise IOError("missing file")
+        return torch.full((1, 8, 3, 4, 4), float(int(row["video"][5:11])))
+
+    refs, dist = rag.get_ref_videos(a, video, load_clip, ref_video_num=9)
+    assert refs.shape == (9, 8, 3, 4, 4) and len(dist) == 9
+    assert dist[2] == 1.0 and refs[2].abs().max().item() == 0 and dist[0] == a["ref_videos"][0]["_distance"]
+    assert refs[0, 0, 0, 0, 0].item() == float(int(a["ref_videos"][0]["video"][5:11]))
+    refs, dist = rag.get_ref_videos(a, video, load_clip, ref_video_num=9, uncond_video_ratio=1.0)        # all references dropped
+    assert dist == [1.0] * 9 and refs.abs().max().item() == 0

@@ -161,14 +161,17 @@ def norm():
 
 
 
-def unet():
-    """DynamiCrafter-1024 UNet + CAMA tokens, one CFG denoise step at 16x576x1024 (x [2, 8, 16, 72, 128]), random-init weights"""
-    from motionrag_amd import workloads as W
-    net = W.dynamicrafter1024_unet(DEV)
+def unet(precision="bf16", net=None):
+    """DynamiCrafter-1024 UNet + CAMA tokens, one CFG denoise step at 16x576x1024 (x [2, 8, 16, 72, 128]), random-init weights;
+    precision='fp8': spatial self-attention on the e4m3 MFMA path (BASELINE config #5)"""
+    from motionrag_amd import workloads as W, dynamicrafter as dc
+    net = W.dynamicrafter1024_unet(DEV) if net is None else net
+    dc.set_attention_precision(net, precision)
     x, ts, ctx, fs = W.dynamicrafter1024_inputs(DEV)
     dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=3, warm=1)
+    dc.set_attention_precision(net, "bf16")
     T = W.DC1024_STEP_TFLOP
-    print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024): {dt*1e3:.1f} ms  {T/dt:.0f} TFLOP/s of {T} TFLOP algorithmic  -> {16/dt:.1f} frames/s")
+    print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024, attention {precision}): {dt*1e3:.1f} ms  {T/dt:.0f} TFLOP/s of {T} TFLOP algorithmic  -> {16/dt:.1f} frames/s")
     return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": T, "tflops_per_s": round(T / dt), "frames_per_s": round(16 / dt, 1)}
 
 

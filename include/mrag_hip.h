@@ -138,7 +138,8 @@ enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pa
        MRAG_ATTN_TUNE_NW4 = 4,       /* 4-wave workgroups for long sequences                       */
        MRAG_ATTN_TUNE_LEGACY = 8,    /* long unmasked sequences through the 32x32x16 kernel        */
        MRAG_ATTN_TUNE_QB4 = 16,      /* attn16 with 64 query rows per wave (no key-split tail)     */
-       MRAG_ATTN_TUNE_QB4W4 = 32 };  /* the same in 4-wave workgroups, two per CU                  */
+       MRAG_ATTN_TUNE_QB4W4 = 32,    /* the same in 4-wave workgroups, two per CU                  */
+       MRAG_ATTN_TUNE_SUBS2 = 64 };  /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 

@@ -165,6 +165,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         Lt = encoder_hidden_states.shape[1]
         Nv = F * (H // p) * (W // p)
         S = Lt + Nv
+        if S > self.patch_embed.pos_embedding.shape[1] or Lt != cfg["max_text"]:
+            raise ValueError(f"{Lt} text + {Nv} video tokens do not fit the model's positional table ({cfg['max_text']} text rows + "
+                             f"{self.patch_embed.pos_embedding.shape[1] - cfg['max_text']} video rows: sample_frames / sample_height / sample_width)")
         (rope, ip) = image_rotary_emb if (isinstance(image_rotary_emb, tuple) and isinstance(image_rotary_emb[0], tuple)) else (image_rotary_emb, None)
         mod_w, mod_b = self._mod_weights()
 

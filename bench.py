@@ -34,9 +34,11 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (SVD / DynamiCrafter UNet CFG step, retrieval, CAMA), which are measured "
                     "after the timed region at N = 1 (~30 s) and reported under `secondary_workloads`; for profiling runs that should hold only the headline launches")
-    ap.add_argument("--shard", choices=["clips", "sequence"], default="clips",
+    ap.add_argument("--shard", choices=["clips", "sequence", "cfg"], default="clips",
                     help="clips (judged default): one clip per rank, weak scaling; sequence: ONE clip, its token sequence sharded over the ranks "
-                         "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling")
+                         "with a K/V all-gather per block (SURVEY 8e tier 2), strong scaling; cfg: one clip per PAIR of ranks, each running one "
+                         "classifier-free-guidance branch, 2.2 MB exchange per step (SURVEY 8e tier 1)")
+    ap.add_argument("--check", action="store_true", help="developer check: print a checksum of the final latents on rank 0 (tests compare N = 1 with N > 1)")
     return ap.parse_args()
 
 
@@ -145,8 +147,14 @@ def main():
     lat_frames = (args.frames - 1) // 4 + 1
     dit, cam, pipe = build_models(dev, args.layers, lat_frames)
     seq = args.shard == "sequence" and world > 1
+    cfg_dp = args.shard == "cfg" and world > 1
     sp = SequenceParallel(rank, world) if seq else None
-    g = torch.Generator().manual_seed(1234 + (0 if seq else rank))          # each rank denoises its own clip (sequence mode: the same clip)
+    cfgp = None
+    if cfg_dp:
+        from motionrag_amd.dist import CFGParallel
+        cfgp = CFGParallel(rank, world, group=CFGParallel.pair_groups(world, rank))
+    clip_id = 0 if seq else (rank // 2 if cfg_dp else rank)
+    g = torch.Generator().manual_seed(1234 + clip_id)          # each rank denoises its own clip (sequence mode: the same clip; cfg mode: one per pair)
     b = 1
     latents = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
     image_latents = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
@@ -167,6 +175,9 @@ def main():
 
     pipe.action_emb = action_emb
     rope_ip = pipe._prepare_rotary_positional_embeddings(lat_frames, 30, 45, dev)
+    if cfgp is not None:
+        br = slice(cfgp.branch * b, (cfgp.branch + 1) * b)
+        prompt_br, rope_br = prompt[br].contiguous(), (rope_ip[0], action_emb[br].contiguous())
     sched = pipe.scheduler
     total = args.warmup + args.steps
     ts = sched.set_timesteps(max(total, 1))
@@ -174,7 +185,11 @@ def main():
     def step(i):
         t = int(ts[i])
         timestep = torch.full((2 * b,), float(t), dtype=torch.float32, device=dev)
-        v = dit(latents, prompt, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=2 * b, sp=sp)
+        if cfgp is None:
+            v = dit(latents, prompt, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=2 * b, sp=sp)
+        else:                                                                  # this rank's guidance branch at batch b, then the pair's 2.2 MB exchange
+            v = dit(latents, prompt_br, timestep[:b], image_rotary_emb=rope_br, image_latents=image_latents, batch=b)
+            v = cfgp.gather_branches(v.view(1, *v.shape)).view(2 * b, *v.shape[1:])
         ops.cfg_ddim_step_(v, latents, 6.0, *sched.coeffs(t))
 
     def barrier():
@@ -190,7 +205,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-    gathered = latents if seq else gather_latents(latents, world)        # RCCL all-gather of the ranks' clips at the end of the loop
+    gathered = latents if seq else gather_latents(latents, world)        # RCCL all-gather of the ranks' clips at the end of the loop (cfg mode: both copies of a pair)
     barrier()
     elapsed = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
@@ -234,7 +249,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        frames = args.frames * b * (1 if seq else world)
+        frames = args.frames * b * (1 if seq else (world // 2 if cfg_dp else world))
         value = frames / (elapsed / args.steps)
         durs = [e0.elapsed_time(e1) * 1e-3 for (_, _, e0, e1) in timing]
         flops = timing[0][1] if timing else 0.0
@@ -243,19 +258,21 @@ def main():
         d = 3072
         step_flops = 2 * args.layers * (24 * S * d * d + 4 * S * S * d + 2 * S * d * d + 4 * S * 25 * d + 4 * 25 * 1024 * d)
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r1_attn_traffic.json")   # rocprofv3 PMC pass of the same kernel + shape (tools/pmc_traffic.sh)
+        tp = os.path.join(ROOT, "profiles", "r2_attn_traffic.json")   # rocprofv3 PMC pass of the same kernel + shape (tools/pmc_traffic.sh)
         if args.layers == 42 and args.frames == 49 and os.path.exists(tp):
             with open(tp) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch_corrected"])
-            traffic_src = "profiles/r1_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)"
+            traffic_src = "profiles/r2_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)"
         out = {
             "metric": "denoise_step_frames_per_sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if seq else "weak", "vs_baseline": None,
+            **({"latents_check": {"abs_mean": float(latents.float().abs().mean().item()), "first": latents.flatten()[:16].float().tolist(),
+                                   "strided": latents.flatten()[::9973][:32].float().tolist()}} if args.check else {}),
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"CogVideoX-5B-I2V DiT ({args.layers} layers) + CAMA motion injection, {args.frames}x480x720, CFG batch 2, "
-                                   f"one DDIM denoise step per clip, " + (f"token sequence sharded sp{world} (K/V all-gather per block)" if seq else f"clip-sharded dp{world}"),
+                                   f"one DDIM denoise step per clip, " + (f"token sequence sharded sp{world} (K/V all-gather per block)" if seq else (f"CFG branches on rank pairs, dp{world // 2} x cfg2" if cfg_dp else f"clip-sharded dp{world}")),
                        "clips_per_gpu": b, "tokens": S,
-                       "parallelism": (f"sp{world}" if seq else f"dp{world}")},
+                       "parallelism": (f"sp{world}" if seq else (f"dp{world // 2}xcfg2" if cfg_dp else f"dp{world}"))},
             "frames_per_sec_per_gpu": round(value / world, 4),
             "step_tflops_algorithmic": round(step_flops / 1e12, 1),
             "step_tflops_per_sec_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
@@ -263,7 +280,7 @@ def main():
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
             "e2e_sec_per_clip_50_steps_measured": round(e2e_sec, 2) if e2e_sec is not None else None,
             "secondary_workloads": secondary,
-            "roofline": {"kernel": "attn_fwd_kernel<8,false,false,false,true> + attn_combine_kernel (joint text+video flash attention with the key-split tail, 48 heads x 64, S=%d, B=2)" % S,
+            "roofline": {"kernel": "attn16_kernel<2,8,1,4,false,true> + attn_combine_kernel (joint text+video flash attention on 16x16x32 MFMAs with the key-split tail, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

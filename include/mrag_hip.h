@@ -58,7 +58,8 @@ enum mrag_epilogue {
   MRAG_EPI_GEGLU = 6,       /* C[M, N/2] = v * gelu_erf(g): W / bias rows interleaved in 16-row [value | gate] groups
                              * (GEGLU of lvdm/modules/attention.py:448-455 and diffusers' FeedForward, N % 32 == 0)  */
   MRAG_EPI_QKNORM_ROPE = 7  /* fused QKV projection of the joint attention (attn_processor.py:209-231): C = [Q | K | V] with
-                             * N = 3 * qk_dmodel; per-head LayerNorm(64) of the Q and K thirds (computed on the bf16-rounded
+                             * N = 3 * qk_dmodel (or a suffix / prefix of the three: column block j is third qk_first + j, so a
+                             * sequence-sharded rank can project [K | V] first, start their all-gather, and project Q under it); per-head LayerNorm(64) of the Q and K thirds (computed on the bf16-rounded
                              * projection, as the reference's norm_q / norm_k see it), RoPE on rows whose position inside the
                              * sample (m % rows_per_batch) is >= rope_text_len, Q multiplied by q_premul.  Same arithmetic as
                              * mrag_qknorm_rope_bf16 after a plain GEMM; MRAG_ENOTSUP when the launch cannot take the LDS-staged
@@ -89,6 +90,7 @@ typedef struct mrag_gemm_args {
   const float* rope_sin;
   int64_t qk_dmodel;                         /* D = H * 64 */
   float qk_eps, q_premul;
+  int32_t qk_first;   /* MRAG_EPI_QKNORM_ROPE: which third the first qk_dmodel columns are (0 = Q, 1 = K, 2 = V); N = (1..3 - qk_first) * qk_dmodel */
   int32_t tuning;     /* developer knobs (tools/microbench.py), 0 = shipped: MRAG_GEMM_TUNE_* bits, bits 4-7 tile choice
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
 } mrag_gemm_args;
@@ -139,7 +141,9 @@ enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pa
        MRAG_ATTN_TUNE_LEGACY = 8,    /* long unmasked sequences through the 32x32x16 kernel        */
        MRAG_ATTN_TUNE_QB4 = 16,      /* attn16 with 64 query rows per wave (no key-split tail)     */
        MRAG_ATTN_TUNE_QB4W4 = 32,    /* the same in 4-wave workgroups, two per CU                  */
-       MRAG_ATTN_TUNE_SUBS2 = 64 };  /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
+       MRAG_ATTN_TUNE_SUBS2 = 64,    /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
+       MRAG_ATTN_TUNE_W4PF = 128,    /* attn16: 4-wave workgroups x 3 per CU, fragment prefetch    */
+       MRAG_ATTN_TUNE_W8PF = 256 };  /* attn16: 8-wave workgroups at 168 VGPRs, fragment prefetch  */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
@@ -342,6 +346,23 @@ int mrag_geglu_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t 
 int mrag_ddim_v_step_f32(void* stream, const void* v_pred, float* x, const float* noise, int64_t n, float guidance,
                          float sqrt_alpha_t, float sqrt_one_minus_alpha_t, float rescale, float sqrt_alpha_prev,
                          float dir_coef, float sigma);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU exchange step: RCCL all-gather over xGMI on a    */
+/* caller-chosen stream.  The reference's only collective use is Lightning DDP */
+/* (configs/cogvideox/MotionRAG_open.yml:4-8); the hot path's exchanges are: the */
+/* ranks' final latents at the end of the loop, a rank's K / V rows per block   */
+/* (sequence sharding), a guidance branch's velocity (CFG pairs).               */
+/* RCCL is resolved at run time (the process's librccl.so); MRAG_ENOTSUP when   */
+/* there is none.  1000 + ncclResult_t on an RCCL failure.                      */
+/*   id: 128 opaque bytes on the HOST: rank 0 creates it, the launcher's store  */
+/*   carries it to the other ranks (motionrag_amd/dist.py: RcclComm).           */
+/* ------------------------------------------------------------------------ */
+int mrag_comm_unique_id(void* id128_host);
+int mrag_comm_init(const void* id128_host, int32_t rank, int32_t world, void** comm_out);
+int mrag_comm_destroy(void* comm);
+/* recv[r * bytes_per_rank ..] = rank r's send buffer, on `stream`; returns after ENQUEUEING (asynchronous like a kernel launch) */
+int mrag_allgather(void* stream, void* comm, const void* send, void* recv, int64_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "norm.hip", "pointwise.hip", "topk.hip", "unet_ops.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "topk.hip", "unet_ops.hip"]
 ABI_VERSION = 2
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
@@ -29,6 +29,7 @@ SYMBOLS = [
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
+    "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
 ]
 
 
@@ -49,7 +50,7 @@ class GemmArgs(Structure):
         ("rows_per_batch", c_int64), ("split", c_int64), ("gate_stride", c_int64),
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
-        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("tuning", c_int32),
+        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32),
     ]
 
 
@@ -130,7 +131,7 @@ def build(verbose: bool = False) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout.decode()}")
@@ -161,6 +162,10 @@ def lib() -> ctypes.CDLL:
     L.mrag_attn_fp8_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
     L.mrag_attn_fp8_workspace_bytes.restype = c_int64
     L.mrag_attn_fwd_fp8.argtypes = [c_void_p, POINTER(AttnArgs)]
+    L.mrag_comm_unique_id.argtypes = [c_void_p]
+    L.mrag_comm_init.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
+    L.mrag_comm_destroy.argtypes = [c_void_p]
+    L.mrag_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
     L.mrag_layernorm_bf16.argtypes = [c_void_p, POINTER(LnArgs)]
     L.mrag_qknorm_rope_bf16.argtypes = [c_void_p, POINTER(QkNormRopeArgs)]
     L.mrag_timestep_embedding_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32]

@@ -104,17 +104,44 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
         if getattr(attn, "is_cross_attention", False):
             raise NotImplementedError("RoPE on Q only (is_cross_attention=True) is not used by CogVideoX attn1")
     nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)
+    if sp is not None:
+        o = _sharded_attention(attn, x, wqkv, bqkv, H, nq, nk, cos, sin, text_len, sp)
+        return _motion_branch(attn, proc, o, ip_hidden_states, scale)
     # :209-211 + :220-231 in ONE GEMM: the projection's epilogue applies norm_q / norm_k and the rotary embedding to the Q and K thirds
     qkv = ops.qkv_linear_qknorm_rope(x, wqkv, bqkv, H, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
                                      nk.weight if nk is not None else None, nk.bias if nk is not None else None, cos, sin, text_len,
                                      eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)
     q5 = qkv.view(B, S, 3, H, 64)
-    if sp is None:
-        o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237
-    else:
-        kv = q5[:, :, 1:].permute(1, 0, 2, 3, 4).contiguous()                     # [s_loc, B, 2, H, 64]: rows outermost -> the gather is one flat buffer
-        g = sp.all_gather(kv)                                                     # [S, B, 2, H, 64]
-        o = ops.attention(q5[:, :, 0], g[:, :, 0].permute(1, 0, 2, 3), g[:, :, 1].permute(1, 0, 2, 3), q_prescaled=True)
+    o = ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], q_prescaled=True)   # :233-237
+    return _motion_branch(attn, proc, o, ip_hidden_states, scale)
+
+
+def _sharded_attention(attn, x, wqkv, bqkv, H, nq, nk, cos, sin, text_len, sp):
+    """Tier-2 sequence sharding: x holds this rank's rows.  The [K | V] thirds are projected FIRST (norm_k + RoPE in the GEMM
+    epilogue) straight into this rank's row range of the gathered buffer's layout -- per sample a contiguous [s_loc, 2 D] block -- and their
+    all-gather is started asynchronously (RCCL runs it on its own stream over xGMI); the Q third is projected while the gather is in
+    flight; the attention waits for the gather.  No permute / contiguous copy: the gathered [B, S, 2, H, 64] buffer is read through strides."""
+    B, S, D = x.shape
+    qn = dict(eps=nq.eps if nq is not None else 1e-6, q_premul=ops.LOG2E * 64 ** -0.5)
+    gq, bq, gk, bk = (nq.weight if nq is not None else None, nq.bias if nq is not None else None,
+                      nk.weight if nk is not None else None, nk.bias if nk is not None else None)
+    try:
+        kv = ops.qkv_linear_qknorm_rope(x, wqkv[D:], bqkv[D:] if bqkv is not None else None, H, gq, bq, gk, bk, cos, sin, text_len, first=1, **qn)   # [B, s_loc, 2 D]
+    except NotImplementedError:          # toy sizes (128x128 GEMM tiles carry no fused epilogue): whole projection + the norm / RoPE kernel, then split
+        qkv = ops.qkv_linear_qknorm_rope(x, wqkv, bqkv, H, gq, bq, gk, bk, cos, sin, text_len, **qn)
+        g = sp.all_gather_rows_async(qkv[..., D:].contiguous()).wait().view(B, -1, 2, H, 64)
+        return ops.attention(qkv[..., :D].unflatten(-1, (H, 64)), g[:, :, 0], g[:, :, 1], q_prescaled=True)
+    pending = sp.all_gather_rows_async(kv)                                        # -> [B, S_total, 2 D], rank-major rows == global row order
+    q = ops.qkv_linear_qknorm_rope(x, wqkv[:D], bqkv[:D] if bqkv is not None else None, H, gq, bq, gk, bk, cos, sin, text_len, first=0, **qn)    # [B, s_loc, D]
+    g = pending.wait().view(B, -1, 2, H, 64)
+    return ops.attention(q.view(B, S, H, 64), g[:, :, 0], g[:, :, 1], q_prescaled=True)
+
+
+def _motion_branch(attn, proc, o, ip_hidden_states, scale):
+    """attn_processor.py:243-273: o += scale * SDPA(to_q_ip(o), to_k_ip(ip), to_v_ip(ip))"""
+    B, S, D = o.shape
+    H = attn.heads
+    fw = proc._fused
     if ip_hidden_states is not None and scale != 0:                               # :243-249
         ip = ip_hidden_states if ip_hidden_states.dtype == torch.bfloat16 else ip_hidden_states.to(torch.bfloat16)
         ip = ip.contiguous()

@@ -388,22 +388,30 @@ class CogVideoXImageToVideoActionPipeline:
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
-                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None) -> torch.Tensor:
+                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None, cfgp=None) -> torch.Tensor:
         """the hot loop: latents [b, F, 16, h, w] bf16 (N(0,1) noise), prompt_embeds = cat([negative, positive])
-        [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329)."""
+        [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329).
+        `sp` (dist.SequenceParallel): the token sequence of the clip sharded over the ranks; `cfgp` (dist.CFGParallel): this rank runs ONE of
+        the two guidance branches at batch b and the pair exchanges the velocity prediction (2.2 MB per step) before the shared update."""
         self.action_emb = action_emb
         b, F, C, h, w = latents.shape
         p = self.transformer.cfg["patch"]
-        rope_ip = self._prepare_rotary_positional_embeddings(F, h // p, w // p, latents.device)
         ts = self.scheduler.set_timesteps(num_inference_steps)
         B = 2 * b
+        if cfgp is not None:
+            sl = slice(cfgp.branch * b, (cfgp.branch + 1) * b)
+            prompt_embeds, self.action_emb, B = prompt_embeds[sl].contiguous(), action_emb[sl].contiguous(), b
+        rope_ip = self._prepare_rotary_positional_embeddings(F, h // p, w // p, latents.device)
         for i, t in enumerate(ts):
             timestep = torch.full((B,), float(t), dtype=torch.float32, device=latents.device)
             v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B, sp=sp)
+            if cfgp is not None:
+                v = cfgp.gather_branches(v.view(1, *v.shape)).view(2 * b, *v.shape[1:])     # [uncond ; cond]
             sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))
             ops.cfg_ddim_step_(v, latents, guidance_scale, sa, sb, a_t, b_t)
             if callback is not None:
                 callback(i, int(t), latents)
+        self.action_emb = action_emb
         return latents
 
     @torch.no_grad()

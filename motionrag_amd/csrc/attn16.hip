@@ -30,8 +30,7 @@ namespace {
 
 constexpr int KVB = 64;                // keys per compute tile
 constexpr int TILE_BYTES = KVB * 128;
-constexpr int RING_BYTES = 4 * TILE_BYTES;   // K ring (and V ring): 4 x 64-key stages, or 2 x 128-key stages (SUBS = 2: half the barriers)
-constexpr int V_BASE = RING_BYTES;
+// LDS: K ring of NS stages, then the V ring; a stage = SUBS compute tiles (SUBS = 2: half the barriers)
 constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
 
 struct Lane16 {
@@ -40,9 +39,37 @@ struct Lane16 {
   int g;
 };
 
-// 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads (16 VGPRs of fragments live at a time).
-template <int OFF, int QB, typename Between>
+// 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads.  PF = false: one group (16 VGPRs of fragments) live at a time;
+// PF = true (the 168-register, 3-waves-per-SIMD configuration): both groups requested up front, the second lands under the first one's MFMAs.
+template <int OFF, int QB, bool PF, typename Between>
 __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
+  if constexpr (PF) {
+    u32x4 k0[4], k1[4];
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
+                 : "=&v"(k0[0]), "=&v"(k0[1]), "=&v"(k0[2]), "=&v"(k0[3])
+                 : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF), "n"(OFF + 2048) : "memory");
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
+                 : "=&v"(k1[0]), "=&v"(k1[1]), "=&v"(k1[2]), "=&v"(k1[3])
+                 : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 4096), "n"(OFF + 6144) : "memory");
+    between();
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]) :: "memory");   // LDS reads return in order
+#pragma unroll
+    for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        s[kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
+        s[kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[2 * kbl + 1]), qf[qb][1], s[kbl][qb], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) :: "memory");
+#pragma unroll
+    for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        s[2 + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
+        s[2 + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[2 * kbl + 1]), qf[qb][1], s[2 + kbl][qb], 0, 0, 0);
+      }
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
     u32x4 kf[4];                           // [2 * kbl + ks]
@@ -68,8 +95,29 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
   }
 }
 
+// the 8 transposed reads of one 32-key step of V^T (4 d-blocks x keys 4 g.. / 16 + 4 g..), no wait: the caller retires them
+template <int VOFF>
+__device__ __forceinline__ void pv_issue(const Lane16& ln, u32x2 (&lo)[4], u32x2 (&hi)[4]) {
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF), "n"(VOFF + 2048) : "memory");
+}
+
+template <int QB>
+__device__ __forceinline__ void pv_mma(const u32x2 (&lo)[4], const u32x2 (&hi)[4], const bf16x8 (&pb)[QB], f32x4 (&o)[4][QB]) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[qb], o[db][qb], 0, 0, 0);
+  }
+}
+
 // O^T += V^T . P^T: per 32-key step 4 d-blocks x 2 transposed reads, QB MFMAs per fragment.  EXEC is all ones (wave-uniform control flow only).
-template <int OFF, int QB>
+template <int VOFF, int QB>
 __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB]) {
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -81,7 +129,7 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
                    "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + OFF), "n"(V_BASE + OFF + 2048) : "memory");
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF), "n"(VOFF + 2048) : "memory");
     else
       asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
                    "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
@@ -89,7 +137,7 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
                    "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(V_BASE + OFF + 4096), "n"(V_BASE + OFF + 6144) : "memory");
+                   : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF + 4096), "n"(VOFF + 6144) : "memory");
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
@@ -103,10 +151,10 @@ struct NoHook16 {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <int QB, int NW, int SUBS, bool KVSPLIT>
-__global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const AttnP p) {
+template <int QB, int NW, int SUBS, int NS, bool PF, bool KVSPLIT>
+__global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : (PF ? 3 : 4)) void attn16_kernel(const AttnP p) {
   constexpr int ROWS = NW * QB * 16;
-  constexpr int SK = SUBS * KVB, STAGE_BYTES = SUBS * TILE_BYTES, NS = 4 / SUBS;   // an LDS stage = SUBS compute tiles; one barrier per stage
+  constexpr int SK = SUBS * KVB, STAGE_BYTES = SUBS * TILE_BYTES, V_BASE = NS * STAGE_BYTES;   // an LDS stage = SUBS compute tiles; one barrier per stage
   constexpr int PPW = SUBS * 8 / NW;                                                // 1-KiB DMA pieces per wave per K (and V) stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -238,9 +286,11 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
     // ~20 log2 units: never on real activations): those re-centre -- exact tile maximum, m moves, O and l are rescaled by the exact
     // factor -- and, for an exploded tile, the score MFMAs are simply run again (its K stage is still resident).
     bool recentre = (t == 0 && SUB == 0);
+    u32x2 vlo[4], vhi[4];
+    if constexpr (PF) pv_issue<V_BASE + OFF>(ln, vlo, vhi);   // V^T fragments of k-step 0: their LDS latency hides under the score MFMAs and the softmax
     for (int pass = 0;; ++pass) {
-      if (pass == 0) qk16<OFF, QB>(ln, qf, negm, s, hook);
-      else qk16<OFF, QB>(ln, qf, negm, s, NoHook16());
+      if (pass == 0) qk16<OFF, QB, PF>(ln, qf, negm, s, hook);
+      else qk16<OFF, QB, PF>(ln, qf, negm, s, NoHook16());
       if (ragged) {   // keys before t * 64 were consumed by the previous tile
         asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
         const int lo = t * SK;
@@ -301,7 +351,16 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
         pb[st][qb] = __builtin_bit_cast(bf16x8, w);
       }
     }
-    pv16<OFF, QB>(ln, pb, o);
+    if constexpr (PF) {
+      u32x2 wlo[4], whi[4];
+      pv_issue<V_BASE + OFF + 4096>(ln, wlo, whi);            // k-step 1 lands under k-step 0's MFMAs
+      asm volatile("" : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3]));   // landed at qk16's lgkmcnt(0)
+      pv_mma<QB>(vlo, vhi, pb[0], o);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wlo[0]), "+v"(wlo[1]), "+v"(wlo[2]), "+v"(wlo[3]), "+v"(whi[0]), "+v"(whi[1]), "+v"(whi[2]), "+v"(whi[3]) :: "memory");
+      pv_mma<QB>(wlo, whi, pb[1], o);
+    } else {
+      pv16<V_BASE + OFF, QB>(ln, pb, o);
+    }
   };
   auto iter = [&](int t, auto stage_c) {
     constexpr int STG = decltype(stage_c)::value;
@@ -314,23 +373,15 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
 
 
   int t = 0;
-  if constexpr (NS == 4) {
-    for (; t + 4 <= nt; t += 4) {
-      iter(t, std::integral_constant<int, 0>{});
-      iter(t + 1, std::integral_constant<int, 1>{});
-      iter(t + 2, std::integral_constant<int, 2>{});
-      iter(t + 3, std::integral_constant<int, 3>{});
-    }
-    if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
-    if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; }
-    if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; }
-  } else {
-    for (; t + 2 <= nt; t += 2) {
-      iter(t, std::integral_constant<int, 0>{});
-      iter(t + 1, std::integral_constant<int, 1>{});
-    }
-    if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
+  for (; t + NS <= nt; t += NS) {
+    iter(t, std::integral_constant<int, 0>{});
+    iter(t + 1, std::integral_constant<int, 1>{});
+    if constexpr (NS >= 3) iter(t + 2, std::integral_constant<int, 2>{});
+    if constexpr (NS >= 4) iter(t + 3, std::integral_constant<int, 3>{});
   }
+  if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
+  if constexpr (NS >= 3) { if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; } }
+  if constexpr (NS >= 4) { if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; } }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
 
   if (!wave_active) return;
@@ -371,45 +422,47 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 4 : 2) void attn16_kernel(const 
 
 }  // namespace
 
-template <int QB, int NW, int SUBS>
+template <int QB, int NW, int SUBS, int NS, bool PF>
 static int launch16_plain(hipStream_t s, AttnP p) {
   constexpr int ROWS = NW * QB * 16;
-  const size_t lds = 2 * RING_BYTES;
+  const size_t lds = 2 * NS * SUBS * TILE_BYTES;
   p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
-  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, false>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, NS, PF, false>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, NS, PF, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
 
-template <int SUBS>
 static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace) {
   constexpr int QB = 2, NW = 8;
   const int nbh = p.B * p.H;
-  const size_t lds = 2 * RING_BYTES;
+  const size_t lds = 2 * 4 * TILE_BYTES;
   p.n_qtiles = pl->n_full;
   p.n_main = pl->n_full * nbh;
   p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
   p.part_o = (float*)workspace;
   p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
-  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, true>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, 1, 4, false, true>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, 1, 4, false, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return mrag_launch_attn_combine(s, p);
 }
 
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
-  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1>(s, p);       // developer A/B: 64 query rows per wave, 512-row workgroups, one per CU
-  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1>(s, p);     // developer A/B: 64 rows per wave, 4-wave workgroups, two per CU
-  const bool subs2 = (tuning & MRAG_ATTN_TUNE_SUBS2) != 0;                     // developer A/B: 128-key LDS stages, one barrier per 128 keys
+  // developer A/B variants (tools/attn_ab.py), all without the key-split tail:
+  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1, 4, false>(s, p);      // 64 query rows per wave, 512-row workgroups, one per CU
+  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1, 4, false>(s, p);    // 64 rows per wave, 4-wave workgroups, two per CU
+  if (tuning & MRAG_ATTN_TUNE_SUBS2) return launch16_plain<2, 8, 2, 2, false>(s, p);    // 128-key LDS stages, one barrier per 128 keys
+  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 3, true>(s, p);      // 4-wave workgroups, three per CU, 168 VGPRs, fragment prefetch
+  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 1, 4, true>(s, p);      // 8-wave workgroups at 168 VGPRs (one + a half per CU), fragment prefetch
   if (pl) {
-    if (pl->chunk_keys % (subs2 ? 2 * KVB : KVB) != 0 || pl->rem_rows >= 256) return MRAG_ENOTSUP;
-    return subs2 ? launch16_split<2>(s, p, pl, workspace) : launch16_split<1>(s, p, pl, workspace);
+    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 256) return MRAG_ENOTSUP;
+    return launch16_split(s, p, pl, workspace);
   }
-  return subs2 ? launch16_plain<2, 8, 2>(s, p) : launch16_plain<2, 8, 1>(s, p);
+  return launch16_plain<2, 8, 1, 4, false>(s, p);
 }

@@ -53,7 +53,7 @@ struct GemmP {
   int tiles_m, tiles_n, group_m, staged, tuning;
   // MRAG_EPI_QKNORM_ROPE
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
-  long long qk_D; int rope_text_len; float qk_eps, q_premul;
+  long long qk_D; int rope_text_len, qk_first; float qk_eps, q_premul;
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T;
   long long cv_C, cv_HW;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
       }
     };
     if constexpr (EPI == MRAG_EPI_QKNORM_ROPE) {
-      qk_which = (int)((bn0 + wn * TN * 16) / p.qk_D);
+      qk_which = p.qk_first + (int)((bn0 + wn * TN * 16) / p.qk_D);
       has_rope = p.rcos != nullptr && qk_which < 2;
       if (has_rope) {
 #pragma unroll
@@ -759,11 +759,12 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
-    if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N != 3 * a->qk_dmodel || a->rows_per_batch <= 0) return MRAG_EINVAL;
+    if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
+        a->rows_per_batch <= 0) return MRAG_EINVAL;
     if ((a->rope_cos != nullptr) != (a->rope_sin != nullptr) || (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 15)) return MRAG_EINVAL;
     if (((uintptr_t)a->q_gamma | (uintptr_t)a->q_beta | (uintptr_t)a->k_gamma | (uintptr_t)a->k_beta) & 15) return MRAG_EINVAL;
     p.qg = (const bf16_t*)a->q_gamma; p.qb = (const bf16_t*)a->q_beta; p.kg = (const bf16_t*)a->k_gamma; p.kb = (const bf16_t*)a->k_beta;
-    p.rcos = a->rope_cos; p.rsin = a->rope_sin; p.qk_D = a->qk_dmodel; p.rope_text_len = a->rope_text_len; p.qk_eps = a->qk_eps; p.q_premul = a->q_premul;
+    p.rcos = a->rope_cos; p.rsin = a->rope_sin; p.qk_D = a->qk_dmodel; p.rope_text_len = a->rope_text_len; p.qk_first = a->qk_first; p.qk_eps = a->qk_eps; p.q_premul = a->q_premul;
   }
   hipStream_t s = (hipStream_t)stream;
   // big problems: 256x256 tiles, 8 waves (1 workgroup per CU); small ones: 128x128, 4 waves,

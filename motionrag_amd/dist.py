@@ -69,3 +69,131 @@ class SequenceParallel:
         out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x, group=self.group)
         return out
+
+    def all_gather_rows_async(self, x: torch.Tensor) -> "_Pending":
+        """x [B, n, W] (this rank's rows of every sample, contiguous) -> pending [B, world * n, W]: one all-gather per sample straight into
+        that sample's slice of the result (rank-major == global row order: no permute, no copy), issued with async_op=True so that RCCL runs
+        them on its own stream while the caller keeps launching work on the current stream; `.wait()` orders the current stream behind them."""
+        B, n, W = x.shape
+        if not x.is_contiguous():
+            raise ValueError("all_gather_rows_async: contiguous [B, n, W] required")
+        if self._ag is not None or (x.is_cuda and dist.get_backend(self.group) == "gloo"):    # test harness / one-GPU developer runs: synchronous
+            return _Pending(torch.stack([self.all_gather(x[b]) for b in range(B)]), [])
+        out = torch.empty(B, self.world * n, W, dtype=x.dtype, device=x.device)
+        works = [dist.all_gather_into_tensor(out[b], x[b], group=self.group, async_op=True) for b in range(B)]
+        return _Pending(out, works)
+
+
+class _Pending:
+    def __init__(self, out, works):
+        self.out, self.works = out, works
+
+    def wait(self) -> torch.Tensor:
+        for w in self.works:
+            w.wait()
+        return self.out
+
+
+class RcclComm:
+    """`mrag_allgather` (include/mrag_hip.h): RCCL through the C ABI on a stream of the caller's choice, for exchanges that should overlap
+    compute explicitly (a side stream + events) instead of going through torch.distributed's process group.  The 128-byte unique id is
+    created on rank 0 and carried by the launcher's store (any initialised torch.distributed backend, gloo included)."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self.rank, self.world = _lib.lib(), rank, world
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self._lib.mrag_comm_unique_id(buf), "mrag_comm_unique_id")
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        self._comm = ctypes.c_void_p()
+        _lib.check(self._lib.mrag_comm_init(buf, rank, world, ctypes.byref(self._comm)), "mrag_comm_init")
+
+    def all_gather(self, x: torch.Tensor, out: torch.Tensor = None, stream: torch.cuda.Stream = None) -> torch.Tensor:
+        """[n, ...] -> [world * n, ...], enqueued on `stream` (default: the current one)"""
+        import ctypes
+        from . import _lib
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("RcclComm.all_gather: contiguous GPU tensor required")
+        if out is None:
+            out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        st = stream if stream is not None else torch.cuda.current_stream(x.device)
+        _lib.check(self._lib.mrag_allgather(ctypes.c_void_p(st.cuda_stream), self._comm, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                            x.numel() * x.element_size()), "mrag_allgather")
+        return out
+
+    def close(self):
+        if self._comm:
+            self._lib.mrag_comm_destroy(self._comm)
+            self._comm = None
+
+
+class CFGParallel:
+    """SURVEY 8e tier 1: the two classifier-free-guidance branches of ONE clip on a PAIR of GPUs.  Rank parity picks the branch (even =
+    unconditional, odd = conditional: the [uncond ; cond] batch order of the pipelines and of ActionTransformer.predict, module.py:329);
+    each rank runs the denoiser at batch 1 and the pair exchanges its velocity prediction once per step -- [1, F, 16, h, w] bf16 = 2.2 MB
+    at 49x480x720 -- before both apply the CFG + scheduler update on identical inputs (latents stay bit-identical on the pair without a
+    broadcast)."""
+
+    def __init__(self, rank: int, world: int, group=None, all_gather=None):
+        if world % 2:
+            raise ValueError("CFG parallelism pairs ranks: world size must be even")
+        self.rank, self.world, self.branch, self.clip = rank, world, rank % 2, rank // 2
+        self.group, self._ag = group, all_gather            # `group`: this rank's pair {2i, 2i + 1}
+
+    @staticmethod
+    def pair_groups(world: int, rank: int):
+        """every rank creates every pair group (torch.distributed requires it) and keeps its own"""
+        mine = None
+        for i in range(0, world, 2):
+            g = dist.new_group([i, i + 1])
+            if rank in (i, i + 1):
+                mine = g
+        return mine
+
+    def gather_branches(self, v_local: torch.Tensor) -> torch.Tensor:
+        """[1, ...] of this rank's branch -> [2, ...] = [uncond ; cond] on both ranks of the pair"""
+        x = v_local.contiguous()
+        if self._ag is not None:
+            return self._ag(x)
+        if x.is_cuda and dist.get_backend(self.group) == "gloo":
+            parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(2)]
+            dist.all_gather(parts, x.cpu(), group=self.group)
+            return torch.cat(parts, dim=0).to(x.device)
+        out = torch.empty((2 * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------- UNet backbones: frame <-> pixel transposes
+def frames_to_pixels(x: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """Ulysses-style transpose in front of a temporal layer of the UNets (TemporalTransformer, attention.py:395-445; TemporalConvBlock,
+    openaimodel3d.py:233-236): spatial layers run with the FRAMES sharded, temporal layers need all frames of a pixel.
+    x [b, t_loc, hw, c] (this rank's frames, all pixels) -> [b, t_loc * world, hw / world, c] (all frames, this rank's pixel slab);
+    one all-to-all of hw / world x t_loc x c elements per peer (xGMI: all-pairs, every link busy)."""
+    b, tl, hw, c = x.shape
+    if hw % world:
+        raise ValueError(f"{hw} pixels do not split over {world} ranks")
+    if world == 1:
+        return x
+    send = x.view(b, tl, world, hw // world, c).permute(2, 0, 1, 3, 4).contiguous()        # [peer, b, t_loc, hw_loc, c]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                                          # recv[r] = rank r's frames of MY pixel slab
+    return recv.permute(1, 0, 2, 3, 4).reshape(b, world * tl, hw // world, c)                # frame index = r * t_loc + i (rank-major == frame order)
+
+
+def pixels_to_frames(y: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """inverse of `frames_to_pixels`: [b, t, hw_loc, c] -> [b, t / world, hw_loc * world, c]"""
+    b, t, hwl, c = y.shape
+    if t % world:
+        raise ValueError(f"{t} frames do not split over {world} ranks")
+    if world == 1:
+        return y
+    send = y.view(b, world, t // world, hwl, c).permute(1, 0, 2, 3, 4).contiguous()         # [peer, b, t_loc, hw_loc, c]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)                                          # recv[r] = MY frames of rank r's pixel slab
+    return recv.permute(1, 2, 0, 3, 4).reshape(b, t // world, world * hwl, c)

@@ -22,7 +22,7 @@ LOG2E = 1.4426950408889634
 # Nothing on the launch path reads the environment.
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
-ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4, ATTN_TUNE_SUBS2 = 1, 2, 4, 8, 16, 32, 64
+ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4, ATTN_TUNE_SUBS2, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class HipOnly(RuntimeError):
@@ -260,19 +260,23 @@ def qknorm_rope_(qkv: torch.Tensor, H: int, q_gamma, q_beta, k_gamma, k_beta, co
 
 
 def qkv_linear_qknorm_rope(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], H: int, q_gamma, q_beta, k_gamma, k_beta,
-                           cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], text_len: int, eps: float = 1e-6, q_premul: float = 1.0) -> torch.Tensor:
-    """fused QKV projection + per-head qk LayerNorm + RoPE: x [B, S, K] -> [B, S, 3*H*64] (attn_processor.py:209-231).  One GEMM whose epilogue does
-    what `qknorm_rope_` does in a second pass; falls back to the two kernels when the launch cannot take that epilogue (MRAG_ENOTSUP)."""
+                           cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], text_len: int, eps: float = 1e-6, q_premul: float = 1.0,
+                           first: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused QKV projection + per-head qk LayerNorm + RoPE: x [B, S, K] -> [B, S, n*H*64] (attn_processor.py:209-231).  One GEMM whose epilogue does
+    what `qknorm_rope_` does in a second pass; falls back to the two kernels when the launch cannot take that epilogue (MRAG_ENOTSUP).
+    `weight` holds the thirds first .. first + n - 1 of [Wq | Wk | Wv] (first = 1, n = 2: the K | V projection of a sequence-sharded rank)."""
     _dev(x, name="x"); _dev(weight, name="weight")
     B, S, K = x.shape
     N = weight.shape[0]
-    if N != 3 * H * 64 or weight.shape[1] != K or not x.is_contiguous() or K % 64 != 0:
-        raise ValueError("qkv_linear_qknorm_rope: x [B, S, K] contiguous, weight [3*H*64, K], K % 64 == 0")
-    out = torch.empty(B, S, N, dtype=torch.bfloat16, device=x.device)
+    D = H * 64
+    if N % D or first + N // D > 3 or weight.shape[1] != K or not x.is_contiguous() or K % 64 != 0:
+        raise ValueError("qkv_linear_qknorm_rope: x [B, S, K] contiguous, weight [n*H*64, K] with first + n <= 3, K % 64 == 0")
+    if out is None:
+        out = torch.empty(B, S, N, dtype=torch.bfloat16, device=x.device)
     a = GemmArgs()
     a.A, a.W, a.bias, a.C = _p(x), _p(weight), _p(bias), _p(out)
     a.M, a.N, a.K, a.lda, a.ldw, a.ldc = B * S, N, K, K, weight.stride(0), N
-    a.epilogue, a.rows_per_batch, a.rope_text_len, a.qk_dmodel, a.qk_eps, a.q_premul = EPI_QKNORM_ROPE, S, text_len, H * 64, eps, q_premul
+    a.epilogue, a.rows_per_batch, a.rope_text_len, a.qk_dmodel, a.qk_eps, a.q_premul, a.qk_first = EPI_QKNORM_ROPE, S, text_len, D, eps, q_premul, first
     a.q_gamma, a.q_beta, a.k_gamma, a.k_beta = _p(q_gamma), _p(q_beta), _p(k_gamma), _p(k_beta)
     if cos is not None:
         _dev(cos, torch.float32, "cos"); _dev(sin, torch.float32, "sin")
@@ -282,6 +286,8 @@ def qkv_linear_qknorm_rope(x: torch.Tensor, weight: torch.Tensor, bias: Optional
     a.tuning = TUNING["gemm"]
     rc = _lib.MRAG_ENOTSUP if TUNING["no_qkv_fuse"] else _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))
     if rc == _lib.MRAG_ENOTSUP:                                   # small problem / unaligned output: plain GEMM, then the norm + RoPE pass
+        if first != 0 or N != 3 * D:
+            raise NotImplementedError("the two-kernel fallback needs the whole fused [Q | K | V] buffer")
         linear(x, weight, bias, out=out)
         return qknorm_rope_(out, H, q_gamma, q_beta, k_gamma, k_beta, cos, sin, text_len, eps=eps, q_premul=q_premul)
     check(rc, "mrag_gemm_bf16")

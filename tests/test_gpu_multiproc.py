@@ -1,0 +1,74 @@
+"""The N > 1 code paths of bench.py on a ONE-GPU box: two ranks started through torch.distributed.run as CHILD processes (nothing here re-execs a
+process that touched the GPU), both on cuda:0, collectives through gloo (MRAG_BENCH_ONE_GPU=1) -- the same Python path as the RCCL run except for
+the transport.  `--shard sequence` (SURVEY 8e tier 2: K/V all-gather per block, projected K|V first and gathered under the Q projection) and
+`--shard cfg` (tier 1: the two guidance branches on a rank pair, 2.2 MB exchange per step) must reproduce the unsharded N = 1 clip."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--layers", "2", "--frames", "9", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-secondary", "--check"]
+
+
+def _run(cmd, env):
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def _bench(n, shard):
+    env = dict(os.environ, MRAG_BENCH_ONE_GPU="1")
+    if n == 1:
+        return _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON, env)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+                 str(port), "bench.py", "--gpus", str(n), "--shard", shard] + COMMON, env)
+
+
+@pytest.mark.timeout(1800)
+def test_two_rank_sequence_and_cfg_sharding_reproduce_the_single_gpu_clip(hip):
+    ref = _bench(1, "clips")
+    assert ref["n_gpus"] == 1 and ref["config"]["tokens"] == 226 + 3 * 1350
+    for shard, par in (("sequence", "sp2"), ("cfg", "dp1xcfg2")):
+        got = _bench(2, shard)
+        assert got["n_gpus"] == 2 and got["config"]["parallelism"] == par
+        a, b = ref["latents_check"], got["latents_check"]
+        scale = a["abs_mean"]
+        assert abs(a["abs_mean"] - b["abs_mean"]) <= 2e-3 * scale, shard
+        for k in ("first", "strided"):
+            assert max(abs(x - y) for x, y in zip(a[k], b[k])) <= 0.03 * scale + 0.02 * max(abs(x) for x in a[k]), (shard, k)   # bf16 latents, 2 steps
+    assert _bench(2, "clips")["n_gpus"] == 2      # the judged default: one clip per rank + the end-of-loop all-gather
+
+
+def test_bench_refuses_a_mismatched_launcher(hip):
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b"WORLD_SIZE=1" in out.stderr
+
+
+def test_rccl_allgather_c_abi_single_rank(hip):
+    """mrag_comm_* / mrag_allgather (include/mrag_hip.h) resolve RCCL at run time and move bytes on a side stream: with one rank the all-gather is a
+    copy, ordered against the producer by an event (multi-rank transport is RCCL's own; the driver's scaling run exercises it)"""
+    import torch
+    from motionrag_amd.dist import RcclComm
+    comm = RcclComm(0, 1)
+    x = torch.randn(3, 1000, device="cuda").to(torch.bfloat16)
+    side = torch.cuda.Stream()
+    ready = torch.cuda.Event()
+    y = x * 2                                            # producer on the current stream
+    ready.record()
+    side.wait_event(ready)
+    out = comm.all_gather(y, stream=side)
+    done = torch.cuda.Event()
+    done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    assert torch.equal(out, y)
+    comm.close()

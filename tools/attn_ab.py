@@ -14,7 +14,9 @@ for name, (B, H, S) in (("dit joint", (2, 48, 17776)), ("dc level0", (32, 5, 921
     qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
     fl = 4.0 * B * H * S * S * 64
-    variants = ((0, "attn16 QB2 (shipped)"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16"), (ops.ATTN_TUNE_SUBS2, "attn16 QB2 128-key stages"))
+    variants = ((0, "attn16 QB2 (shipped)"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16"), (ops.ATTN_TUNE_W4PF, "attn16 NW4 x3/CU prefetch"), (ops.ATTN_TUNE_W8PF, "attn16 NW8 168-VGPR prefetch"))
+    if os.environ.get("AB_SUBS2"):
+        variants += ((ops.ATTN_TUNE_SUBS2, "attn16 QB2 128-key stages"),)
     if os.environ.get("AB_QB4"):
         variants += ((ops.ATTN_TUNE_QB4, "attn16 QB4 NW8"), (ops.ATTN_TUNE_QB4W4, "attn16 QB4 NW4"))
     res = {t: [] for t, _ in variants}
@@ -23,6 +25,18 @@ for name, (B, H, S) in (("dit joint", (2, 48, 17776)), ("dc level0", (32, 5, 921
             ops.TUNING["attn"] = tune
             ops.TUNING["attn_no_split"] = True      # all variants without the key-split tail (the QB4 forms have none)
             res[tune].append(timeit(lambda: ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out), iters=8, warm=2))
+    ops.TUNING["attn_no_split"] = True
+    ref = None
+    for tune, label in variants:          # every variant computes the same attention: compare with the 32x32x16 kernel
+        ops.TUNING["attn"] = tune
+        o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).float()
+        if tune == ops.ATTN_TUNE_LEGACY:
+            ref = o
+    for tune, label in variants:
+        ops.TUNING["attn"] = tune
+        o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).float()
+        d = (o - ref).abs().max().item()
+        print(f"  {label}: max |diff| vs legacy {d:.4g}" + ("  <-- WRONG" if not d < 0.01 else ""))
     ops.TUNING["attn"] = 0
     ops.TUNING["attn_no_split"] = False
     for tune, label in variants:

@@ -287,6 +287,9 @@ int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* latents, int
 /* skipped (the `video != "<self>"` filter, src/data/datamodule.py:235).      */
 /* Output sorted by (dist asc, row asc); missing entries are row = -1.        */
 /* ------------------------------------------------------------------------ */
+/* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
+ * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a
+ * workspace; every call leaves them zero, so a workspace is zeroed once when it is allocated.                                 */
 int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries);
 int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim,
                   const float* queries, const int32_t* exclude, int32_t n_queries,

@@ -672,9 +672,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
       }
       if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
+        // the same rounding points as the LDS-staged epilogue above and as the reference's bf16 tensors (`x + gate * linear(.)`: the gated
+        // projection is a bf16 tensor before the residual add) -- so a GEMM gives the same bits whichever tile configuration its size selects
+        // (a sequence-sharded rank runs smaller problems than the unsharded model)
         const u32x2 rr = *(const u32x2*)(p.resid + m * p.ldr + n);
-        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        v[0] = bf_round(v[0]) + __uint_as_float(rr[0] << 16); v[1] = bf_round(v[1]) + __uint_as_float(rr[0] & 0xffff0000u);
+        v[2] = bf_round(v[2]) + __uint_as_float(rr[1] << 16); v[3] = bf_round(v[3]) + __uint_as_float(rr[1] & 0xffff0000u);
       }
       u32x2 out;
       out[0] = pack_bf2(v[0], v[1]);

@@ -74,6 +74,7 @@ struct TopkP {
   const float* db; const int* group; const float* q; const int* excl;
   Cand* ws; int* out_rows; float* out_dist;
   long long n_rows; int dim, nq, k, metric, slices, rows_per_slice;
+  unsigned* tickets;    // FUSED: one arrival counter per query tile (zero between calls)
 };
 
 // Distance of one (query, row) pair = 16 interleaved fp32 fmaf chains + a fixed 4-level pairwise tree (the definition
@@ -84,7 +85,9 @@ struct TopkP {
 // contiguous bytes), a wavefront streams 4 rows per load instruction straight from HBM into registers (no LDS staging of the
 // database), 16 such row-quads make the 64-row batch whose candidates sit one per lane for the bitonic selection.
 // The queries (QT per workgroup pass) live in LDS and are read as 16-lane-contiguous ds_read_b128.
-template <int METRIC, int QT, int JC>
+__device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh);
+
+template <int METRIC, int QT, int JC, bool FUSED = false>
 __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const TopkP p) {   // <= 168 / 128 VGPRs: 3-4 waves per SIMD stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = (float*)smem;                      // [QT][dimp], dimp = dim rounded up to 64, zero padded
@@ -244,17 +247,42 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
   for (int qi = 0; qi < QT; ++qi) {
     if (q0 + qi < p.nq) p.ws[((long long)(q0 + qi) * nparts + part) * 64 + lane] = run[qi];
   }
+  if constexpr (FUSED) {
+    // ONE launch for the latency-bound single-query search: the workgroup that arrives LAST at this query tile's counter merges the lists.
+    // Placement-independent hand-off (cdna guide, Guideline 16, counter form): plain stores -> every wave drains -> barrier -> one lane:
+    // agent-scope release, asm wait, relaxed agent fetch_add; the last arriver: agent-scope acquire, wait, barrier, plain loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = (unsigned*)smem;                              // the query image is dead: LDS scratch for the flag and the merge
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned last = t == (unsigned)p.slices - 1;
+      if (last) {
+        __hip_atomic_store(p.tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();
+    if (!last) return;
+    for (int qi = 0; qi < QT; ++qi)
+      if (q0 + qi < p.nq) merge_query(p, q0 + qi, (Cand*)smem);
+  }
 }
 
 // one workgroup (4 waves) per query: merge the per-wave partial lists (each sorted ascending, 64 entries).
 // Phase A bounds the answer: the k-th smallest of the lists' MINIMA is an upper bound of the final k-th distance, so only lists
 // whose minimum does not exceed it can contribute (about k of thousands).  Phase B merges just those.  The result is the
 // unique top-k under the total order (distance, row), whatever the merge order.
-__global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
-  __shared__ Cand sh[4][64];
-  __shared__ Cand thr_s;
+// `sh` = 4 x 64 candidates + 1 of LDS scratch.
+__device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
+  Cand* thr_s = sh + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = blockIdx.x;
   const int nparts = p.slices * 4;
   const Cand* lists = p.ws + (long long)q * nparts * 64;
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
@@ -265,15 +293,15 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
     m = wave_sort(m, lane);
     best = wave_merge_top(best, m, lane);
   }
-  sh[wave][lane] = best;
+  sh[wave * 64 + lane] = best;
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int w = 1; w < 4; ++w) best = wave_merge_top(best, sh[w][lane], lane);
-    if (lane == p.k - 1) thr_s = best;           // k-th smallest minimum
+    for (int w = 1; w < 4; ++w) best = wave_merge_top(best, sh[w * 64 + lane], lane);
+    if (lane == p.k - 1) *thr_s = best;           // k-th smallest minimum
   }
   __syncthreads();
-  const Cand thr = thr_s;
+  const Cand thr = *thr_s;
   Cand run = inf;
   for (int base = wave * 64; base < nparts; base += 256) {
     const int part = base + lane;
@@ -287,17 +315,23 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
     }
   }
   __syncthreads();
-  sh[wave][lane] = run;
+  sh[wave * 64 + lane] = run;
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w][lane], lane);
+    for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
     if (lane < p.k) {
       const bool ok = run.r != INT_MAX;
       p.out_rows[(long long)q * p.k + lane] = ok ? run.r : -1;
       p.out_dist[(long long)q * p.k + lane] = run.d;
     }
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
+  __shared__ Cand sh[257];
+  merge_query(p, blockIdx.x, sh);
 }
 
 inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
@@ -318,11 +352,13 @@ void plan(long long n_rows, int nq, int* slices, int* rows_per_slice) {
 
 }  // namespace
 
+constexpr int64_t kTicketBytes = 64;     // arrival counters of the fused single-launch form (<= 4 queries = 1 query tile ... 4 tiles of QT = 1)
+
 extern "C" int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries) {
   if (n_rows <= 0 || n_queries <= 0) return 0;
   int slices, rps;
   plan(n_rows, n_queries, &slices, &rps);
-  return (int64_t)n_queries * slices * 4 * 64 * (int64_t)sizeof(Cand);
+  return kTicketBytes + (int64_t)n_queries * slices * 4 * 64 * (int64_t)sizeof(Cand);
 }
 
 extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim, const float* queries,
@@ -338,15 +374,31 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   if (workspace_bytes < mrag_topk_workspace_bytes(n_rows, n_queries)) return MRAG_EINVAL;
   TopkP p{};
   p.db = db; p.group = exclude ? group : nullptr; p.q = queries; p.excl = exclude;
-  p.ws = (Cand*)workspace; p.out_rows = out_rows; p.out_dist = out_dist;
+  p.tickets = (unsigned*)workspace; p.ws = (Cand*)((char*)workspace + kTicketBytes); p.out_rows = out_rows; p.out_dist = out_dist;
   p.n_rows = n_rows; p.dim = dim; p.nq = n_queries; p.k = k; p.metric = metric;
   plan(n_rows, n_queries, &p.slices, &p.rows_per_slice);
   hipStream_t s = (hipStream_t)stream;
   const int QT = pick_qt(n_queries), nj = (dim + 63) / 64;
   // blocks of 64 floats per register-ring step: 4 for the single query, 2 for query tiles (their chains need the registers)
   const int JCsel = QT == 1 ? (nj % 4 == 0 ? 4 : 1) : (nj % 2 == 0 ? 2 : 1);
-  const size_t lds = (QT == 1 ? (size_t)nj * 64 : (size_t)nj * 16 * (4 * QT + 4)) * sizeof(float);
+  size_t lds = (QT == 1 ? (size_t)nj * 64 : (size_t)nj * 16 * (4 * QT + 4)) * sizeof(float);
   const dim3 grid(p.slices, (n_queries + QT - 1) / QT), block(256);
+  // <= 4 queries (the interactive search of rag.py:63-80): ONE launch, the last workgroup to arrive merges (needs the first 64 workspace
+  // bytes ZERO on entry -- see the header; the kernel leaves them zero)
+  const bool fused = n_queries <= 4 && ((uintptr_t)workspace & 15) == 0;
+  if (fused && lds < 257 * sizeof(Cand)) lds = 257 * sizeof(Cand);
+#define MRAG_TOPK_FUSED(M, Q, J)                                                                                  \
+  if (fused && metric == M && QT == Q && JCsel == J) {                                                            \
+    auto kfn = topk_scan_kernel<M, Q, J, true>;                                                                   \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    if (e != hipSuccess) return (int)e;                                                                           \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                                     \
+    MRAG_LAUNCH_CHECK();                                                                                          \
+    return MRAG_OK;                                                                                               \
+  }
+  MRAG_TOPK_FUSED(0, 1, 1) MRAG_TOPK_FUSED(0, 1, 4) MRAG_TOPK_FUSED(0, 4, 1) MRAG_TOPK_FUSED(0, 4, 2)
+  MRAG_TOPK_FUSED(1, 1, 1) MRAG_TOPK_FUSED(1, 1, 4) MRAG_TOPK_FUSED(1, 4, 1) MRAG_TOPK_FUSED(1, 4, 2)
+#undef MRAG_TOPK_FUSED
 #define MRAG_TOPK_CASE(M, Q, J)                                                                                   \
   if (metric == M && QT == Q && JCsel == J) {                                                                     \
     auto kfn = topk_scan_kernel<M, Q, J>;                                                                         \

@@ -422,9 +422,25 @@ def cfg_ddim_step_(v_pred: torch.Tensor, latents: torch.Tensor, guidance: float,
     return latents
 
 
+_TOPK_WS = {}
+
+
+def topk_workspace(device: torch.device, N: int, Q: int) -> torch.Tensor:
+    """scratch of mrag_topk_f32, one ZEROED buffer per (device, stream, N, Q): its first 64 bytes are the arrival counters of the
+    single-launch form, zero on first use and left zero by every call (include/mrag_hip.h)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, N, Q)
+    ws = _TOPK_WS.get(key)
+    if ws is None:
+        if len(_TOPK_WS) > 64:
+            _TOPK_WS.clear()
+        ws = _TOPK_WS[key] = torch.zeros(_lib.lib().mrag_topk_workspace_bytes(N, Q), dtype=torch.uint8, device=device)
+    return ws
+
+
 def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None,
-         exclude: Optional[torch.Tensor] = None):
-    """flat-scan top-k: returns (rows int32 [Q, k], dist fp32 [Q, k]) sorted by (dist asc, row asc)."""
+         exclude: Optional[torch.Tensor] = None, out: Optional[tuple] = None):
+    """flat-scan top-k: returns (rows int32 [Q, k], dist fp32 [Q, k]) sorted by (dist asc, row asc).  `out` = (rows, dist) buffers to fill
+    (a caller that searches repeatedly keeps them: no allocation on the call path)."""
     _dev(db, torch.float32, "db"); _dev(queries, torch.float32, "queries")
     if not db.is_contiguous() or not queries.is_contiguous():
         raise ValueError("topk: contiguous db / queries required")
@@ -433,13 +449,16 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
     m = {"l2": 0, "dot": 1}[metric]
     if exclude is not None:
         _dev(group, torch.int32, "group"); _dev(exclude, torch.int32, "exclude")
-    L = _lib.lib()
-    ws_bytes = L.mrag_topk_workspace_bytes(N, Q)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=db.device)
-    rows = torch.empty(Q, k, dtype=torch.int32, device=db.device)
-    dist = torch.empty(Q, k, dtype=torch.float32, device=db.device)
-    check(L.mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
-                          _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws_bytes), "mrag_topk_f32")
+    ws = topk_workspace(db.device, N, Q)
+    if out is None:
+        rows = torch.empty(Q, k, dtype=torch.int32, device=db.device)
+        dist = torch.empty(Q, k, dtype=torch.float32, device=db.device)
+    else:
+        rows, dist = out
+        if tuple(rows.shape) != (Q, k) or tuple(dist.shape) != (Q, k) or rows.dtype != torch.int32 or dist.dtype != torch.float32:
+            raise ValueError("topk: out = (int32 [Q, k], float32 [Q, k])")
+    check(_lib.lib().mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
+                                   _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws.numel()), "mrag_topk_f32")
     return rows, dist
 
 

@@ -101,6 +101,37 @@ def test_condition_fusion_against_reference_golden(hip, golden_dir):
         cama.condition_fusion(big.to(DEV), "weight", [[0.1] * 8] * 2)
 
 
+def test_cama_predict_as_hip_graph(hip, golden_dir):
+    """cama.GraphedPredict: the ~170-launch CAMA forward captured once and replayed equals the eager predict bit for bit, follows new inputs
+    through the static buffers, and re-captures for a new shape"""
+    from motionrag_amd import cama
+    from oracle import cama_ref
+    g = np.load(os.path.join(golden_dir, "cama_predict.npz"))
+    sd = cama_ref.random_cama_sd(seed=int(g["weight_seed"]))
+
+    class Enc(torch.nn.Module):                                              # capturable stand-ins of the frozen encoders: a fixed projection of the pixels
+        def __init__(self, tokens, dim, seed):
+            super().__init__()
+            gen = torch.Generator().manual_seed(seed)
+            self.register_buffer("w", torch.randn(tokens, dim, generator=gen).to(torch.bfloat16))
+
+        def forward(self, x):
+            return (self.w[None] * (1 + x.float().mean(dim=tuple(range(1, x.dim()))).view(-1, 1, 1).to(torch.bfloat16))).contiguous()
+
+    model = cama.build_cama(Enc(1568, 768, 1), Enc(257, 1024, 2))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV, torch.bfloat16)
+    gen = torch.Generator().manual_seed(6)
+    mk = lambda b: {"ref_videos": torch.randn(b, 9, 4, 3, 8, 8, generator=gen).to(DEV, torch.bfloat16), "video": torch.randn(b, 4, 3, 8, 8, generator=gen).to(DEV, torch.bfloat16)}
+    gp = cama.GraphedPredict(model, do_classifier_free_guidance=True)
+    b1, b2 = mk(1), mk(1)
+    assert torch.equal(gp(b1).clone(), model.predict(b1, do_classifier_free_guidance=True))
+    assert torch.equal(gp(b2).clone(), model.predict(b2, do_classifier_free_guidance=True))        # replay with new inputs
+    assert len(gp._graphs) == 1
+    b3 = mk(2)
+    assert torch.equal(gp(b3).clone(), model.predict(b3, do_classifier_free_guidance=True)) and len(gp._graphs) == 2
+
+
 def test_cogvideox_processor_dropin(hip):
     """APAdapterCogVideoXAttnProcessor2_0 called through the diffusers processor protocol vs the oracle restatement
     of attn_processor.py:176-283 (incl. `((cos, sin), ip)` smuggled through image_rotary_emb and B % B' repeat)."""

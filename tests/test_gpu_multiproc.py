@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--layers", "2", "--frames", "9", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-secondary", "--check"]
+COMMON = ["--layers", "2", "--frames", "9", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-secondary", "--no-attn-split"]
 
 
 def _run(cmd, env):
@@ -22,29 +22,34 @@ def _run(cmd, env):
     return json.loads(line)
 
 
-def _bench(n, shard):
+def _bench(n, shard, dump=None):
     env = dict(os.environ, MRAG_BENCH_ONE_GPU="1")
+    extra = ["--check", dump] if dump else []
     if n == 1:
-        return _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON, env)
+        return _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + extra, env)
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
-                 str(port), "bench.py", "--gpus", str(n), "--shard", shard] + COMMON, env)
+                 str(port), "bench.py", "--gpus", str(n), "--shard", shard] + COMMON + extra, env)
 
 
 @pytest.mark.timeout(1800)
-def test_two_rank_sequence_and_cfg_sharding_reproduce_the_single_gpu_clip(hip):
-    ref = _bench(1, "clips")
+def test_two_rank_sequence_and_cfg_sharding_reproduce_the_single_gpu_clip(hip, tmp_path):
+    """two DDIM steps of a 2-layer, full-width (3072) DiT at 9 frames: the sharded runs' final latents against the single-GPU run's.  Every
+    GEMM / norm / attention row is computed by the same arithmetic whatever the sharding (the key-split attention tail, whose summation order
+    depends on the launch shape, is off in all three runs: --no-attn-split), so the clips agree to bf16 rounding of a few tail rows: <= 0.5 %"""
+    import numpy as np
+    ref = _bench(1, "clips", str(tmp_path / "ref.npy"))
     assert ref["n_gpus"] == 1 and ref["config"]["tokens"] == 226 + 3 * 1350
+    want = np.load(tmp_path / "ref.npy")
     for shard, par in (("sequence", "sp2"), ("cfg", "dp1xcfg2")):
-        got = _bench(2, shard)
+        got = _bench(2, shard, str(tmp_path / f"{shard}.npy"))
         assert got["n_gpus"] == 2 and got["config"]["parallelism"] == par
-        a, b = ref["latents_check"], got["latents_check"]
-        scale = a["abs_mean"]
-        assert abs(a["abs_mean"] - b["abs_mean"]) <= 2e-3 * scale, shard
-        for k in ("first", "strided"):
-            assert max(abs(x - y) for x, y in zip(a[k], b[k])) <= 0.03 * scale + 0.02 * max(abs(x) for x in a[k]), (shard, k)   # bf16 latents, 2 steps
+        x = np.load(tmp_path / f"{shard}.npy")
+        assert x.shape == want.shape and np.isfinite(x).all()
+        rel = float(np.linalg.norm(x - want) / np.linalg.norm(want))
+        assert rel <= 5e-3, f"{shard}: relative Frobenius difference {rel:.4f} against the unsharded clip"
     assert _bench(2, "clips")["n_gpus"] == 2      # the judged default: one clip per rank + the end-of-loop all-gather
 
 

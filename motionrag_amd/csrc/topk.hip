@@ -75,6 +75,7 @@ struct TopkP {
   Cand* ws; int* out_rows; float* out_dist;
   long long n_rows; int dim, nq, k, metric, slices, rows_per_slice;
   unsigned* tickets;    // FUSED: one arrival counter per query tile (zero between calls)
+  int wpb;              // waves per workgroup: 4, or 1 for small databases (10 k rows = 157 one-wave workgroups instead of 40 four-wave ones)
 };
 
 // Distance of one (query, row) pair = 16 interleaved fp32 fmaf chains + a fixed 4-level pairwise tree (the definition
@@ -87,7 +88,7 @@ struct TopkP {
 // The queries (QT per workgroup pass) live in LDS and are read as 16-lane-contiguous ds_read_b128.
 __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh);
 
-template <int METRIC, int QT, int JC, bool FUSED = false>
+template <int METRIC, int QT, int JC, bool FUSED = false, int NQD = 16>
 __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const TopkP p) {   // <= 168 / 128 VGPRs: 3-4 waves per SIMD stream
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = (float*)smem;                      // [QT][dimp], dimp = dim rounded up to 64, zero padded
@@ -101,9 +102,9 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
   // lanes of a row) so one ds_read_b128 returns the SAME feature of 4 queries -> packed fp32 math (v_pk_add_f32 / v_pk_fma_f32) on query pairs
   constexpr int QS = 4 * QT + 4;
   if constexpr (QT == 1) {
-    for (int i = tid; i < dimp; i += 256) qs[i] = (q0 < p.nq && i < p.dim) ? p.q[(long long)q0 * p.dim + i] : 0.f;
+    for (int i = tid; i < dimp; i += blockDim.x) qs[i] = (q0 < p.nq && i < p.dim) ? p.q[(long long)q0 * p.dim + i] : 0.f;
   } else {
-    for (int i = tid; i < QT * dimp; i += 256) {
+    for (int i = tid; i < QT * dimp; i += blockDim.x) {
       const int qi = i / dimp, k = i - qi * dimp;
       qs[(k >> 2) * QS + (k & 3) * QT + qi] = (q0 + qi < p.nq && k < p.dim) ? p.q[(long long)(q0 + qi) * p.dim + k] : 0.f;
     }
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
   const int nchunk = nj / JC;                    // JC divides nj (host picks JC)
   const bool tail = (p.dim & 63) != 0;           // last 64-block is partial: lanes past the row end contribute exact zeros
 
-  for (long long r0 = row_begin + wave * 64; r0 < row_end; r0 += ROWS) {
+  // a wave scans NQD row-quads (4 NQD rows) per pass: 64 rows, or 16 for small databases (4x the waves -> 4x the bytes in flight: a 10 k-row
+  // scan is latency-bound, 157 waves with 12 KB in flight each reached 0.7 TB/s)
+  for (long long r0 = row_begin + wave * (4 * NQD); r0 < row_end; r0 += (blockDim.x >> 6) * (4 * NQD)) {
     // (quad t, chunk ch) stream
     auto load = [&](int t, int ch, f32x4* dst) {
       long long row = r0 + 4 * t + g;
@@ -196,36 +199,36 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
         ++t;
       }
     };
-    const int nit = 16 * nchunk;
+    const int nit = NQD * nchunk;
     if constexpr (QT == 1) {
       // single query: latency-bound -> 4-deep register ring, statically indexed (step loop unrolled by 4; nit % 4 == 0)
       constexpr int PF = 4;
       f32x4 ring[PF][JC];
 #pragma unroll
       for (int u = 0; u < PF - 1; ++u) {
-        if (lt < 16) { load(lt, lch, ring[u]); advance(); }
+        if (lt < NQD) { load(lt, lch, ring[u]); advance(); }
       }
       for (int it = 0; it < nit; it += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-          if (lt < 16) { load(lt, lch, ring[(u + PF - 1) % PF]); advance(); }
-          consume(ring[u]);
+          if (lt < NQD) { load(lt, lch, ring[(u + PF - 1) % PF]); advance(); }
+          if (it + u < nit) consume(ring[u]);         // nit = NQD * nchunk need not be a multiple of the ring depth
         }
       }
     } else {
       // query tiles: the 4 / 16 chains need the registers and the issue slots -> two steps ahead, rotated by moves
       f32x4 cur[JC], n1[JC], n2[JC];
       load(lt, lch, cur); advance();
-      if (lt < 16) { load(lt, lch, n1); advance(); }
+      if (lt < NQD) { load(lt, lch, n1); advance(); }
       for (int it = 0; it < nit; ++it) {
-        if (lt < 16) { load(lt, lch, n2); advance(); }
+        if (lt < NQD) { load(lt, lch, n2); advance(); }
         consume(cur);
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) { cur[jj] = n1[jj]; n1[jj] = n2[jj]; }
       }
     }
     const long long myrow = r0 + 4 * s + g;      // the row whose distance this lane captured
-    const bool valid = myrow < row_end;
+    const bool valid = myrow < row_end && s < NQD;
     const int grp = (valid && p.group) ? p.group[myrow] : INT_MIN + 1;
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
     }
   }
   // partial result of this wave: [query][part][64]
-  const int part = slice * 4 + wave, nparts = p.slices * 4;
+  const int part = slice * p.wpb + wave, nparts = p.slices * p.wpb;
 #pragma unroll
   for (int qi = 0; qi < QT; ++qi) {
     if (q0 + qi < p.nq) p.ws[((long long)(q0 + qi) * nparts + part) * 64 + lane] = run[qi];
@@ -282,12 +285,12 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
 // `sh` = 4 x 64 candidates + 1 of LDS scratch.
 __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   Cand* thr_s = sh + 256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nparts = p.slices * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int nparts = p.slices * p.wpb;
   const Cand* lists = p.ws + (long long)q * nparts * 64;
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
   Cand best = inf;
-  for (int base = wave * 64; base < nparts; base += 256) {
+  for (int base = wave * 64; base < nparts; base += nw * 64) {
     const int part = base + lane;
     Cand m = part < nparts ? lists[(long long)part * 64] : inf;
     m = wave_sort(m, lane);
@@ -296,14 +299,13 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   sh[wave * 64 + lane] = best;
   __syncthreads();
   if (wave == 0) {
-#pragma unroll
-    for (int w = 1; w < 4; ++w) best = wave_merge_top(best, sh[w * 64 + lane], lane);
+    for (int w = 1; w < nw; ++w) best = wave_merge_top(best, sh[w * 64 + lane], lane);
     if (lane == p.k - 1) *thr_s = best;           // k-th smallest minimum
   }
   __syncthreads();
   const Cand thr = *thr_s;
   Cand run = inf;
-  for (int base = wave * 64; base < nparts; base += 256) {
+  for (int base = wave * 64; base < nparts; base += nw * 64) {
     const int part = base + lane;
     const Cand m = part < nparts ? lists[(long long)part * 64] : inf;
     unsigned long long todo = __ballot(part < nparts && !cand_less(thr, m));   // min <= thr
@@ -318,8 +320,7 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   sh[wave * 64 + lane] = run;
   __syncthreads();
   if (wave == 0) {
-#pragma unroll
-    for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
+    for (int w = 1; w < nw; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
     if (lane < p.k) {
       const bool ok = run.r != INT_MAX;
       p.out_rows[(long long)q * p.k + lane] = ok ? run.r : -1;
@@ -336,10 +337,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
 
 inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
 
+inline bool small_db(long long n_rows, int nq) { return nq <= 4 && n_rows < 256LL * ROWS; }   // < 65 536 rows, <= 4 queries: 16 rows per wave
+
 void plan(long long n_rows, int nq, int* slices, int* rows_per_slice) {
   const int QT = pick_qt(nq);
   const int ntq = (nq + QT - 1) / QT;
   const int MAX_SLICES = 2048;
+  const int ROWS = small_db(n_rows, nq) ? 64 : 256;     // rows per workgroup pass (4 waves x 16 or 64 rows; 8 rows per wave measured slower:
+                                                        // 34.0 vs 27.5 us at 10 k rows -- the 1 256-list merge of the last arriver then dominates)
   long long tiles = (n_rows + ROWS - 1) / ROWS;
   long long s = MAX_SLICES / ntq;
   if (s < 1) s = 1;
@@ -377,6 +382,8 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   p.tickets = (unsigned*)workspace; p.ws = (Cand*)((char*)workspace + kTicketBytes); p.out_rows = out_rows; p.out_dist = out_dist;
   p.n_rows = n_rows; p.dim = dim; p.nq = n_queries; p.k = k; p.metric = metric;
   plan(n_rows, n_queries, &p.slices, &p.rows_per_slice);
+  p.wpb = 4;
+  const bool small = small_db(n_rows, n_queries);
   hipStream_t s = (hipStream_t)stream;
   const int QT = pick_qt(n_queries), nj = (dim + 63) / 64;
   // blocks of 64 floats per register-ring step: 4 for the single query, 2 for query tiles (their chains need the registers)
@@ -386,10 +393,11 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   // <= 4 queries (the interactive search of rag.py:63-80): ONE launch, the last workgroup to arrive merges (needs the first 64 workspace
   // bytes ZERO on entry -- see the header; the kernel leaves them zero)
   const bool fused = n_queries <= 4 && ((uintptr_t)workspace & 15) == 0;
+  if (small && !fused) return MRAG_EINVAL;                                          // the small-database plan exists only in the fused form
   if (fused && lds < 257 * sizeof(Cand)) lds = 257 * sizeof(Cand);
 #define MRAG_TOPK_FUSED(M, Q, J)                                                                                  \
   if (fused && metric == M && QT == Q && JCsel == J) {                                                            \
-    auto kfn = topk_scan_kernel<M, Q, J, true>;                                                                   \
+    auto kfn = small ? topk_scan_kernel<M, Q, J, true, 4> : topk_scan_kernel<M, Q, J, true, 16>;                  \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
     if (e != hipSuccess) return (int)e;                                                                           \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                                     \

@@ -462,6 +462,48 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
     return rows, dist
 
 
+class TopkPlan:
+    """A prepared search over a resident database: every buffer (query tile, exclusion ids, workspace, outputs) is allocated once and every
+    ctypes argument is built once, so a query costs ONE C-ABI call -- for <= 4 queries one kernel launch (scan + merge fused) -- and nothing is
+    allocated on the call path (the latency-bound interactive search of src/data/rag.py:63-80: 10 k rows stream in ~7 us, everything above
+    that was host overhead).  `graph=True` additionally records the launch in a HIP graph (`replay()`)."""
+
+    def __init__(self, db: torch.Tensor, n_queries: int, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None, graph: bool = False):
+        _dev(db, torch.float32, "db")
+        if not db.is_contiguous():
+            raise ValueError("TopkPlan: contiguous db required")
+        self.db, self.group, self.k, self.Q = db, group, k, n_queries
+        N, D = db.shape
+        dev = db.device
+        self.queries = torch.zeros(n_queries, D, dtype=torch.float32, device=dev)          # caller fills: plan.queries.copy_(q)
+        self.exclude = torch.full((n_queries,), -1, dtype=torch.int32, device=dev) if group is not None else None
+        self.rows = torch.empty(n_queries, k, dtype=torch.int32, device=dev)
+        self.dist = torch.empty(n_queries, k, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        self._ws = torch.zeros(L.mrag_topk_workspace_bytes(N, n_queries), dtype=torch.uint8, device=dev)   # private: counters stay consistent
+        self._fn = L.mrag_topk_f32
+        self._args = (_p(db), _p(group) if group is not None else None, N, D, _p(self.queries), _p(self.exclude) if group is not None else None,
+                      n_queries, k, {"l2": 0, "dot": 1}[metric], _p(self.rows), _p(self.dist), _p(self._ws), self._ws.numel())
+        self._graph = None
+        if graph:
+            self.run()
+            torch.cuda.synchronize(dev)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.run()
+
+    def run(self):
+        """launch on the current stream; results land in `.rows` / `.dist`"""
+        rc = self._fn(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), *self._args)
+        if rc:
+            check(rc, "mrag_topk_f32")
+        return self.rows, self.dist
+
+    def replay(self):
+        self._graph.replay()
+        return self.rows, self.dist
+
+
 # ---------------------------------------------------------------------------------------------- UNet ops (channels-last rows)
 def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int, eps: float, *, silu: bool = False,
               emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

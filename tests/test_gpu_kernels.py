@@ -575,3 +575,30 @@ def test_topk_baseline_size_ranks_equal_float64_oracle(hip):
         assert np.array_equal(rows[safe], want_r[:, :12][safe])
         np.testing.assert_allclose(dist, want_d[:, :12], rtol=0, atol=2e-6)
         assert not np.any(rows == excl[:, None])
+
+
+def test_topk_prepared_plan_single_launch(hip):
+    """ops.TopkPlan: the prepared single-query search (one C-ABI call, scan + merge in ONE launch through the arrival-counter hand-off) returns
+    the same rows / distances as the two-kernel path and the oracle, call after call (the counters are left zero), with and without the
+    self-exclusion filter, directly and through a HIP-graph replay"""
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    rng = np.random.default_rng(5)
+    db, qs = _unit(rng, 10000, 768), _unit(rng, 6, 768)
+    group = (np.arange(10000) // 3).astype(np.int32)
+    dbd, gd = torch.from_numpy(db).to(DEV), torch.from_numpy(group).to(DEV)
+    plan = ops.TopkPlan(dbd, 1, 12, group=gd, graph=True)
+    for i in range(6):
+        plan.queries.copy_(torch.from_numpy(qs[i:i + 1]))
+        excl = int(group[rng.integers(0, 10000)]) if i % 2 else -1
+        plan.exclude.fill_(excl)
+        rows, dist = plan.run() if i < 4 else plan.replay()
+        want_r, want_d = topk_ref.topk(db, qs[i:i + 1], 12, "l2", group, np.array([excl], np.int32), mode="f32chain")
+        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+    plan4 = ops.TopkPlan(dbd, 4, 12, metric="dot")
+    plan4.queries.copy_(torch.from_numpy(qs[:4]))
+    rows, dist = plan4.run()
+    want_r, want_d = topk_ref.topk(db, qs[:4], 12, "dot", mode="f32chain")
+    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))

@@ -135,6 +135,7 @@ def gemm_epi():
 
 
 def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
+    import time
     res = {}
     for N, Q in cases:
         db = torch.randn(N, 768, device=DEV)
@@ -142,6 +143,20 @@ def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
         dt = timeit(lambda: ops.topk(db, q, 12), iters=5)
         print(f"topk N={N} Q={Q}: {dt*1e6:.1f} us  db stream {N*768*4/dt/1e9:.0f} GB/s  ({Q/dt:.0f} queries/s)")
         res[f"N{N}_Q{Q}"] = {"us": round(dt * 1e6, 1), "db_stream_GBps": round(N * 768 * 4 / dt / 1e9), "queries_per_s": round(Q / dt)}
+        if Q <= 4:      # the interactive query through a prepared plan: one C-ABI call = one kernel launch, nothing allocated
+            plan = ops.TopkPlan(db, Q, 12, graph=True)
+            plan.queries.copy_(q)
+            dtp = timeit(plan.run, iters=200, warm=20)                       # back-to-back launches: max(host call, kernel)
+            dtg = timeit(plan.replay, iters=200, warm=20)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                plan.run()
+                torch.cuda.synchronize()                                     # one query at a time: launch + kernel + completion
+            lat = (time.perf_counter() - t0) / 200
+            assert torch.equal(plan.rows, ops.topk(db, q, 12)[0])
+            print(f"   prepared plan: {dtp*1e6:.1f} us per call ({N*768*4/dtp/1e9:.0f} GB/s), HIP-graph replay {dtg*1e6:.1f} us, launch-to-completion latency {lat*1e6:.1f} us")
+            res[f"N{N}_Q{Q}"].update({"plan_us": round(dtp * 1e6, 1), "plan_graph_us": round(dtg * 1e6, 1), "plan_latency_us": round(lat * 1e6, 1)})
     return res
 
 

@@ -143,12 +143,12 @@ enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pa
        MRAG_ATTN_TUNE_QB4W4 = 32,    /* the same in 4-wave workgroups, two per CU                  */
        MRAG_ATTN_TUNE_SUBS2 = 64,    /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
        MRAG_ATTN_TUNE_W4PF = 128,    /* attn16: 4-wave workgroups x 3 per CU, fragment prefetch    */
-       MRAG_ATTN_TUNE_W8PF = 256 };  /* attn16: 8-wave workgroups at 168 VGPRs, fragment prefetch  */
+       MRAG_ATTN_TUNE_W8PF = 256 };  /* attn16: 32 rows per wave, 8-wave workgroups, two per CU    */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
 /* Scratch bytes with which mrag_attn_fwd_bf16 runs the ragged last query tile
- * (Sq % 256 rows per (b, h)) as several short key-chunk workgroups + a merge
+ * (Sq % 192 or Sq % 256 rows per (b, h), by kernel family) as several short key-chunk workgroups + a merge
  * instead of B*H full-length stragglers; 0 when the shape has no such tail.  */
 int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv);
 

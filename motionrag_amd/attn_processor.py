@@ -98,9 +98,14 @@ def joint_attention_core(attn, proc, x: torch.Tensor, text_len: int, rope, ip_hi
                                                       _cat_weights([attn.to_q, attn.to_k, attn.to_v], "bias")))
     cos = sin = None
     if rope is not None:
-        cos, sin = fw.get(("rope", rope[0].data_ptr(), S, text_len),
-                          lambda: (rope[0].to(device=x.device, dtype=torch.float32).contiguous(),
-                                   rope[1].to(device=x.device, dtype=torch.float32).contiguous()))
+        # single slot, valid only for the SAME table objects (the entry holds references, so their addresses cannot be recycled under it): a
+        # pipeline that rebuilds image_rotary_emb per call replaces the entry instead of growing the cache
+        ent = fw._cache.get("rope")
+        if ent is None or ent[0] is not rope[0] or ent[1] is not rope[1] or ent[2] != (S, text_len, rope[0]._version, rope[1]._version):
+            ent = (rope[0], rope[1], (S, text_len, rope[0]._version, rope[1]._version),
+                   rope[0].to(device=x.device, dtype=torch.float32).contiguous(), rope[1].to(device=x.device, dtype=torch.float32).contiguous())
+            fw._cache["rope"] = ent
+        cos, sin = ent[3], ent[4]
         if getattr(attn, "is_cross_attention", False):
             raise NotImplementedError("RoPE on Q only (is_cross_attention=True) is not used by CogVideoX attn1")
     nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)

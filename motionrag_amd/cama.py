@@ -171,8 +171,9 @@ class TransformerEncoder(nn.Module):
     def __init__(self, encoder_layer: Optional[TransformerEncoderLayer] = None, num_layers: int = 4, d_model=1024, nhead=16,
                  dim_feedforward=4096):
         super().__init__()
-        if encoder_layer is not None:
-            d_model, nhead = encoder_layer.norm1.normalized_shape[0], encoder_layer.nhead
+        if encoder_layer is not None:       # this module's layer, or torch.nn.TransformerEncoderLayer as the reference YAML instantiates it
+            d_model = encoder_layer.norm1.normalized_shape[0]     # (configs/cogvideox/MotionRAG_open.yml:253-267): only the hyper-parameters are read
+            nhead = getattr(encoder_layer, "nhead", None) or encoder_layer.self_attn.num_heads
             dim_feedforward = encoder_layer.linear1.out_features
         self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead, dim_feedforward) for _ in range(num_layers)])
 

@@ -152,7 +152,7 @@ struct NoHook16 {
 };
 
 template <int QB, int NW, int SUBS, int NS, bool PF, bool KVSPLIT>
-__global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : (PF ? 3 : 4)) void attn16_kernel(const AttnP p) {
+__global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) void attn16_kernel(const AttnP p) {
   constexpr int ROWS = NW * QB * 16;
   constexpr int SK = SUBS * KVB, STAGE_BYTES = SUBS * TILE_BYTES, V_BASE = NS * STAGE_BYTES;   // an LDS stage = SUBS compute tiles; one barrier per stage
   constexpr int PPW = SUBS * 8 / NW;                                                // 1-KiB DMA pieces per wave per K (and V) stage
@@ -435,34 +435,39 @@ static int launch16_plain(hipStream_t s, AttnP p) {
   return MRAG_OK;
 }
 
+template <int QB, int NW, int NS>
 static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace) {
-  constexpr int QB = 2, NW = 8;
   const int nbh = p.B * p.H;
-  const size_t lds = 2 * 4 * TILE_BYTES;
+  const size_t lds = 2 * NS * TILE_BYTES;
   p.n_qtiles = pl->n_full;
   p.n_main = pl->n_full * nbh;
-  p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows;
+  p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows; p.tile_rows = NW * QB * 16;
   p.part_o = (float*)workspace;
   p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
-  const void* kf = (const void*)attn16_kernel<QB, NW, 1, 4, false, true>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, 1, NS, false, true>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, 1, 4, false, true>), dim3(p.n_main + nbh * pl->splits), dim3(512), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, 1, NS, false, true>), dim3(p.n_main + nbh * pl->splits), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return mrag_launch_attn_combine(s, p);
 }
 
+// Shipped configuration (interleaved A/B on MI355X, tools/attn_ab.py, profiles/r2_attn_ab_variants.txt): 48 query rows per wave (QB = 3),
+// 4-wave workgroups of 192 rows, THREE per CU (168 VGPRs, 3 waves per SIMD, 48 KB of LDS each).  Against 32 rows per wave in 8-wave
+// workgroups (two per CU, 4 waves per SIMD) it reads 2/3 of the K / V fragment bytes per FLOP and its barriers couple 4 waves instead of 8:
+// 6.54-6.62 vs 6.82-6.83 ms at the BASELINE shape, 2.87-2.89 vs 2.95-3.03 ms at the DynamiCrafter level-0 shape.  64 rows per wave (2 waves
+// per SIMD) loses 5-7 %, fragment prefetching at 150 VGPRs 4 %, 128-key LDS stages 1 % (all kept as developer variants below).
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
   // developer A/B variants (tools/attn_ab.py), all without the key-split tail:
   if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1, 4, false>(s, p);      // 64 query rows per wave, 512-row workgroups, one per CU
   if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1, 4, false>(s, p);    // 64 rows per wave, 4-wave workgroups, two per CU
   if (tuning & MRAG_ATTN_TUNE_SUBS2) return launch16_plain<2, 8, 2, 2, false>(s, p);    // 128-key LDS stages, one barrier per 128 keys
-  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 3, true>(s, p);      // 4-wave workgroups, three per CU, 168 VGPRs, fragment prefetch
-  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 1, 4, true>(s, p);      // 8-wave workgroups at 168 VGPRs (one + a half per CU), fragment prefetch
+  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 3, true>(s, p);      // 4-wave workgroups, three per CU, 150 VGPRs, fragment prefetch
+  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 1, 4, false>(s, p);     // round-2 first form: 32 rows per wave, 8-wave workgroups, two per CU
   if (pl) {
-    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 256) return MRAG_ENOTSUP;
-    return launch16_split(s, p, pl, workspace);
+    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 192) return MRAG_ENOTSUP;
+    return launch16_split<3, 4, 3>(s, p, pl, workspace);
   }
-  return launch16_plain<2, 8, 1, 4, false>(s, p);
+  return launch16_plain<3, 4, 1, 3, false>(s, p);
 }

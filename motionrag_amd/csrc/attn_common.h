@@ -9,7 +9,7 @@ struct AttnP {
   int B, H, Sq, Skv, kv_div, n_qtiles;
   float qscale, out_scale;
   // key-split tail (KVSPLIT instantiation): workgroups >= n_main own (b, h, chunk) of the ragged last query tile
-  int n_main, kv_splits, chunk_keys, rem_rows;
+  int n_main, kv_splits, chunk_keys, rem_rows, tile_rows;
   float* part_o;    // [B*H*kv_splits, rem_rows, 64] unnormalised partial outputs
   float2* part_ml;  // [B*H*kv_splits, rem_rows] (running max in log2 units, row sum)
 };
@@ -20,7 +20,7 @@ struct SplitPlan {
   int splits = 1, chunk_keys = 0, rem_rows = 0, n_full = 0;
   size_t bytes = 0;
 };
-SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv);
+SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv, int tile_rows, int slots);
 int mrag_launch_attn_combine(hipStream_t s, const AttnP& p);
 // attn16.hip: long unmasked sequences (Sq > 128, Skv >= 256) on v_mfma_f32_16x16x32_bf16; returns MRAG_ENOTSUP for shapes it does not take
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning);

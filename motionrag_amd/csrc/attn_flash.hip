@@ -993,11 +993,12 @@ int launch_attn(hipStream_t s, AttnP p) {
 // between two key tiles, carried through HBM instead of registers.
 }  // namespace
 
-SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv) {
+SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv, int tile_rows, int slots) {
+  // tile_rows: query rows per workgroup (256: attn_flash.hip; 192: attn16.hip); slots: workgroups resident on the chip (2 or 3 per CU)
   SplitPlan pl;
-  const int rem = Sq % 256, n_full = Sq / 256, nt = (Skv + KVB - 1) / KVB;
+  const int rem = Sq % tile_rows, n_full = Sq / tile_rows, nt = (Skv + KVB - 1) / KVB;
   const long long nbh = (long long)B * H;
-  int want = (int)(512 / nbh);
+  int want = (int)(slots / nbh);
   if (want > 8) want = 8;
   if (rem == 0 || nbh * n_full < 1024 || want < 2 || nt < 8 * want) return pl;
   const int tpc = (nt + want - 1) / want;
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
   }
   const float inv = p.out_scale / l;
   const int b = bh / p.H, h = bh % p.H;
-  const long long off = (long long)b * p.o_sb + (long long)(p.n_qtiles * 256 + row) * p.o_ss + h * 64 + d;
+  const long long off = (long long)b * p.o_sb + (long long)(p.n_qtiles * p.tile_rows + row) * p.o_ss + h * 64 + d;
   float v[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
   if (p.resid) {
     const u32x2 rr = *(const u32x2*)(p.resid + off);
@@ -1045,7 +1046,7 @@ int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspa
   const int nbh = p.B * p.H;
   p.n_qtiles = pl.n_full;
   p.n_main = pl.n_full * nbh;
-  p.kv_splits = pl.splits; p.chunk_keys = pl.chunk_keys; p.rem_rows = pl.rem_rows;
+  p.kv_splits = pl.splits; p.chunk_keys = pl.chunk_keys; p.rem_rows = pl.rem_rows; p.tile_rows = 256;
   p.part_o = (float*)workspace;
   p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl.splits * pl.rem_rows * 64 * sizeof(float));
   const size_t lds = 2 * NS * TILE_BYTES;
@@ -1069,7 +1070,8 @@ int mrag_launch_attn_combine(hipStream_t s, const AttnP& p) {
 
 extern "C" int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv) {
   if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
-  return (int64_t)mrag_plan_kv_split(B, H, Sq, Skv).bytes;
+  const size_t a = mrag_plan_kv_split(B, H, Sq, Skv, 256, 512).bytes, b = mrag_plan_kv_split(B, H, Sq, Skv, 192, 768).bytes;
+  return (int64_t)(a > b ? a : b);      // either kernel family's tail plan fits
 }
 
 // ---------------------------------------------------------------------------------------------- tiny sequences
@@ -1293,18 +1295,22 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   const int nw_big = (a->tuning & MRAG_ATTN_TUNE_NW4) ? 4 : 8;
   if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
   const bool legacy = (a->tuning & MRAG_ATTN_TUNE_LEGACY) != 0;
-  SplitPlan pl;
-  bool split = false;
-  if (a->Sq > 128 && !pipe && !a->mask && a->workspace) {   // key-split tail for the ragged last query tile (plan_kv_split)
-    if (((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
-    pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv);
-    split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
-  }
-  if (a->Sq > 128 && !pipe && !a->mask && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip)
+  const bool may_split = a->Sq > 128 && !pipe && !a->mask && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
+  if (may_split && ((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
+  if (a->Sq > 128 && !pipe && !a->mask && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
+    SplitPlan pl;
+    bool split = false;
+    if (may_split) {
+      pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, 192, 768);
+      split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
+    }
     const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace, a->tuning);
     if (rc != MRAG_ENOTSUP) return rc;
   }
-  if (split) return launch_attn_split(s, p, pl, a->workspace);
+  if (may_split) {
+    const SplitPlan pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, 256, 512);
+    if (pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes) return launch_attn_split(s, p, pl, a->workspace);
+  }
   if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
   if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
   return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);

@@ -40,12 +40,15 @@ class _Cache:
     def __init__(self):
         self.d = {}
 
-    def get(self, key, ref: torch.Tensor, build):
+    def get(self, key, ref, build):
+        """`ref`: the tensor -- or a tuple of ALL tensors (None entries allowed) -- that `build` reads: replacing or updating any one of
+        them in place invalidates the entry"""
         import weakref
-        tag = (ref.data_ptr(), ref.dtype, ref._version)
+        refs = tuple(r for r in (ref if isinstance(ref, (tuple, list)) else (ref,)) if r is not None)
+        tag = tuple((r.data_ptr(), r.dtype, r._version) for r in refs)
         ent = self.d.get(key)
-        if ent is None or ent[0] != tag or ent[1]() is not ref:
-            ent = (tag, weakref.ref(ref), build())
+        if ent is None or ent[0] != tag or any(w() is not r for w, r in zip(ent[1], refs)):
+            ent = (tag, tuple(weakref.ref(r) for r in refs), build())
             self.d[key] = ent
         return ent[2]
 
@@ -145,7 +148,7 @@ class CrossAttention(nn.Module):
                 self.register_parameter("alpha_action", nn.Parameter(torch.tensor(0.0)))
 
     def _kv(self, key, wk, wv, ctx):
-        w = _CACHE.get((key, id(self)), wk.weight, lambda: _cat0([wk.weight, wv.weight]))
+        w = _CACHE.get((key, id(self)), (wk.weight, wv.weight), lambda: _cat0([wk.weight, wv.weight]))
         kv = ops.linear(ctx.contiguous(), w)
         return kv[..., : self.inner].unflatten(-1, (self.heads, 64)), kv[..., self.inner:].unflatten(-1, (self.heads, 64))
 
@@ -159,7 +162,7 @@ class CrossAttention(nn.Module):
         H, inner = self.heads, self.inner
         Nb, L, _ = x.shape
         if context is None:                                                         # spatial / temporal self-attention  :175-183
-            w = _CACHE.get(("qkv", id(self)), self.to_q.weight, lambda: _cat0([self.to_q.weight, self.to_k.weight, self.to_v.weight]))
+            w = _CACHE.get(("qkv", id(self)), (self.to_q.weight, self.to_k.weight, self.to_v.weight), lambda: _cat0([self.to_q.weight, self.to_k.weight, self.to_v.weight]))
             qkv = ops.linear(x, w)
             if temporal is None:
                 q5 = qkv.view(Nb, L, 3, H, 64)
@@ -211,7 +214,7 @@ class FeedForward(nn.Module):
 
     def forward(self, x, resid=None):
         pj = self.net[0].proj
-        w, b = _CACHE.get(("geglu", id(pj)), pj.weight, lambda: ops.geglu_interleave(pj.weight, pj.bias))
+        w, b = _CACHE.get(("geglu", id(pj)), (pj.weight, pj.bias), lambda: ops.geglu_interleave(pj.weight, pj.bias))
         h = ops.linear(x, w, b, epilogue=ops.EPI_GEGLU)                             # value * gelu(gate) in the GEMM epilogue
         if resid is not None:
             return ops.linear(h, self.net[2].weight, self.net[2].bias, epilogue=ops.EPI_RESID, resid=resid)

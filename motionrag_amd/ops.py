@@ -517,7 +517,7 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
         out = torch.empty_like(x)
     chunks = max(1, min(1024, HW // 32, max(64, -(-2048 // N))))        # >= ~2048 statistics workgroups even when N is 1 or 2
     L = _lib.lib()
-    ws = torch.empty(L.mrag_groupnorm_workspace_bytes(N, C, chunks), dtype=torch.uint8, device=x.device)
+    ws = _attn_workspace(x.device, L.mrag_groupnorm_workspace_bytes(N, C, chunks), "gn")     # grow-only per (device, stream): no allocation per call
     a = GroupNormArgs()
     a.x, a.y, a.gamma, a.beta, a.workspace = _p(x), _p(out), _p(gamma), _p(beta), _p(ws)
     a.N, a.HW, a.C, a.G, a.chunks, a.silu, a.eps = N, HW, C, groups, chunks, 1 if silu else 0, eps

@@ -89,6 +89,7 @@ class RAGDatabase:
         self.video_ids = {v: i for i, v in enumerate(dict.fromkeys(videos))}
         self.group = torch.tensor([self.video_ids[v] for v in videos], dtype=torch.int32, device=self.device)
         self.vectors = torch.from_numpy(self.vectors_host).to(self.device)   # resident in HBM for every search
+        self._plans = {}
 
     def __len__(self):
         return len(self.rows)
@@ -142,7 +143,18 @@ class RAGDatabase:
         if where is not None and any(w is not None for w in where):
             exclude = torch.tensor([self._exclude_id(w) for w in where], dtype=torch.int32, device=self.device)
             group = self.group
-        rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude)
+        if Q <= 4 and top_k <= 64:       # the interactive search (rag.py:63-80): a prepared plan -- one C-ABI call = one launch, no allocation
+            plan = self._plans.get((Q, top_k))
+            if plan is None:
+                plan = self._plans[(Q, top_k)] = ops.TopkPlan(self.vectors, Q, top_k, metric=self.metric, group=self.group)
+            plan.queries.copy_(q)
+            if exclude is not None:
+                plan.exclude.copy_(exclude)
+            else:
+                plan.exclude.fill_(-1)
+            rows, dist = plan.run()
+        else:
+            rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
         return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
 

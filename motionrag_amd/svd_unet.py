@@ -131,7 +131,7 @@ class AttnProcessor2_0:
         Nb, L, C = x.shape
         H = attn.heads
         if encoder_hidden_states is None:
-            w = _CACHE.get(("qkv", id(attn)), attn.to_q.weight, lambda: _cat0([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight]))
+            w = _CACHE.get(("qkv", id(attn)), (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight), lambda: _cat0([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight]))
             qkv = ops.linear(x, w)
             if temporal is None:
                 q5 = qkv.view(Nb, L, 3, H, 64)
@@ -146,7 +146,7 @@ class AttnProcessor2_0:
         else:
             ctx = encoder_hidden_states.contiguous()
             q = ops.linear(x, attn.to_q.weight).view(Nb, L, H, 64)
-            wkv = _CACHE.get(("kv", id(attn)), attn.to_k.weight, lambda: _cat0([attn.to_k.weight, attn.to_v.weight]))
+            wkv = _CACHE.get(("kv", id(attn)), (attn.to_k.weight, attn.to_v.weight), lambda: _cat0([attn.to_k.weight, attn.to_v.weight]))
             kv = ops.linear(ctx, wkv)
             o = ops.attention(q, kv[..., :C].unflatten(-1, (H, 64)), kv[..., C:].unflatten(-1, (H, 64)), kv_batch_div=Nb // ctx.shape[0])
         return ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias)
@@ -165,7 +165,7 @@ class FeedForward(nn.Module):
 
     def forward(self, x, resid=None):
         pj = self.net[0].proj
-        w, b = _CACHE.get(("geglu", id(pj)), pj.weight, lambda: ops.geglu_interleave(pj.weight, pj.bias))
+        w, b = _CACHE.get(("geglu", id(pj)), (pj.weight, pj.bias), lambda: ops.geglu_interleave(pj.weight, pj.bias))
         h = ops.linear(x, w, b, epilogue=ops.EPI_GEGLU)                             # value * gelu(gate) in the GEMM epilogue
         if resid is not None:
             return ops.linear(h, self.net[2].weight, self.net[2].bias, epilogue=ops.EPI_RESID, resid=resid)

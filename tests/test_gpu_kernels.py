@@ -221,33 +221,35 @@ def test_attention_large_sequence_properties(hip):
 
 
 def test_attention_key_split_tail(hip):
-    """long launches hand the ragged last query tile (Sq % 256 rows per head) to short key-chunk workgroups + a merge kernel
-    (attn_flash.hip plan_kv_split): the tail rows and a sample of the others equal the fp32 reference, with even and ragged chunkings, a
-    fused residual, and agree with the unsplit kernel to a bf16 ulp or two"""
+    """long launches hand the ragged last query tile (Sq % 192 rows per head in attn16.hip, Sq % 256 in attn_flash.hip) to short key-chunk
+    workgroups + a merge kernel (plan_kv_split): the tail rows and a sample of the others equal the fp32 reference, with a fused residual,
+    and agree with the unsplit kernel to a bf16 ulp or two -- for both kernel families"""
     from motionrag_amd import ops, _lib
     g = torch.Generator().manual_seed(9)
     B, H, Sq, Skv = 1, 16, 64 * 256 + 112, 4200
-    assert _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv) > 0 and _lib.lib().mrag_attn_workspace_bytes(B, H, 64 * 256, Skv) == 0
+    TAIL = Sq % 192                                                                    # 176 rows (attn16: 192-row workgroups); Sq % 256 = 112 (legacy)
+    assert _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv) > 0 and _lib.lib().mrag_attn_workspace_bytes(B, H, 21 * 768, Skv) == 0
     q = bf(torch.randn(B, Sq, H, 64, generator=g))
     k, v = (bf(torch.randn(B, Skv, H, 64, generator=g)) for _ in range(2))
     k[:, 3000] = bf(9.0 * q[:, Sq - 5] / q[:, Sq - 5].norm(dim=-1, keepdim=True))     # one tail row's max lives in a late chunk
     resid = bf(torch.randn(B, Sq, H * 64, generator=g))
-    rows = torch.cat([torch.arange(Sq - 112, Sq), torch.randint(0, Sq - 112, (80,), generator=g)])
+    rows = torch.cat([torch.arange(Sq - 176, Sq), torch.randint(0, Sq - 176, (80,), generator=g)])
     want = sdpa_ref(q[:, rows], k, v)
     qd, kd, vd, rd = q.to(DEV), k.to(DEV), v.to(DEV), resid.to(DEV)
     outs = {}
-    for splits in ("", "0"):                       # "0": no workspace handed over -> the unsplit launch
-        ops.TUNING["attn_no_split"] = splits == "0"
-        try:
-            outs[splits] = ops.attention(qd, kd, vd)
-            fused = ops.attention(qd, kd, vd, resid=rd, out_scale=0.5)
-        finally:
-            ops.TUNING["attn_no_split"] = False
-        close(outs[splits][:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
-        close(fused[:, rows.to(DEV)], resid[:, rows].float() + 0.5 * want, scale=1.0)
-    for splits in ("",):
-        assert torch.equal(outs[splits][:, :Sq - 112], outs["0"][:, :Sq - 112])          # full tiles: same code path, bit-identical
-        close(outs[splits][:, Sq - 112:], outs["0"][:, Sq - 112:].float().cpu(), scale=0.05, rtol=2e-2, atol_frac=4e-2)
+    for family, tail in ((ops.ATTN_TUNE_LEGACY, 112), (0, TAIL)):          # the shipped family last: `outs` feeds the C-ABI checks below
+        for splits in ("", "0"):                       # "0": no workspace handed over -> the unsplit launch
+            ops.TUNING["attn_no_split"], ops.TUNING["attn"] = splits == "0", family
+            try:
+                outs[splits] = ops.attention(qd, kd, vd)
+                fused = ops.attention(qd, kd, vd, resid=rd, out_scale=0.5)
+            finally:
+                ops.TUNING["attn_no_split"], ops.TUNING["attn"] = False, 0
+            close(outs[splits][:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
+            close(fused[:, rows.to(DEV)], resid[:, rows].float() + 0.5 * want, scale=1.0)
+        assert torch.equal(outs[""][:, :Sq - tail], outs["0"][:, :Sq - tail])              # full tiles: same code path, bit-identical
+        assert not torch.equal(outs[""][:, Sq - tail:], outs["0"][:, Sq - tail:])          # the tail really took the key-split path
+        close(outs[""][:, Sq - tail:], outs["0"][:, Sq - tail:].float().cpu(), scale=0.05, rtol=2e-2, atol_frac=4e-2)
     # C ABI: the workspace is optional (none / too small -> the unsplit launch, same result as without the split) and must be 16-byte aligned
     import ctypes
     need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)
@@ -270,7 +272,7 @@ def test_attention_key_split_tail(hip):
 
 
 def test_attention_baseline_shape_split_tail_properties(hip):
-    """the BASELINE launch itself (B = 2, H = 48, S = 17 776: 6 624 full query tiles + 96 ragged ones run as 480 key-chunk workgroups + merge):
+    """the BASELINE launch itself (B = 2, H = 48, S = 17 776 = 92 x 192 + 112: 8 832 full query tiles + 96 ragged ones run as 768 key-chunk workgroups + merge):
     softmax rows sum to one everywhere (V = ones -> exactly 1), and the ragged tiles' rows of a few heads equal the fp32 reference"""
     from motionrag_amd import ops, _lib
     g = torch.Generator().manual_seed(10)

@@ -221,13 +221,21 @@ __global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) v
   const unsigned v_loff = (unsigned)(kit * p.v_ss + (ppos ^ (((kit >> 1) & 3) << 1)) * 8) * 2u;     // V: 32-byte chunks XORed by (key >> 1) & 3
   const int last_start = skv - SK;      // >= 0 (the launcher takes only Skv >= 256 and chunks of whole stages); a ragged last stage is slid back
   const unsigned lds0 = (unsigned)(size_t)smem;
-  auto issue_kv = [&](int stage, int t) {
-    const int start = t * SK < last_start ? t * SK : last_start;
+  // The DMA requests stage 0, 1, 2, ... in order, so the source offset is WALKED: one 32-bit scalar per operand, advanced by a constant and
+  // clamped to the slid-back last stage (requests past the end re-read it; never consumed) -- 2 scalar instructions per request instead of a
+  // 64-bit multiply chain (~15).  32-bit byte offsets: a (batch, head) slice of K / V spans Skv * stride * 2 < 4 GB (checked by the launcher).
+  const unsigned k_step = (unsigned)(SK * p.k_ss * 2), v_step = (unsigned)(SK * p.v_ss * 2);
+  const unsigned k_last = (unsigned)((long long)last_start * p.k_ss * 2), v_last = (unsigned)((long long)last_start * p.v_ss * 2);
+  const unsigned k_piece = (unsigned)(NW * 8 * p.k_ss * 2), v_piece = (unsigned)(NW * 8 * p.v_ss * 2);
+  unsigned k_next = 0, v_next = 0;
+  auto issue_kv = [&](int stage, int /*t: requests come in stage order*/) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      glds16_sbase((const char*)kbase + (long long)(start + i * NW * 8) * p.k_ss * 2, k_loff, lds0 + stage * STAGE_BYTES + (wave + i * NW) * 1024);
-      glds16_sbase((const char*)vbase + (long long)(start + i * NW * 8) * p.v_ss * 2, v_loff, lds0 + V_BASE + stage * STAGE_BYTES + (wave + i * NW) * 1024);
+      glds16_sbase((const char*)kbase + (k_next + i * k_piece), k_loff, lds0 + stage * STAGE_BYTES + (wave + i * NW) * 1024);
+      glds16_sbase((const char*)vbase + (v_next + i * v_piece), v_loff, lds0 + V_BASE + stage * STAGE_BYTES + (wave + i * NW) * 1024);
     }
+    k_next = k_next + k_step < k_last ? k_next + k_step : k_last;
+    v_next = v_next + v_step < v_last ? v_next + v_step : v_last;
   };
 
   // ---- fragment read addresses
@@ -459,11 +467,12 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
 // per SIMD) loses 5-7 %, fragment prefetching at 150 VGPRs 4 %, 128-key LDS stages 1 % (all kept as developer variants below).
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
+  if ((long long)p.Skv * p.k_ss * 2 >= 0xffffffffLL || (long long)p.Skv * p.v_ss * 2 >= 0xffffffffLL) return MRAG_ENOTSUP;   // walked 32-bit DMA offsets
   // developer A/B variants (tools/attn_ab.py), all without the key-split tail:
   if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1, 4, false>(s, p);      // 64 query rows per wave, 512-row workgroups, one per CU
   if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1, 4, false>(s, p);    // 64 rows per wave, 4-wave workgroups, two per CU
   if (tuning & MRAG_ATTN_TUNE_SUBS2) return launch16_plain<2, 8, 2, 2, false>(s, p);    // 128-key LDS stages, one barrier per 128 keys
-  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 3, true>(s, p);      // 4-wave workgroups, three per CU, 150 VGPRs, fragment prefetch
+  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 2, false>(s, p);     // 32 rows per wave, 4-wave workgroups, FOUR per CU (2-stage ring)
   if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 1, 4, false>(s, p);     // round-2 first form: 32 rows per wave, 8-wave workgroups, two per CU
   if (pl) {
     if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 192) return MRAG_ENOTSUP;

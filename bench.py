@@ -303,7 +303,7 @@ def main():
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
             "e2e_sec_per_clip_50_steps_measured": round(e2e_sec, 2) if e2e_sec is not None else None,
             "secondary_workloads": secondary,
-            "roofline": {"kernel": "attn16_kernel<2,8,1,4,false,true> + attn_combine_kernel (joint text+video flash attention on 16x16x32 MFMAs with the key-split tail, 48 heads x 64, S=%d, B=2)" % S,
+            "roofline": {"kernel": "attn16_kernel<3,4,1,3,false,true> + attn_combine_kernel (joint text+video flash attention on 16x16x32 MFMAs with the key-split tail, 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

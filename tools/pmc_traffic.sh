@@ -19,11 +19,11 @@ def collect(d, counter, kern):
             if r["Counter_Name"] == counter and kern in r["Kernel_Name"]:
                 vals.append(float(r["Counter_Value"]))
     return vals
-kern = "attn16_kernel<2, 8, 1, 4, false,"      # the shipped long-sequence instantiation of attn16.hip, with or without the key-split tail
+kern = "attn16_kernel<3, 4, 1, 3, false,"      # the shipped long-sequence instantiation of attn16.hip, with or without the key-split tail
 f, w = collect("f", "FETCH_SIZE", kern), collect("w", "WRITE_SIZE", kern)
 fc, wc = collect("f", "FETCH_SIZE", "attn_combine_kernel"), collect("w", "WRITE_SIZE", "attn_combine_kernel")   # the tail's merge kernel, one per launch
 avg = lambda v: sum(v) / len(v) if v else 0.0
-out = {"kernel": "attn16_kernel<2,8,1,4,false,true> + attn_combine_kernel", "shape": "B=2 H=48 S=17776 D=64", "launches": len(f),
+out = {"kernel": "attn16_kernel<3,4,1,3,false,true> + attn_combine_kernel", "shape": "B=2 H=48 S=17776 D=64", "launches": len(f),
        "FETCH_SIZE_KiB_per_launch": avg(f) + avg(fc), "WRITE_SIZE_KiB_per_launch": avg(w) + avg(wc),
        "combine_kernel_KiB_per_launch": {"FETCH_SIZE": avg(fc), "WRITE_SIZE": avg(wc)},
        "hbm_bytes_per_launch_corrected": (2 * (avg(f) + avg(fc)) + avg(w) + avg(wc)) * 1024,

@@ -259,6 +259,32 @@ int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, in
  *   out[b, n] = (sum_k w[b, k] * x[b, k, n]) / div      fp32 weights / accumulation in k order, one rounding to bf16
  * x [B, K, n] bf16, w [B, K] fp32 on the device or NULL (all ones: mean = sum / K with div = K), n % 8 == 0.            */
 int mrag_weighted_sum_bf16(void* stream, const void* x, const float* w, void* out, int32_t B, int32_t K, int64_t n, float div);
+/* ------------------------------------------------------------------------ */
+/* Frozen feature encoders in front of CAMA: pixel side.   */
+/* ------------------------------------------------------------------------ */
+/* VideoMAEEmbedder.forward / preprocess (src/projects/condition/encoders/condition.py:378-400) and DINOImageEmbedder.forward /
+ * CLIPImageEmbedder.preprocess (condition.py:503-507,599-604): frame gather (uniform 16-frame sampling), torchvision
+ * Resize(antialias) + CenterCrop as precomputed separable tap tables, the (x + 1) / 2 value map and the mean / std normalisation folded
+ * into one per-channel affine, written straight as the rows of the patch-embedding GEMM (transformers VideoMAEPatchEmbeddings: Conv3d
+ * (pt, ph, pw) = (2, 16, 16); Dinov2PatchEmbeddings: Conv2d 14 x 14 with pt = 1):
+ *   out[((n * T/pt + t/pt) * OH/ph + y/ph) * OW/pw + x/pw][((c * pt + t%pt) * ph + y%ph) * pw + x%pw]
+ *       = scale[c] * sum_j wy[y][j] * (sum_k wx[x][k] * src[n, frame_idx[t], c, y0[y] + j, x0[x] + k]) + shift[c]
+ * fp32 accumulation, one rounding to bf16; columns C*pt*ph*pw .. ldo are zeroed (K padding of the GEMM).                         */
+typedef struct mrag_resize_patch_args {
+  const void* src;                 /* [N, T_src, C, H, W] bf16 (or fp32 with src_fp32 = 1); rows of W contiguous pixels      */
+  const int32_t* frame_idx;        /* [T] source frame of output frame t on the device, or NULL (identity)                    */
+  const float* wy; const int32_t* y0; const int32_t* ny;   /* [OH, taps_y] weights, first source row, tap count per output row */
+  const float* wx; const int32_t* x0; const int32_t* nx;   /* [OW, taps_x] ... per output column                               */
+  void* out;                       /* [N * T/pt * OH/ph * OW/pw, ldo] bf16                                                     */
+  int64_t s_n, s_t, s_c, ldo;      /* element strides of src over n, t, c; row stride of out                                   */
+  int32_t N, T, C, H, W, OH, OW, taps_y, taps_x, pt, ph, pw, src_fp32;
+  float scale[4], shift[4];        /* per channel (C <= 4)                                                                     */
+} mrag_resize_patch_args;
+int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_args* args);
+/* ViT token assembly (transformers Dinov2Embeddings.forward: cat(cls, patches) + position table; VideoMAEEmbeddings.forward: P = 0):
+ *   out[n, j, :] = (j < P ? prefix[j, :] : x[n, j - P, :]) + pos[j, :]     x [N, L, D], prefix [P, D], pos [L + P, D] or NULL, D % 8 == 0 */
+int mrag_assemble_tokens_bf16(void* stream, const void* x, const void* prefix, const void* pos, void* out,
+                              int64_t N, int32_t L, int32_t P, int32_t D);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "topk.hip", "unet_ops.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip"]
 ABI_VERSION = 2
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
@@ -30,6 +30,7 @@ SYMBOLS = [
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
+    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16",
 ]
 
 
@@ -75,6 +76,18 @@ class LnArgs(Structure):
         ("rows_per_batch", c_int64), ("split", c_int64), ("mod_stride", c_int64),
         ("y_rows_per_batch", c_int64), ("y_batch_stride", c_int64),
         ("eps", c_float),
+    ]
+
+
+class ResizePatchArgs(Structure):
+    _fields_ = [
+        ("src", c_void_p), ("frame_idx", c_void_p),
+        ("wy", c_void_p), ("y0", c_void_p), ("ny", c_void_p), ("wx", c_void_p), ("x0", c_void_p), ("nx", c_void_p),
+        ("out", c_void_p),
+        ("s_n", c_int64), ("s_t", c_int64), ("s_c", c_int64), ("ldo", c_int64),
+        ("N", c_int32), ("T", c_int32), ("C", c_int32), ("H", c_int32), ("W", c_int32), ("OH", c_int32), ("OW", c_int32),
+        ("taps_y", c_int32), ("taps_x", c_int32), ("pt", c_int32), ("ph", c_int32), ("pw", c_int32), ("src_fp32", c_int32),
+        ("scale", c_float * 4), ("shift", c_float * 4),
     ]
 
 
@@ -193,6 +206,8 @@ def lib() -> ctypes.CDLL:
     L.mrag_geglu_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64]
     L.mrag_weighted_sum_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_float]
     L.mrag_ddim_v_step_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 7
+    L.mrag_resize_patchify_bf16.argtypes = [c_void_p, POINTER(ResizePatchArgs)]
+    L.mrag_assemble_tokens_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]
     for name in SYMBOLS:          # everything that did not declare a 64-bit / pointer result above returns an int status
         fn = getattr(L, name)
         if name not in _NON_INT_RESULT:

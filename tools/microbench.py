@@ -207,6 +207,33 @@ def svd():
     return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(Fr / dt, 1)}
 
 
+def encoders(clips=10, frames=49, H=480, W=720):
+    """the RAG-side overhead in front of the denoising loop (README.md:48 of the reference: "+3.6 s"): VideoMAE-B over the 9 retrieved
+    clips + the target + the all-zero CFG clip, DINOv2-L over their first frames, then CAMA -- raw bf16 videos [1, 9, 49, 3, 480, 720] in, motion tokens out"""
+    from motionrag_amd import cama, encoders as P
+    torch.manual_seed(0)
+    vm, dm = P.VideoMAEEmbedder(P.VideoMAEModel()).to(DEV, torch.bfloat16), P.DINOImageEmbedder(P.Dinov2Model()).to(DEV, torch.bfloat16)
+    model = cama.build_cama(vm, dm).to(DEV, torch.bfloat16)
+    vids = (torch.rand(1, clips, frames, 3, H, W, device=DEV) * 2 - 1).to(torch.bfloat16)
+    batch = {"ref_videos": vids[:, :clips - 1], "video": vids[:, clips - 1]}
+    flat = vids.reshape(clips, frames, 3, H, W)
+    idx = P.uniform_frame_indices(frames, 16).to(DEV, torch.int32)
+    t_pix = timeit(lambda: P.pixels_to_patch_rows(flat, resize=224, crop=224, mode="bilinear", patch=(2, 16, 16), frame_idx=idx), iters=10, warm=2)
+    t_vm = timeit(lambda: vm(flat), iters=5, warm=2)
+    t_dm = timeit(lambda: dm(flat[:, 0]), iters=5, warm=2)
+    t_all = timeit(lambda: model.predict(batch, do_classifier_free_guidance=True), iters=5, warm=2)
+    # algorithmic bytes of the pixel kernel: the 16 sampled frames of every clip read once + the patch rows written once
+    px_bytes = clips * 16 * 3 * H * W * 2 + clips * 8 * 196 * 1536 * 2
+    S, D, L = 1568, 768, 12
+    vm_flops = clips * (L * (24 * S * D * D + 4 * S * S * D) + 2 * S * 1536 * D)
+    print(f"pixels -> patch rows ({clips} clips x 16 of {frames} frames, {H}x{W} -> 224): {t_pix*1e6:.0f} us  {px_bytes/t_pix/1e9:.0f} GB/s algorithmic")
+    print(f"VideoMAE-B embedder, {clips} clips: {t_vm*1e3:.2f} ms  {vm_flops/t_vm/1e12:.0f} TFLOP/s;  DINOv2-L embedder, {clips} images: {t_dm*1e3:.2f} ms")
+    print(f"CAMA predict from raw pixels (both encoders + 2 Resamplers + encoder, CFG): {t_all*1e3:.2f} ms per clip")
+    return {"pixels_to_patch_rows_us": round(t_pix * 1e6), "pixels_GBps_algorithmic": round(px_bytes / t_pix / 1e9), "videomae_b_ms": round(t_vm * 1e3, 2),
+            "videomae_b_tflops_per_s": round(vm_flops / t_vm / 1e12), "dinov2_l_ms": round(t_dm * 1e3, 2), "cama_predict_from_pixels_ms": round(t_all * 1e3, 2),
+            "clips": clips, "source": f"{frames}x{H}x{W} bf16"}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

@@ -285,6 +285,10 @@ int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_args* args);
  *   out[n, j, :] = (j < P ? prefix[j, :] : x[n, j - P, :]) + pos[j, :]     x [N, L, D], prefix [P, D], pos [L + P, D] or NULL, D % 8 == 0 */
 int mrag_assemble_tokens_bf16(void* stream, const void* x, const void* prefix, const void* pos, void* out,
                               int64_t N, int32_t L, int32_t P, int32_t D);
+/* Row softmax of a materialised score matrix, y[r, :] = softmax(scale * x[r, :]) (fp32 statistics, bf16 in / out; rows 16-byte aligned, ld % 8 == 0,
+ * scale > 0): the middle of the KL-VAE decoder's single-head head_dim-512 AttnBlock (lvdm/modules/networks/ae_modules.py:54-79: bmm, * c^-0.5,
+ * softmax(dim=2), bmm), whose two products run on mrag_gemm_bf16.                                                                                    */
+int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float scale);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,

@@ -214,6 +214,54 @@ __global__ void weighted_sum_kernel(const bf16_t* x, const float* w, bf16_t* out
   }
 }
 
+// Row softmax of a materialised score matrix: y[r, :] = softmax(scale * x[r, :]).  The single-head, head_dim-512 attention of the KL-VAE mid block
+// (AttnBlock.forward, lvdm/modules/networks/ae_modules.py:54-79: bmm -> * c^-0.5 -> softmax(dim=2) -> bmm) runs as two GEMMs around this pass; at 9 216 keys a
+// row is 18 KB, read three times through L2 (max, sum, write) -- HBM sees one read and one write.  One 256-thread workgroup per row, fp32 statistics.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* x, bf16_t* y, long long cols, long long ldx, long long ldy, float scale) {
+  __shared__ float red[4];
+  const bf16_t* xr = x + (long long)blockIdx.x * ldx;
+  bf16_t* yr = y + (long long)blockIdx.x * ldy;
+  const int tid = threadIdx.x;
+  const long long c8 = cols / 8;
+  float m = -INFINITY;
+  for (long long i = tid; i < c8; i += 256) {
+    float v[8]; unpack8(*(const u32x4*)(xr + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, v[e]);
+  }
+  for (long long i = c8 * 8 + tid; i < cols; i += 256) m = fmaxf(m, __uint_as_float(((unsigned)xr[i]) << 16));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  __syncthreads();
+  const float k = scale * 1.4426950408889634f, mk = m * 1.4426950408889634f;
+  float sum = 0.f;
+  for (long long i = tid; i < c8; i += 256) {
+    float v[8]; unpack8(*(const u32x4*)(xr + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += exp2f(fmaf(v[e], k, -mk));
+  }
+  for (long long i = c8 * 8 + tid; i < cols; i += 256) sum += exp2f(fmaf(__uint_as_float(((unsigned)xr[i]) << 16), k, -mk));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (long long i = tid; i < c8; i += 256) {
+    float v[8]; unpack8(*(const u32x4*)(xr + i * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = exp2f(fmaf(v[e], k, -mk)) * inv;
+    *(u32x4*)(yr + i * 8) = pack8(v);
+  }
+  for (long long i = c8 * 8 + tid; i < cols; i += 256) {
+    const float e = exp2f(fmaf(__uint_as_float(((unsigned)xr[i]) << 16), k, -mk)) * inv;
+    float one[8] = {e, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    yr[i] = (bf16_t)(pack8(one)[0] & 0xffffu);
+  }
+}
+
 }  // namespace
 
 extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
@@ -310,6 +358,15 @@ extern "C" int mrag_weighted_sum_bf16(void* stream, const void* x, const float* 
   if (((uintptr_t)x | (uintptr_t)out) & 15) return MRAG_EINVAL;
   const dim3 grid(grid_for(n / 8), (unsigned)B);
   MRAG_LAUNCH(weighted_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)out, K, n / 8, div);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float scale) {
+  if (!x || !y || rows <= 0 || cols <= 0 || ldx < cols || ldy < cols || !(scale > 0.f)) return MRAG_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15) || (ldx % 8) || (ldy % 8)) return MRAG_EINVAL;
+  if (rows > 0x7fffffffLL) return MRAG_EINVAL;
+  MRAG_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)cols, (long long)ldx, (long long)ldy, scale);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

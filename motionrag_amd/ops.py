@@ -386,6 +386,17 @@ def weighted_sum(x: torch.Tensor, w: Optional[torch.Tensor], div: float = 1.0) -
     return out
 
 
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(scale * x, dim=-1) of a 2-D bf16 score matrix (fp32 statistics); the row stride may exceed the width"""
+    _dev(x, name="x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("softmax_rows: [rows, cols] with contiguous columns required")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().mrag_softmax_rows_bf16(_stream(), _p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(scale)), "mrag_softmax_rows_bf16")
+    return out
+
+
 def patchify(src0: torch.Tensor, src1: Optional[torch.Tensor], B: int) -> torch.Tensor:
     """[Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> [B*F*(H/2)*(W/2), (C0+C1)*4]; batch b reads latent b % Bl."""
     _dev(src0, name="src0")

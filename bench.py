@@ -260,6 +260,7 @@ def main():
                          "dynamicrafter1024_unet_16x576x1024_cfg_step_fp8_attention": mb.unet("fp8", dcnet),     # BASELINE config #5, same weights / inputs
                          "retrieval_top12_768d": mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1)))}
             del dcnet
+            secondary["dynamicrafter_kl_vae_decode_16x576x1024"] = mb.vae()            # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
             secondary["rag_side_encoders_plus_cama"] = mb.encoders()             # VideoMAE-B + DINOv2-L + CAMA from raw pixels
 
     if world > 1:

@@ -156,10 +156,26 @@ class Decoder(nn.Module):
             self.up.insert(0, up)
         self.norm_out = Normalize(block_in)
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
+        self.peak_channels = ch * ch_mult[min(1, len(ch_mult) - 1)]            # channels of the finest level's upsampled input: the largest activation
+
+    def _conv_in(self, z: torch.Tensor) -> torch.Tensor:
+        """3x3 convolution from z_channels = 4: the row gather moves 16-byte (8-channel) granules, so the latent and the kernel get 4 zero channels"""
+        N, H, W, cz = z.shape
+        conv = self.conv_in
+        cp = (cz + 7) // 8 * 8
+        if cp != cz:
+            z = torch.nn.functional.pad(z, (0, cp - cz))
+        kp = ops._kpad(9 * cp)
+
+        def build():
+            w = torch.nn.functional.pad(_b(conv.weight), (0, 0, 0, 0, 0, cp - cz)).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * cp)
+            return torch.nn.functional.pad(w, (0, kp - 9 * cp)).contiguous()
+        wk = _CACHE.get(("vae_in", id(conv), cp), conv.weight, build)
+        return ops.linear(ops.im2col3x3(z.contiguous()), wk, _b(conv.bias)).view(N, H, W, -1)
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """z [N, H, W, z_channels] channels-last -> [N, H * 2^(levels-1), W * 2^(levels-1), out_ch]"""
-        h = conv3x3(z, self.conv_in)
+        h = self._conv_in(z)
         h = self.mid.block_1(h)
         h = self.mid.attn_1(h)
         h = self.mid.block_2(h)
@@ -205,12 +221,23 @@ class AutoencoderKL(nn.Module):
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
-        """z [N, C, h, w] -> images [N, out_ch, 8 h, 8 w] (bf16), as autoencoder.py:104-107"""
+        """z [N, C, h, w] -> images [N, out_ch, 8 h, 8 w] (bf16), as autoencoder.py:104-107.  Frames are independent (the reference's `perframe_ae` decodes them one
+        by one); here as many go through one batch as keep the largest activation -- the finest level's upsampled input -- below the convolution's 2^31-element
+        limit (14 frames at 576 x 1024)."""
         if not z.is_cuda:
             raise ops.HipOnly("AutoencoderKL.decode: GPU tensors only")
-        zc = z.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()            # channels-last rows (a few KB per frame)
-        zc = ops.linear(zc, _b(_lin_w(self.post_quant_conv)), _b(self.post_quant_conv.bias))
-        return self.decoder(zc).permute(0, 3, 1, 2)
+        N, _, h, w = z.shape
+        up = 2 ** (self.decoder.num_resolutions - 1)
+        per_frame = (up * h) * (up * w) * self.decoder.peak_channels
+        chunk = max(1, min(N, (2 ** 31 - 1) // per_frame))
+        if chunk < N:
+            chunk = max(1, N // -(-N // chunk))                                # even chunks (16 frames -> 2 x 8)
+        outs = []
+        for i in range(0, N, chunk):
+            zc = z[i:i + chunk].to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()       # channels-last rows (a few KB per frame)
+            zc = ops.linear(zc, _b(_lin_w(self.post_quant_conv)), _b(self.post_quant_conv.bias))
+            outs.append(self.decoder(zc).permute(0, 3, 1, 2))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 def decode_first_stage(first_stage_model: AutoencoderKL, z: torch.Tensor, scale_factor: float = 0.18215, perframe_ae: bool = True) -> torch.Tensor:

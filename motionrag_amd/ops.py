@@ -391,8 +391,10 @@ def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor
     _dev(x, name="x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise ValueError("softmax_rows: [rows, cols] with contiguous columns required")
-    if out is None:
-        out = torch.empty_like(x)
+    if out is None:                                       # rows start on 16-byte boundaries: pad the row stride to a multiple of 8 elements
+        out = torch.empty(x.shape[0], (x.shape[1] + 7) // 8 * 8, dtype=torch.bfloat16, device=x.device)[:, :x.shape[1]]
+    if x.stride(0) % 8 or out.stride(0) % 8:
+        raise ValueError("softmax_rows: row strides must be multiples of 8 elements")
     check(_lib.lib().mrag_softmax_rows_bf16(_stream(), _p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(scale)), "mrag_softmax_rows_bf16")
     return out
 

@@ -241,6 +241,22 @@ def encoders(clips=10, frames=49, H=480, W=720):
             "clips": clips, "source": f"{frames}x{H}x{W} bf16"}
 
 
+def vae(frames=16, h=72, w=128):
+    """DynamiCrafter KL-VAE decode of one clip's final latents: z [1, 4, 16, 72, 128] -> video [1, 3, 16, 576, 1024], the shipped decoder
+    (configs/dynamicrafter/MotionRAG_open.yml:245-259), random-init weights, all frames in one batch"""
+    from motionrag_amd import dynamicrafter_vae as V
+    torch.manual_seed(0)
+    m = V.AutoencoderKL(dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[],
+                             dropout=0.0), embed_dim=4).to(DEV, torch.bfloat16)
+    z = (torch.randn(1, 4, frames, h, w, device=DEV) * 0.18215).to(torch.bfloat16)
+    out = {}
+    fl = count_flops(lambda: out.setdefault("y", V.decode_first_stage(m, z)))
+    assert out["y"].shape == (1, 3, frames, 8 * h, 8 * w) and torch.isfinite(out["y"].float()).all()
+    dt = timeit(lambda: V.decode_first_stage(m, z), iters=3, warm=1)
+    print(f"KL-VAE decode {frames}x{8*h}x{8*w}: {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP (GEMM / conv launches)  -> {frames/dt:.0f} frames/s")
+    return {"ms_per_clip": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(frames / dt)}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

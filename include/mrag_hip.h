@@ -365,6 +365,9 @@ typedef struct mrag_conv_args {
   int32_t N, H, Wd, Cin, Cout;
   int32_t stride, upsample;        /* MRAG_CONV_3X3 only */
   int32_t mode, epilogue;
+  int32_t asym_pad;                /* MRAG_CONV_3X3, stride 2: 0 = padding 1 on every side; 1 = zero row / column at the bottom / right only --
+                                      `F.pad(x, (0, 1, 0, 1))` + Conv2d(3, stride 2, padding 0), the KL-VAE encoder's Downsample
+                                      (lvdm/modules/networks/ae_modules.py:93-113): Ho = H / 2                                       */
 } mrag_conv_args;
 int mrag_conv_bf16(void* stream, const mrag_conv_args* args);
 /* row gather for nn.Conv3d((3,1,1), padding (1,0,0)), openaimodel3d.py:256-268:

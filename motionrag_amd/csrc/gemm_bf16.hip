@@ -55,7 +55,7 @@ struct GemmP {
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
   long long qk_D; int rope_text_len, qk_first; float qk_eps, q_premul;
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
-  int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T;
+  int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
 };
 
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         const int yo = (int)(r2 % p.cv_Ho);
         const long long n = r2 / p.cv_Ho;
         gsrc[i] = p.A + n * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
-        cv_y[i] = yo * p.cv_stride - 1;
-        cv_x[i] = xo * p.cv_stride - 1;
+        cv_y[i] = yo * p.cv_stride - p.cv_pad;
+        cv_x[i] = xo * p.cv_stride - p.cv_pad;
       } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row pointer and t
         gsrc[i] = p.A + row * p.cv_C + chunk * 8;
         cv_y[i] = (int)((row / p.cv_HW) % p.cv_T);
@@ -800,7 +800,10 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
     if ((a->stride != 1 && a->stride != 2) || (a->upsample != 0 && a->upsample != 1)) return MRAG_EINVAL;
     p.cv_H = a->H; p.cv_W = a->Wd; p.cv_up = a->upsample; p.cv_stride = a->stride;
     p.cv_Hi = a->upsample ? 2 * a->H : a->H; p.cv_Wi = a->upsample ? 2 * a->Wd : a->Wd;
-    p.cv_Ho = (p.cv_Hi - 1) / a->stride + 1; p.cv_Wo = (p.cv_Wi - 1) / a->stride + 1;
+    if (a->asym_pad != 0 && (a->asym_pad != 1 || a->stride != 2 || a->upsample)) return MRAG_EINVAL;
+    p.cv_pad = a->asym_pad ? 0 : 1;
+    // padding 1 / 1: Ho = (Hi + 2 - 3) / stride + 1; padding 0 / 1: Ho = (Hi + 1 - 3) / stride + 1
+    p.cv_Ho = (p.cv_Hi + p.cv_pad - 2) / a->stride + 1; p.cv_Wo = (p.cv_Wi + p.cv_pad - 2) / a->stride + 1;
     p.M = (long long)a->N * p.cv_Ho * p.cv_Wo; p.K = 9LL * a->Cin; p.ldw = p.K;
     const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);

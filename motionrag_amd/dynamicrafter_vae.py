@@ -4,12 +4,13 @@ Mirrors, with the reference's parameter names (so `first_stage_model.*` checkpoi
   * `Decoder` / `ResnetBlock` / `AttnBlock` / `Upsample`  src/projects/dynamicrafter/DynamiCrafter/lvdm/modules/networks/ae_modules.py:27-79,116-132,156-215,472-584
   * `AutoencoderKL.decode`                                lvdm/models/autoencoder.py:104-107  (`post_quant_conv` then the decoder)
   * `LatentDiffusion.decode_core` / `decode_first_stage`  lvdm/models/ddpm3d.py:668-690      (`1 / scale_factor * z`, frames folded into the batch)
-Encoding (the conditioning image's latent) is not built: its stride-2 convolutions pad asymmetrically ((0, 1, 0, 1)), a gather the implicit-GEMM
-convolution does not have yet -- `encode` raises.
+  * `Encoder` / `Downsample`, `AutoencoderKL.encode`, `DiagonalGaussianDistribution`, `get_first_stage_encoding` / `encode_first_stage`
+        ae_modules.py:93-113,370-470; autoencoder.py:97-102; lvdm/distributions.py:24-43; ddpm3d.py:633-666   (the conditioning image's latent)
 
 Data path (channels-last rows, all frames of a clip in one batch -- 16 x 576 x 1024 x 128 bf16 is 2.4 GB of the 288 GB):
   GroupNorm(32, eps 1e-6) + swish      -> `mrag_groupnorm_bf16` (statistics + fused SiLU)
-  3x3 convolutions (+ nearest x2)      -> `mrag_conv_bf16` implicit GEMM, the ResnetBlock's `x + h` in the epilogue; conv_in (4 channels) through the row gather
+  3x3 convolutions (+ nearest x2)      -> `mrag_conv_bf16` implicit GEMM, the ResnetBlock's `x + h` in the epilogue; conv_in (3 / 4 channels) through the row gather
+  Downsample (pad (0,1,0,1), stride 2) -> the same implicit GEMM with `asym_pad` (taps start at the pixel itself, zero row / column at the bottom / right)
   1x1 convolutions / nin_shortcut      -> `mrag_gemm_bf16`
   AttnBlock (1 head, head_dim 512)     -> q / k projections, S = q k^T as a GEMM per frame, `mrag_softmax_rows_bf16`, V^T produced directly by a GEMM with swapped
                                           operands (no transpose pass), O = P V^T^T as a GEMM (+ the value bias: rows of P sum to 1), proj_out with the residual.
@@ -158,24 +159,9 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
         self.peak_channels = ch * ch_mult[min(1, len(ch_mult) - 1)]            # channels of the finest level's upsampled input: the largest activation
 
-    def _conv_in(self, z: torch.Tensor) -> torch.Tensor:
-        """3x3 convolution from z_channels = 4: the row gather moves 16-byte (8-channel) granules, so the latent and the kernel get 4 zero channels"""
-        N, H, W, cz = z.shape
-        conv = self.conv_in
-        cp = (cz + 7) // 8 * 8
-        if cp != cz:
-            z = torch.nn.functional.pad(z, (0, cp - cz))
-        kp = ops._kpad(9 * cp)
-
-        def build():
-            w = torch.nn.functional.pad(_b(conv.weight), (0, 0, 0, 0, 0, cp - cz)).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * cp)
-            return torch.nn.functional.pad(w, (0, kp - 9 * cp)).contiguous()
-        wk = _CACHE.get(("vae_in", id(conv), cp), conv.weight, build)
-        return ops.linear(ops.im2col3x3(z.contiguous()), wk, _b(conv.bias)).view(N, H, W, -1)
-
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """z [N, H, W, z_channels] channels-last -> [N, H * 2^(levels-1), W * 2^(levels-1), out_ch]"""
-        h = self._conv_in(z)
+        h = _conv_small_cin(z, self.conv_in, "vae_dec_in")
         h = self.mid.block_1(h)
         h = self.mid.attn_1(h)
         h = self.mid.block_2(h)
@@ -206,18 +192,140 @@ class Decoder(nn.Module):
         return y[..., :self.out_ch]
 
 
+class Downsample(nn.Module):
+    """ae_modules.py:93-113: F.pad(x, (0, 1, 0, 1)) + Conv2d(3, stride 2, padding 0) -- one implicit-GEMM launch"""
+
+    def __init__(self, in_channels: int, with_conv: bool):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("resamp_with_conv = False is not on the reference's path")
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        conv = self.conv
+        C = x.shape[-1]
+        if C % 64:
+            raise NotImplementedError("Downsample: channel counts are multiples of 64 on the reference's path")
+        wk = _CACHE.get(("c3", id(conv)), conv.weight, lambda: _b(conv.weight).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * C).contiguous())
+        return ops.conv_implicit(x.contiguous(), wk, _b(conv.bias), ops.CONV_3X3, stride=2, asym_pad=True)
+
+
+def _conv_small_cin(z: torch.Tensor, conv: nn.Conv2d, tag: str) -> torch.Tensor:
+    """3x3 convolution from 3 (RGB) or 4 (latent) channels: the row gather moves 16-byte (8-channel) granules, so the input and the kernel get zero channels"""
+    N, H, W, cz = z.shape
+    cp = (cz + 7) // 8 * 8
+    if cp != cz:
+        z = torch.nn.functional.pad(z, (0, cp - cz))
+    kp = ops._kpad(9 * cp)
+
+    def build():
+        w = torch.nn.functional.pad(_b(conv.weight), (0, 0, 0, 0, 0, cp - cz)).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * cp)
+        return torch.nn.functional.pad(w, (0, kp - 9 * cp)).contiguous()
+    wk = _CACHE.get((tag, id(conv), cp), conv.weight, build)
+    return ops.linear(ops.im2col3x3(z.contiguous()), wk, _b(conv.bias)).view(N, H, W, -1)
+
+
+class Encoder(nn.Module):
+    """ae_modules.py:370-470"""
+
+    def __init__(self, *, ch: int, out_ch: int = 3, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int, attn_resolutions: Sequence[int] = (), dropout: float = 0.0,
+                 resamp_with_conv: bool = True, in_channels: int = 3, resolution: int = 256, z_channels: int = 4, double_z: bool = True, use_linear_attn: bool = False,
+                 attn_type: str = "vanilla", **ignore_kwargs):
+        super().__init__()
+        if use_linear_attn or attn_type != "vanilla":
+            raise NotImplementedError("only the vanilla AttnBlock is on the reference's path")
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = _Level()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(down)
+        self.mid = _Level()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [N, H, W, 3] channels-last -> moments [N, H / 2^(levels-1), W / 2^(levels-1), 2 z_channels]"""
+        h = _conv_small_cin(x, self.conv_in, "vae_enc_in")
+        for i_level in range(self.num_resolutions):
+            lv = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = lv.block[i_block](h)
+                if len(lv.attn) > 0:
+                    h = lv.attn[i_block](h)
+            if i_level != self.num_resolutions - 1:
+                h = lv.downsample(h)
+        h = self.mid.block_1(h)
+        h = self.mid.attn_1(h)
+        h = self.mid.block_2(h)
+        h = _gn_swish(h, self.norm_out)
+        return conv3x3(h, self.conv_out)
+
+
+class DiagonalGaussianDistribution:
+    """lvdm/distributions.py:24-43 (the fields the inference path reads): `parameters` [N, 2 z, h, w] -> mean, logvar clamped to [-30, 20], std; `sample(noise)` /
+    `mode()`.  A few KB per frame: computed in fp32 with torch on the device."""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters.float(), 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if noise is None:
+            noise = torch.randn(self.mean.shape)                 # the reference draws on the CPU too (distributions.py:37-38)
+        return self.mean + self.std * noise.to(device=self.parameters.device, dtype=torch.float32)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
-    """lvdm/models/autoencoder.py:13-107, decode side.  Constructor keywords as the reference's YAML (`ddconfig`, `embed_dim`; the rest is accepted and ignored);
-    state-dict keys `decoder.*`, `post_quant_conv.*` (an `encoder.*` / `quant_conv.*` / `loss.*` checkpoint loads with strict=False)."""
+    """lvdm/models/autoencoder.py:13-107.  Constructor keywords as the reference's YAML (`ddconfig`, `embed_dim`; the rest is accepted and ignored);
+    state-dict keys `encoder.*`, `decoder.*`, `quant_conv.*`, `post_quant_conv.*` as the reference's (`loss.*` of a training checkpoint: strict=False)."""
 
     def __init__(self, ddconfig: dict, embed_dim: int, lossconfig=None, **_ignored):
         super().__init__()
+        assert ddconfig["double_z"]
+        self.encoder = Encoder(**ddconfig)
         self.decoder = Decoder(**ddconfig)
+        self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
 
-    def encode(self, x, **kwargs):
-        raise NotImplementedError("KL-VAE encode is not built (asymmetric-padding stride-2 convolutions); decode is")
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, **kwargs) -> DiagonalGaussianDistribution:
+        """x [N, 3, H, W] in [-1, 1] -> posterior over z [N, embed_dim, H / 8, W / 8]  (autoencoder.py:97-102)"""
+        if not x.is_cuda:
+            raise ops.HipOnly("AutoencoderKL.encode: GPU tensors only")
+        xc = x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+        h = self.encoder(xc)
+        moments = ops.linear(h, _b(_lin_w(self.quant_conv)), _b(self.quant_conv.bias))
+        return DiagonalGaussianDistribution(moments.permute(0, 3, 1, 2))
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
@@ -238,6 +346,19 @@ class AutoencoderKL(nn.Module):
             zc = ops.linear(zc, _b(_lin_w(self.post_quant_conv)), _b(self.post_quant_conv.bias))
             outs.append(self.decoder(zc).permute(0, 3, 1, 2))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+def encode_first_stage(first_stage_model: AutoencoderKL, x: torch.Tensor, scale_factor: float = 0.18215, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LatentDiffusion.encode_first_stage + get_first_stage_encoding (ddpm3d.py:633-666): x [b, 3, t, H, W] or [n, 3, H, W] in [-1, 1] ->
+    scale_factor * posterior.sample(noise) (fp32).  `noise` = None draws like the reference (CPU generator); pass zeros for the posterior mean."""
+    reshape_back = x.dim() == 5
+    if reshape_back:
+        b, c, t, h, w = x.shape
+        x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    z = scale_factor * first_stage_model.encode(x).sample(noise=noise)
+    if reshape_back:
+        z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+    return z
 
 
 def decode_first_stage(first_stage_model: AutoencoderKL, z: torch.Tensor, scale_factor: float = 0.18215, perframe_ae: bool = True) -> torch.Tensor:

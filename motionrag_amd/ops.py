@@ -547,7 +547,7 @@ CONV_3X3, CONV_T3 = 1, 2
 
 
 def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor], mode: int, *, stride: int = 1, upsample: bool = False,
-                  frames: int = 0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  frames: int = 0, resid: Optional[torch.Tensor] = None, asym_pad: bool = False) -> torch.Tensor:
     """implicit-GEMM convolution (no materialised im2col), Cin % 64 == 0.
     CONV_3X3: x [N, H, W, Cin] -> [N, Ho, Wo, Cout], wk [Cout, 9 Cin] in (ky, kx, cin) order.
     CONV_T3:  x [(b t), HW, Cin] with `frames` = t -> same rows x Cout, wk [Cout, 3 Cin] in (kt, cin) order."""
@@ -560,8 +560,9 @@ def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor
     if mode == CONV_3X3:
         N, H, W, C = x.shape
         Hi, Wi = (2 * H, 2 * W) if upsample else (H, W)
-        out = torch.empty(N, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1, cout, dtype=torch.bfloat16, device=x.device)
-        a.N, a.H, a.Wd, a.stride, a.upsample = N, H, W, stride, 1 if upsample else 0
+        front = 0 if asym_pad else 1                         # asym_pad: F.pad(x, (0, 1, 0, 1)) + stride-2 convolution without padding (KL-VAE Downsample)
+        out = torch.empty(N, (Hi + front - 2) // stride + 1, (Wi + front - 2) // stride + 1, cout, dtype=torch.bfloat16, device=x.device)
+        a.N, a.H, a.Wd, a.stride, a.upsample, a.asym_pad = N, H, W, stride, 1 if upsample else 0, 1 if asym_pad else 0
         taps = 9
     else:
         NT, HW, C = x.shape

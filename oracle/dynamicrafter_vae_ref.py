@@ -68,3 +68,32 @@ def decode_core(z, sd, num_resolutions, num_res_blocks, scale_factor=0.18215):
     z = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     out = autoencoder_decode(1.0 / scale_factor * z, sd, num_resolutions, num_res_blocks)
     return out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def encoder(x, sd, num_resolutions, num_res_blocks, p="encoder"):
+    """Encoder.forward, ae_modules.py:436-470 (Downsample: F.pad (0, 1, 0, 1) + stride-2 convolution without padding, :106-110)"""
+    h = _conv(x, sd, p + ".conv_in", 1)
+    for i_level in range(num_resolutions):
+        for i_block in range(num_res_blocks):
+            h = resnet_block(h, sd, f"{p}.down.{i_level}.block.{i_block}")
+            if f"{p}.down.{i_level}.attn.{i_block}.norm.weight" in sd:
+                h = attn_block(h, sd, f"{p}.down.{i_level}.attn.{i_block}")
+        if i_level != num_resolutions - 1:
+            q = f"{p}.down.{i_level}.downsample.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[q + ".weight"], sd[q + ".bias"], stride=2)
+    h = resnet_block(h, sd, p + ".mid.block_1")
+    h = attn_block(h, sd, p + ".mid.attn_1")
+    h = resnet_block(h, sd, p + ".mid.block_2")
+    return _conv(_swish(_gn(h, sd, p + ".norm_out")), sd, p + ".conv_out", 1)
+
+
+def autoencoder_encode_moments(x, sd, num_resolutions, num_res_blocks):
+    """AutoencoderKL.encode up to the posterior's parameters (autoencoder.py:97-100)"""
+    return _conv(encoder(x, sd, num_resolutions, num_res_blocks), sd, "quant_conv", 0)
+
+
+def first_stage_encoding(moments, noise, scale_factor=0.18215):
+    """DiagonalGaussianDistribution(moments).sample(noise) * scale_factor (distributions.py:24-40, ddpm3d.py:633-640)"""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return scale_factor * (mean + std * noise)

@@ -50,6 +50,29 @@ def test_vae_decode_equals_reference_autoencoder(hip, golden_dir):
     assert rel(ya, torch.from_numpy(G["y_attn"])) <= 1e-2                        # vs the REFERENCE's AttnBlock.forward
     y5 = V.decode_first_stage(m, torch.from_numpy(G["z5"]).to(DEV), scale_factor=0.18215)
     assert y5.shape == G["y5"].shape and rel(y5, torch.from_numpy(G["y5"])) <= 2e-2
+    # encode: posterior parameters and a sample with the fixture's noise, vs the REFERENCE's AutoencoderKL.encode / DiagonalGaussianDistribution.sample
+    post = m.encode(torch.from_numpy(G["x_img"]).to(DEV))
+    assert post.parameters.shape == G["moments"].shape
+    assert rel(post.parameters, torch.from_numpy(G["moments"])) <= 2e-2
+    z = V.encode_first_stage(m, torch.from_numpy(G["x_img"]).to(DEV), noise=torch.from_numpy(G["noise"]))
+    assert rel(z, torch.from_numpy(G["z_enc"])) <= 2e-2
+    assert torch.equal(V.encode_first_stage(m, torch.from_numpy(G["x_img"]).to(DEV), noise=torch.zeros_like(post.mean)), 0.18215 * post.mode())
+
+
+@pytest.mark.parametrize("H,W,C,Cout", [(10, 14, 64, 64), (9, 7, 128, 192), (32, 48, 64, 64)])
+def test_asymmetric_pad_stride2_conv(hip, H, W, C, Cout):
+    """Downsample (ae_modules.py:106-110): F.pad(x, (0, 1, 0, 1)) + Conv2d(3, stride 2, padding 0) as one implicit-GEMM launch; odd sizes included"""
+    import torch.nn.functional as F
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(2, C, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(torch.bfloat16)
+    want = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous()
+    got = ops.conv_implicit(x.permute(0, 2, 3, 1).contiguous().to(DEV), wk.to(DEV), b.to(DEV), ops.CONV_3X3, stride=2, asym_pad=True)
+    assert got.shape == (2, want.shape[2], want.shape[3], Cout)
+    assert rel(got.permute(0, 3, 1, 2), want) <= 1e-2
 
 
 def test_vae_decode_shipped_config_vs_oracle(hip):

@@ -372,3 +372,28 @@ def decode_first_stage(first_stage_model: AutoencoderKL, z: torch.Tensor, scale_
     if reshape_back:
         out = out.reshape(b, t, *out.shape[1:]).permute(0, 2, 1, 3, 4)
     return out
+
+
+class FirstStage:
+    """The first-stage methods `image_guided_synthesis` (dynamicrafter_pipeline.py) reads from the LatentVisualDiffusion-shaped model object, ddpm3d.py:633-690:
+    mix into / attach to that object (`model.encode_first_stage = fs.encode_first_stage`, ...) or subclass."""
+
+    def __init__(self, first_stage_model: AutoencoderKL, scale_factor: float = 0.18215, perframe_ae: bool = True):
+        self.first_stage_model, self.scale_factor, self.perframe_ae = first_stage_model, scale_factor, perframe_ae
+
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample(noise=noise)
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    @torch.no_grad()
+    def encode_first_stage(self, x: torch.Tensor) -> torch.Tensor:
+        return encode_first_stage(self.first_stage_model, x, self.scale_factor)
+
+    @torch.no_grad()
+    def decode_first_stage(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
+        return decode_first_stage(self.first_stage_model, z, self.scale_factor, self.perframe_ae)

@@ -53,3 +53,50 @@ def test_svd_full_size_cfg_step(hip):
     assert torch.isfinite(v1.float()).all() and torch.isfinite(l1.float()).all() and v1.float().abs().mean().item() > 1e-3
     assert torch.equal(v1, v2) and torch.equal(l1, lat), "two runs of the same step differ"
     assert abs(fl / 1e12 - W.SVD_STEP_TFLOP) / W.SVD_STEP_TFLOP < 0.015, f"step makes {fl / 1e12:.2f} TFLOP of launches, expected {W.SVD_STEP_TFLOP}"
+
+
+def test_cogvideox_5b_full_size_cfg_step(hip):
+    """The HEADLINE workload at its full size (BASELINE configs[1]: CogVideoX-5B-I2V, 42 layers x 3072, 49 x 480 x 720 -> S = 226 + 17 550 tokens, CFG batch 2)
+    with `bench.py`'s own model builder.  The fp32 oracle needs ~2 h per step on the host cores (bench.py: cpu_baseline), so the checks are the size-independent
+    ones: shape, finiteness, bit-determinism across two runs, the guidance branches' independence (the unconditional half must not move by a single bit when only the
+    conditional half's motion tokens change), sensitivity of the conditional half to its motion tokens, and linearity of the CFG + DDIM update in the guidance scale."""
+    import importlib.util
+    import os
+    from motionrag_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mrag_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dit, cam, pipe = bench.build_models(DEV, 42, 13)
+    assert sum(p.numel() for p in dit.parameters()) > 5.5e9                      # 5.57 B with the 42 motion adapters
+    g = torch.Generator().manual_seed(77)
+    latents = torch.randn(1, 13, 16, 60, 90, generator=g).to(DEV, torch.bfloat16)
+    image_latents = torch.randn(1, 13, 16, 60, 90, generator=g).to(DEV, torch.bfloat16)
+    prompt = torch.randn(2, 226, 4096, generator=g).to(DEV, torch.bfloat16)
+    action = torch.randn(2, 25, 1024, generator=g).to(DEV, torch.bfloat16)
+    pipe.action_emb = action                                                      # the smuggling hand-off of pipeline.py:46-57: ((cos, sin), action_emb)
+    rope = pipe._prepare_rotary_positional_embeddings(13, 30, 45, DEV)[0]
+    ts = torch.full((2,), 500.0, dtype=torch.float32, device=DEV)
+
+    def run(act):
+        return dit(latents, prompt, ts, image_rotary_emb=(rope, act), image_latents=image_latents, batch=2)
+    v1 = run(action)
+    v2 = run(action)
+    assert v1.shape[0] == 2 and v1.numel() == 2 * 13 * 16 * 60 * 90 and v1.dtype == torch.bfloat16
+    assert torch.isfinite(v1.float()).all() and v1.float().abs().mean().item() > 1e-3
+    assert torch.equal(v1, v2), "two runs of the same step differ"
+    act2 = action.clone()
+    act2[1] = act2[1] * 0.5                                                      # only the conditional branch's motion tokens change
+    v3 = run(act2)
+    assert torch.equal(v3[0], v1[0]), "the unconditional branch moved: the CFG samples are not independent"
+    assert (v3[1].float() - v1[1].float()).abs().max().item() > 0, "the motion tokens do not reach the output"
+    # CFG + DDIM update (v-prediction): x_prev is affine in the guidance scale -> second difference zero up to bf16 rounding of the stored latents
+    sched = pipe.scheduler
+    sched.set_timesteps(50)
+    outs = []
+    for gs in (1.0, 3.5, 6.0):
+        x = latents.clone()
+        ops.cfg_ddim_step_(v1, x, gs, *sched.coeffs(500))
+        outs.append(x.float())
+    second = outs[0] - 2 * outs[1] + outs[2]
+    assert second.abs().max().item() <= 4 * 2.0 ** -8 * max(o.abs().max().item() for o in outs)

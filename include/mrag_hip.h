@@ -260,6 +260,48 @@ int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, in
  * x [B, K, n] bf16, w [B, K] fp32 on the device or NULL (all ones: mean = sum / K with div = K), n % 8 == 0.            */
 int mrag_weighted_sum_bf16(void* stream, const void* x, const float* w, void* out, int32_t B, int32_t K, int64_t n, float div);
 /* ------------------------------------------------------------------------ */
+/* CAMA building blocks as native launch sequences (`resampler_fwd`, `cama_encoder_fwd`).  No kernel of their own: they issue the launches
+ * of the entry points above in the order motionrag_amd/cama.py does (bit-identical results), from C++, with caller-provided scratch.                */
+/* ------------------------------------------------------------------------ */
+/* Resampler.forward (src/projects/condition/resampler.py:151-174): x [N, n1, embedding_dim] -> out [N, nq, output_dim]; all weights bf16 in the
+ * nn.Linear layout [out, in]; PerceiverAttention / FeedForward linears have no bias, head_dim 64.                                                    */
+typedef struct mrag_resampler_layer {
+  const void* norm1_w; const void* norm1_b;      /* PerceiverAttention.norm1 (media tokens)      [dim]        */
+  const void* norm2_w; const void* norm2_b;      /* PerceiverAttention.norm2 (latents)           [dim]        */
+  const void* to_q; const void* to_kv; const void* to_out;   /* [H*64, dim], [2*H*64, dim] (K rows first), [dim, H*64] */
+  const void* ff_ln_w; const void* ff_ln_b;      /* FeedForward[0] LayerNorm                                   */
+  const void* ff_w1; const void* ff_w2;          /* FeedForward[1] [ff_dim, dim], FeedForward[3] [dim, ff_dim] */
+} mrag_resampler_layer;
+typedef struct mrag_resampler_args {
+  const void* x; void* out;
+  const void* latents;                           /* [nq, dim] (the learned queries)                            */
+  const void* proj_in_w; const void* proj_in_b; const void* proj_out_w; const void* proj_out_b; const void* norm_out_w; const void* norm_out_b;
+  const mrag_resampler_layer* layers;            /* host array [depth]                                         */
+  void* workspace; int64_t workspace_bytes;      /* >= mrag_resampler_workspace_bytes(...), 256-byte aligned   */
+  int32_t N, n1, nq, embedding_dim, dim, output_dim, heads, depth, ff_dim;
+  float eps;                                     /* every LayerNorm of the module (1e-5)                       */
+} mrag_resampler_args;
+int64_t mrag_resampler_workspace_bytes(int32_t N, int32_t n1, int32_t nq, int32_t dim, int32_t output_dim, int32_t heads, int32_t ff_dim);
+int mrag_resampler_fwd(void* stream, const mrag_resampler_args* args);
+/* torch.nn.TransformerEncoder of post-norm nn.TransformerEncoderLayer(d_model, nhead, ff_dim, activation gelu, batch_first) with a [L, L] byte mask
+ * (nonzero = blocked; CAMA's block-causal mask, src/projects/condition/module.py:131-135,303-305): x [B, L, d_model] -> out [B, L, d_model].        */
+typedef struct mrag_encoder_layer {
+  const void* in_proj_w; const void* in_proj_b;  /* [3 d, d], [3 d]  (nn.MultiheadAttention in_proj: q | k | v) */
+  const void* out_proj_w; const void* out_proj_b;
+  const void* lin1_w; const void* lin1_b; const void* lin2_w; const void* lin2_b;
+  const void* norm1_w; const void* norm1_b; const void* norm2_w; const void* norm2_b;
+} mrag_encoder_layer;
+typedef struct mrag_cama_encoder_args {
+  const void* x; void* out; const uint8_t* mask;
+  const mrag_encoder_layer* layers;              /* host array [num_layers]                                    */
+  void* workspace; int64_t workspace_bytes;
+  int32_t B, L, d_model, nhead, ff_dim, num_layers;
+  float eps;
+} mrag_cama_encoder_args;
+int64_t mrag_cama_encoder_workspace_bytes(int32_t B, int32_t L, int32_t d_model, int32_t ff_dim);
+int mrag_cama_encoder_fwd(void* stream, const mrag_cama_encoder_args* args);
+
+/* ------------------------------------------------------------------------ */
 /* Frozen feature encoders in front of CAMA: pixel side.   */
 /* ------------------------------------------------------------------------ */
 /* VideoMAEEmbedder.forward / preprocess (src/projects/condition/encoders/condition.py:378-400) and DINOImageEmbedder.forward /

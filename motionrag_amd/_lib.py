@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip"]
 ABI_VERSION = 3
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
@@ -31,11 +31,13 @@ SYMBOLS = [
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
     "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16",
+    "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
 ]
 
 
 # entry points whose result is not the int32 status code (their restype is set explicitly in lib())
-_NON_INT_RESULT = ("mrag_target_arch", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes")
+_NON_INT_RESULT = ("mrag_target_arch", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
+                   "mrag_resampler_workspace_bytes", "mrag_cama_encoder_workspace_bytes")
 
 
 class HipLibraryMissing(RuntimeError):
@@ -89,6 +91,27 @@ class ResizePatchArgs(Structure):
         ("taps_y", c_int32), ("taps_x", c_int32), ("pt", c_int32), ("ph", c_int32), ("pw", c_int32), ("src_fp32", c_int32),
         ("scale", c_float * 4), ("shift", c_float * 4),
     ]
+
+
+class ResamplerLayer(Structure):
+    _fields_ = [(n, c_void_p) for n in ("norm1_w", "norm1_b", "norm2_w", "norm2_b", "to_q", "to_kv", "to_out", "ff_ln_w", "ff_ln_b", "ff_w1", "ff_w2")]
+
+
+class ResamplerArgs(Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("latents", c_void_p), ("proj_in_w", c_void_p), ("proj_in_b", c_void_p), ("proj_out_w", c_void_p),
+                ("proj_out_b", c_void_p), ("norm_out_w", c_void_p), ("norm_out_b", c_void_p), ("layers", POINTER(ResamplerLayer)),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)] + [(n, c_int32) for n in ("N", "n1", "nq", "embedding_dim", "dim", "output_dim", "heads",
+                                                                                                    "depth", "ff_dim")] + [("eps", c_float)]
+
+
+class EncoderLayer(Structure):
+    _fields_ = [(n, c_void_p) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b",
+                                        "norm2_w", "norm2_b")]
+
+
+class CamaEncoderArgs(Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("mask", c_void_p), ("layers", POINTER(EncoderLayer)), ("workspace", c_void_p), ("workspace_bytes", c_int64)] + [
+        (n, c_int32) for n in ("B", "L", "d_model", "nhead", "ff_dim", "num_layers")] + [("eps", c_float)]
 
 
 class QkNormRopeArgs(Structure):
@@ -207,6 +230,12 @@ def lib() -> ctypes.CDLL:
     L.mrag_weighted_sum_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_float]
     L.mrag_ddim_v_step_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 7
     L.mrag_resize_patchify_bf16.argtypes = [c_void_p, POINTER(ResizePatchArgs)]
+    L.mrag_resampler_workspace_bytes.argtypes = [c_int32] * 7
+    L.mrag_resampler_workspace_bytes.restype = c_int64
+    L.mrag_resampler_fwd.argtypes = [c_void_p, POINTER(ResamplerArgs)]
+    L.mrag_cama_encoder_workspace_bytes.argtypes = [c_int32] * 4
+    L.mrag_cama_encoder_workspace_bytes.restype = c_int64
+    L.mrag_cama_encoder_fwd.argtypes = [c_void_p, POINTER(CamaEncoderArgs)]
     L.mrag_softmax_rows_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float]
     L.mrag_assemble_tokens_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]
     for name in SYMBOLS:          # everything that did not declare a 64-bit / pointer result above returns an int status

@@ -99,7 +99,57 @@ class Resampler(nn.Module):
         if ckpt_path is not None:
             self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
 
+    def _native_args(self):
+        """the weight-pointer table of `mrag_resampler_fwd`, rebuilt when any parameter is replaced or updated in place"""
+        from ._lib import ResamplerArgs, ResamplerLayer
+        ps = [p for p in self.parameters()]
+        tag = tuple((p.data_ptr(), p.dtype, p._version) for p in ps)
+        ent = getattr(self, "_native", None)
+        if ent is None or ent[0] != tag:
+            if any(p.dtype != torch.bfloat16 or not p.is_cuda or not p.is_contiguous() for p in ps):
+                raise ops.HipOnly("Resampler: parameters must be contiguous bf16 tensors on the GPU (module.to('cuda', torch.bfloat16))")
+            depth = len(self.layers)
+            arr = (ResamplerLayer * depth)()
+            for L, (attn, ff) in zip(arr, self.layers):
+                L.norm1_w, L.norm1_b, L.norm2_w, L.norm2_b = (ops._p(t) for t in (attn.norm1.weight, attn.norm1.bias, attn.norm2.weight, attn.norm2.bias))
+                L.to_q, L.to_kv, L.to_out = ops._p(attn.to_q.weight), ops._p(attn.to_kv.weight), ops._p(attn.to_out.weight)
+                L.ff_ln_w, L.ff_ln_b, L.ff_w1, L.ff_w2 = ops._p(ff[0].weight), ops._p(ff[0].bias), ops._p(ff[1].weight), ops._p(ff[3].weight)
+            a = ResamplerArgs()
+            a.latents = ops._p(self.latents)
+            a.proj_in_w, a.proj_in_b, a.proj_out_w, a.proj_out_b = (ops._p(t) for t in (self.proj_in.weight, self.proj_in.bias, self.proj_out.weight, self.proj_out.bias))
+            a.norm_out_w, a.norm_out_b = ops._p(self.norm_out.weight), ops._p(self.norm_out.bias)
+            a.layers = arr
+            a.nq, a.embedding_dim, a.dim, a.output_dim = self.latents.shape[1], self.embedding_dim, self.dim, self.output_dim
+            a.heads, a.depth, a.ff_dim, a.eps = self.layers[0][0].heads, depth, self.layers[0][1][1].out_features, self.norm_out.eps
+            ent = (tag, a, arr)
+            self._native = ent
+        return ent[1]
+
     def forward(self, x: torch.Tensor, return_cls_tokens: bool = False):
+        """one native call: `mrag_resampler_fwd` issues the ~60 launches below (`forward_sequenced`) from C++, bit-identically"""
+        x = _bf16(x).contiguous()
+        if not x.is_cuda:
+            raise ops.HipOnly("Resampler: GPU tensors only")
+        N, n1, _ = x.shape
+        a = self._native_args()
+        L = ops._lib.lib()
+        need = L.mrag_resampler_workspace_bytes(N, n1, a.nq, a.dim, a.output_dim, a.heads, a.ff_dim)
+        ws = ops._attn_workspace(x.device, need, "resampler")
+        out = torch.empty(N, a.nq, a.output_dim, dtype=torch.bfloat16, device=x.device)
+        a.x, a.out, a.workspace, a.workspace_bytes, a.N, a.n1 = ops._p(x), ops._p(out), ops._p(ws), ws.numel() * ws.element_size(), N, n1
+        ops.check(L.mrag_resampler_fwd(ops._stream(), ops.ctypes.byref(a)), "mrag_resampler_fwd")
+        return self._select(out, return_cls_tokens)
+
+    def _select(self, latents: torch.Tensor, return_cls_tokens: bool):
+        if return_cls_tokens:
+            assert self.with_cls_token is True, "with_cls_token must be True if return_cls_tokens is True"
+            return latents[:, 0], latents[:, 1:]
+        if self.with_cls_token:
+            return latents[:, 1:]
+        return latents
+
+    def forward_sequenced(self, x: torch.Tensor, return_cls_tokens: bool = False):
+        """the same launches issued one by one from Python (the form `mrag_resampler_fwd` restates in C++; kept as its parity check)"""
         x = _bf16(x)
         N, n1, _ = x.shape
         nq = self.latents.shape[1]
@@ -122,12 +172,7 @@ class Resampler(nn.Module):
             latents = ops.linear(h, ff[3].weight, epilogue=ops.EPI_RESID, resid=latents)            # ff(...) + latents :163
         latents = ops.linear(latents, self.proj_out.weight, self.proj_out.bias)
         latents = ops.layernorm(latents, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps)
-        if return_cls_tokens:
-            assert self.with_cls_token is True, "with_cls_token must be True if return_cls_tokens is True"
-            return latents[:, 0], latents[:, 1:]
-        if self.with_cls_token:
-            return latents[:, 1:]
-        return latents
+        return self._select(latents, return_cls_tokens)
 
 
 class _SelfAttnParams(nn.Module):
@@ -177,7 +222,50 @@ class TransformerEncoder(nn.Module):
             dim_feedforward = encoder_layer.linear1.out_features
         self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead, dim_feedforward) for _ in range(num_layers)])
 
+    def _native_args(self):
+        from ._lib import CamaEncoderArgs, EncoderLayer
+        ps = [p for p in self.parameters()]
+        tag = tuple((p.data_ptr(), p.dtype, p._version) for p in ps)
+        ent = getattr(self, "_native", None)
+        if ent is None or ent[0] != tag:
+            if any(p.dtype != torch.bfloat16 or not p.is_cuda or not p.is_contiguous() for p in ps):
+                raise ops.HipOnly("TransformerEncoder: parameters must be contiguous bf16 tensors on the GPU")
+            arr = (EncoderLayer * len(self.layers))()
+            for E, m in zip(arr, self.layers):
+                E.in_proj_w, E.in_proj_b, E.out_proj_w, E.out_proj_b = (ops._p(t) for t in (m.self_attn.in_proj_weight, m.self_attn.in_proj_bias,
+                                                                                             m.self_attn.out_proj.weight, m.self_attn.out_proj.bias))
+                E.lin1_w, E.lin1_b, E.lin2_w, E.lin2_b = (ops._p(t) for t in (m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias))
+                E.norm1_w, E.norm1_b, E.norm2_w, E.norm2_b = (ops._p(t) for t in (m.norm1.weight, m.norm1.bias, m.norm2.weight, m.norm2.bias))
+            a = CamaEncoderArgs()
+            a.layers = arr
+            m0 = self.layers[0]
+            a.d_model, a.nhead, a.ff_dim, a.num_layers, a.eps = m0.norm1.normalized_shape[0], m0.nhead, m0.linear1.out_features, len(self.layers), m0.norm1.eps
+            if any(m.norm1.eps != m0.norm1.eps or m.norm2.eps != m0.norm1.eps for m in self.layers):
+                raise NotImplementedError("one LayerNorm eps per encoder")
+            ent = (tag, a, arr)
+            self._native = ent
+        return ent[1]
+
     def forward(self, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """one native call (`mrag_cama_encoder_fwd`: the launches of `forward_sequenced`, issued from C++)"""
+        x = _bf16(x).contiguous()
+        if not x.is_cuda:
+            raise ops.HipOnly("TransformerEncoder: GPU tensors only")
+        B, Lq, d = x.shape
+        a = self._native_args()
+        if mask is not None:
+            if mask.dtype == torch.bool:
+                mask = mask.view(torch.uint8)
+            if mask.dtype != torch.uint8 or tuple(mask.shape) != (Lq, Lq) or not mask.is_contiguous() or not mask.is_cuda:
+                raise ValueError("mask must be a contiguous bool/uint8 [L, L] on the GPU")
+        L = ops._lib.lib()
+        ws = ops._attn_workspace(x.device, L.mrag_cama_encoder_workspace_bytes(B, Lq, a.d_model, a.ff_dim), "cama_encoder")
+        out = torch.empty_like(x)
+        a.x, a.out, a.mask, a.workspace, a.workspace_bytes, a.B, a.L = ops._p(x), ops._p(out), ops._p(mask), ops._p(ws), ws.numel() * ws.element_size(), B, Lq
+        ops.check(L.mrag_cama_encoder_fwd(ops._stream(), ops.ctypes.byref(a)), "mrag_cama_encoder_fwd")
+        return out
+
+    def forward_sequenced(self, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         for layer in self.layers:
             x = layer(x, mask)
         return x

@@ -394,3 +394,30 @@ def test_dit_full_width_layer_matches_oracle(hip):
     want = cogvideox_ref.dit_forward(_bf_round(sd), cfg, x, text.float(), t, (cos, sin), ip.float())
     assert got.shape == want.shape == (2, 2, 16, 60, 90)
     close(got, want)
+
+
+def test_native_cama_sequencers_equal_the_python_sequenced_forms(hip):
+    """mrag_resampler_fwd / mrag_cama_encoder_fwd (csrc/cama_seq.hip) issue the same launches as cama.Resampler.forward_sequenced / TransformerEncoder.forward_sequenced:
+    bit-identical outputs at the shipped CAMA sizes (VideoMAE features [11, 1568, 768] -> 25 tokens; 250-token block-causal encoder), and stale-pointer safety when a
+    parameter is replaced"""
+    from motionrag_amd import cama
+    torch.manual_seed(5)
+    rs = cama.Resampler(dim=1024, depth=4, dim_head=64, heads=12, num_queries=25, embedding_dim=768, output_dim=1024).to(DEV, torch.bfloat16)
+    x = torch.randn(11, 1568, 768, device=DEV).to(torch.bfloat16)
+    a, b = rs(x), rs.forward_sequenced(x)
+    assert a.shape == (11, 25, 1024) and torch.equal(a, b)
+    with torch.no_grad():
+        rs.proj_out.weight.mul_(0.5)                                       # in-place update: the cached pointer table must be refreshed (version tag)
+    a2 = rs(x)
+    assert torch.equal(a2, rs.forward_sequenced(x)) and not torch.equal(a2, a)
+    enc = cama.TransformerEncoder(num_layers=4, d_model=1024, nhead=16, dim_feedforward=4096).to(DEV, torch.bfloat16)
+    h = torch.randn(2, 250, 1024, device=DEV).to(torch.bfloat16)
+    n = 250
+    mask = (torch.arange(n)[None, :] >= ((torch.arange(n) // 25 + 1) * 25)[:, None]).to(DEV)
+    y, y2 = enc(h, mask), enc.forward_sequenced(h, mask)
+    assert y.shape == h.shape and torch.equal(y, y2)
+    # raw C-ABI misuse is refused, not executed: a workspace one byte short
+    from motionrag_amd import ops
+    args = enc._native_args()
+    args.workspace_bytes = ops._lib.lib().mrag_cama_encoder_workspace_bytes(2, 250, 1024, 4096) - 1
+    assert ops._lib.lib().mrag_cama_encoder_fwd(ops._stream(), ops.ctypes.byref(args)) == ops._lib.MRAG_EINVAL

@@ -93,6 +93,7 @@ typedef struct mrag_gemm_args {
   int32_t qk_first;   /* MRAG_EPI_QKNORM_ROPE: which third the first qk_dmodel columns are (0 = Q, 1 = K, 2 = V); N = (1..3 - qk_first) * qk_dmodel */
   int32_t tuning;     /* developer knobs (tools/microbench.py), 0 = shipped: MRAG_GEMM_TUNE_* bits, bits 4-7 tile choice
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
+  int32_t geglu_act;  /* MRAG_EPI_GEGLU: 0 = v * gelu_erf(g) (diffusers / lvdm GEGLU), 1 = v * gelu_tanh(g) (T5 v1.1 "gated-gelu": gelu_new) */
 } mrag_gemm_args;
 enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4 };
 
@@ -134,6 +135,11 @@ typedef struct mrag_attn_args {
                               result up to fp32 summation order)              */
   int32_t tuning;          /* developer knobs (tools/microbench.py), 0 = shipped:
                               MRAG_ATTN_TUNE_* bits                            */
+  const float* bias;       /* additive score bias, fp32 [H, Sq, Skv] (head stride bias_sh elements, shared by the batch), or NULL:
+                              softmax(scale * Q K^T + bias [masked]) V.  T5's relative position bias (transformers T5Attention:
+                              `scores += position_bias`, scale = 1) -- the prompt encoder of the CogVideoX path.
+                              Takes the per-score path of the 32x32x16 kernel, like a mask.                                        */
+  int64_t bias_sh;
 } mrag_attn_args;
 enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pair kernel          */
        MRAG_ATTN_TUNE_PIPE = 2,      /* intra-wave software-pipelined variant (measured slower)    */
@@ -203,6 +209,7 @@ typedef struct mrag_ln_args {
    * attention (torch.cat at resampler.py:95) without a copy.                  */
   int64_t y_rows_per_batch, y_batch_stride;
   float eps;
+  int32_t rms;        /* nonzero: RMSNorm -- y = x * rsqrt(mean(x^2) + eps) * gamma, no mean subtraction (transformers T5LayerNorm) */
 } mrag_ln_args;
 
 int mrag_layernorm_bf16(void* stream, const mrag_ln_args* args);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip"]
-ABI_VERSION = 3
+ABI_VERSION = 4
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
@@ -53,7 +53,7 @@ class GemmArgs(Structure):
         ("rows_per_batch", c_int64), ("split", c_int64), ("gate_stride", c_int64),
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
-        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32),
+        ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32), ("geglu_act", c_int32),
     ]
 
 
@@ -67,6 +67,7 @@ class AttnArgs(Structure):
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Skv", c_int32), ("kv_batch_div", c_int32),
         ("scale", c_float), ("out_scale", c_float), ("q_prescaled", c_int32),
         ("workspace", c_void_p), ("workspace_bytes", c_int64), ("tuning", c_int32),
+        ("bias", c_void_p), ("bias_sh", c_int64),
     ]
 
 
@@ -77,7 +78,7 @@ class LnArgs(Structure):
         ("rows", c_int64), ("D", c_int64), ("ldx", c_int64), ("ldy", c_int64),
         ("rows_per_batch", c_int64), ("split", c_int64), ("mod_stride", c_int64),
         ("y_rows_per_batch", c_int64), ("y_batch_stride", c_int64),
-        ("eps", c_float),
+        ("eps", c_float), ("rms", c_int32),
     ]
 
 

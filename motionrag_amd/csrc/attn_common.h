@@ -10,6 +10,7 @@ struct AttnP {
   float qscale, out_scale;
   // key-split tail (KVSPLIT instantiation): workgroups >= n_main own (b, h, chunk) of the ragged last query tile
   int n_main, kv_splits, chunk_keys, rem_rows, tile_rows;
+  const float* bias; long long bias_sh;   // additive score bias [H, Sq, Skv] fp32 (head stride bias_sh) or null: the 32x32x16 kernel's mask path only
   float* part_o;    // [B*H*kv_splits, rem_rows, 64] unnormalised partial outputs
   float2* part_ml;  // [B*H*kv_splits, rem_rows] (running max in log2 units, row sum)
 };

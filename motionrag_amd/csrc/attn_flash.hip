@@ -108,7 +108,7 @@ __device__ __forceinline__ float half_swap_max(float v) {
 }
 
 struct Lane {
-  int hh, k_row_off, k_swz, v_lane_off, v_half0, v_half1;
+  int hh, k_row_off, k_swz, v_lane_off, v_half0, v_half1, head;
   unsigned kb[4], vc0, vc1;   // loop-invariant LDS addresses of this lane's K fragment chunks / V^T reads in ring stage 0 (MRAG_ATTN_IMM_STAGE)
 };
 
@@ -429,15 +429,31 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
       if (key + 32 < lo || key + 32 >= skv) s1[i] = -INFINITY;
     }
   }
-  if constexpr (HAS_MASK) {
-    const uint8_t* mrow = p.mask + (long long)qrow_c * p.Skv;
+  if constexpr (HAS_MASK) {   // the instantiation for a byte mask and / or an additive score bias
+    if (p.mask) {
+      const uint8_t* mrow = p.mask + (long long)qrow_c * p.Skv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
-      if (key < p.Skv && mrow[key]) s0[i] = -INFINITY;
-      if (key + 32 < p.Skv && mrow[key + 32]) s1[i] = -INFINITY;
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
+        if (key < p.Skv && mrow[key]) s0[i] = -INFINITY;
+        if (key + 32 < p.Skv && mrow[key + 32]) s1[i] = -INFINITY;
+      }
+    }
+    if (p.bias) {   // softmax(scale q k^T + bias): the scores are in log2 units here (Q carries scale * log2 e), so the bias is too
+      const float* brow = p.bias + (long long)ln.head * p.bias_sh + (long long)qrow_c * p.Skv;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase_idx + (i & 3) + 8 * (i >> 2);
+        if (key < p.Skv) s0[i] = fmaf(brow[key], 1.4426950408889634f, s0[i]);
+        if (key + 32 < p.Skv) s1[i] = fmaf(brow[key + 32], 1.4426950408889634f, s1[i]);
+      }
     }
   }
+  // The v_max3 chains below are inline asm: hipcc pads the MFMA -> VALU read hazard only for instructions it can see, and on the paths without a
+  // DMA hook between the score MFMAs and this point nothing else separates them (a stale read only mis-places the running max -- harmless to the
+  // result, P is formed from the real scores by compiler-visible code -- but the fp8 kernel showed what a stale NaN pattern does).  19 wait
+  // states cover the 16-pass MFMA (< 1 % of a tile).
+  asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");
   // tile max: four independent v_max3 chains, then across the two half-waves
   float ma = max3_asm(s0[0], s0[1], s0[2]), mb = max3_asm(s1[0], s1[1], s1[2]);
   float mc = max3_asm(s0[3], s0[4], s0[5]), md = max3_asm(s1[3], s1[4], s1[5]);
@@ -647,6 +663,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   }
   const int b = bh / p.H, h = bh % p.H;
   const int bkv = b / p.kv_div;
+  ln.head = h;
 
   const int q0 = qt * (NW * 32) + wave * 32;
   const bool wave_active = q0 < p.Sq;
@@ -973,11 +990,11 @@ int launch_attn(hipStream_t s, AttnP p) {
   const dim3 grid(p.n_qtiles * p.B * p.H), block(NW * 64);
   const size_t lds = 2 * NS * TILE_BYTES;
   {
-    const void* kf = p.mask ? (const void*)attn_fwd_kernel<NW, true, PIPE, SHORTKV> : (const void*)attn_fwd_kernel<NW, false, PIPE, SHORTKV>;
+    const void* kf = (p.mask || p.bias) ? (const void*)attn_fwd_kernel<NW, true, PIPE, SHORTKV> : (const void*)attn_fwd_kernel<NW, false, PIPE, SHORTKV>;
     const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (p.mask) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE, SHORTKV>), grid, block, lds, s, p);
+  if (p.mask || p.bias) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE, SHORTKV>), grid, block, lds, s, p);
   else MRAG_LAUNCH((attn_fwd_kernel<NW, false, PIPE, SHORTKV>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
@@ -1272,6 +1289,9 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   AttnP p{};
   p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.V = (const bf16_t*)a->V;
   p.O = (bf16_t*)a->O; p.resid = (const bf16_t*)a->resid; p.mask = a->mask;
+  p.bias = a->bias; p.bias_sh = a->bias_sh;
+  if (a->bias && (((uintptr_t)a->bias & 3) || a->bias_sh < 0)) return MRAG_EINVAL;
+  const bool masked = a->mask || a->bias;   // either one takes the 32x32x16 kernel's per-score path
   p.q_sb = a->q_sb; p.q_ss = a->q_ss; p.q_sh = a->q_sh;
   p.k_sb = a->k_sb; p.k_ss = a->k_ss; p.k_sh = a->k_sh;
   p.v_sb = a->v_sb; p.v_ss = a->v_ss; p.v_sh = a->v_sh;
@@ -1282,7 +1302,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   hipStream_t s = (hipStream_t)stream;
   // The intra-wave software-pipelined variant (PIPE) measures SLOWER than the staggered-barrier loop on MI355X with
   // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
-  if (a->Sq <= 16 && a->Skv <= 16 && !a->mask && !a->resid && !(a->tuning & MRAG_ATTN_TUNE_NO_TINY)) {   // temporal attention of the UNets
+  if (a->Sq <= 16 && a->Skv <= 16 && !masked && !a->resid && !(a->tuning & MRAG_ATTN_TUNE_NO_TINY)) {   // temporal attention of the UNets
     const long long pairs = (long long)a->B * a->H;
     long long blocks = (pairs + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -1295,9 +1315,9 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   const int nw_big = (a->tuning & MRAG_ATTN_TUNE_NW4) ? 4 : 8;
   if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
   const bool legacy = (a->tuning & MRAG_ATTN_TUNE_LEGACY) != 0;
-  const bool may_split = a->Sq > 128 && !pipe && !a->mask && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
+  const bool may_split = a->Sq > 128 && !pipe && !masked && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
   if (may_split && ((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
-  if (a->Sq > 128 && !pipe && !a->mask && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
+  if (a->Sq > 128 && !pipe && !masked && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
     SplitPlan pl;
     bool split = false;
     if (may_split) {

@@ -54,6 +54,7 @@ struct GemmP {
   // MRAG_EPI_QKNORM_ROPE
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
   long long qk_D; int rope_text_len, qk_first; float qk_eps, q_premul;
+  int geglu_tanh;   // MRAG_EPI_GEGLU: gate activation gelu_tanh instead of gelu_erf (wave-uniform)
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
@@ -594,8 +595,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
               g[0] += __uint_as_float(bg[0] << 16); g[1] += __uint_as_float(bg[0] & 0xffff0000u);
               g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
             }
+            if (__builtin_expect(p.geglu_tanh, 0)) {   // wave-uniform: a scalar branch, not a select over both activations
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+              for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_tanh_f(bf_round(g[e]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+            }
             u32x2 out;
             out[0] = pack_bf2(v[0], v[1]);
             out[1] = pack_bf2(v[2], v[3]);
@@ -633,8 +639,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
           g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
         }
         // the reference rounds both halves of proj(x) to bf16 before the product (nn.Linear output dtype)
+        if (__builtin_expect(p.geglu_tanh, 0)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+          for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_tanh_f(bf_round(g[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
+        }
         u32x2 out;
         out[0] = pack_bf2(v[0], v[1]);
         out[1] = pack_bf2(v[2], v[3]);
@@ -761,6 +772,8 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.gate0 = (const bf16_t*)a->gate0; p.gate1 = (const bf16_t*)a->gate1;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
+  p.geglu_tanh = a->geglu_act == 1;
+  if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
     if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
         a->rows_per_batch <= 0) return MRAG_EINVAL;

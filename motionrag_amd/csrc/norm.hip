@@ -31,6 +31,7 @@ struct LnP {
   const bf16_t* shift0; const bf16_t* scale0; const bf16_t* shift1; const bf16_t* scale1;
   long long rows, D, ldx, ldy, rows_per_batch, split, mod_stride, y_rpb, y_bstride;
   float eps;
+  int rms;   // RMSNorm (T5LayerNorm): no mean subtraction, variance = mean(x^2)
 };
 
 // y = LN(x) * gamma + beta ; y = y * (1 + scale[b]) + shift[b]
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
     }
   }
-  const float mean = wave_sum(sum) / (float)p.D;
+  const float mean = p.rms ? 0.f : wave_sum(sum) / (float)p.D;
   float sq = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -185,7 +186,7 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   p.shift0 = (const bf16_t*)a->shift0; p.scale0 = (const bf16_t*)a->scale0;
   p.shift1 = (const bf16_t*)a->shift1; p.scale1 = (const bf16_t*)a->scale1;
   p.rows = a->rows; p.D = a->D; p.ldx = a->ldx; p.ldy = a->ldy;
-  p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.mod_stride = a->mod_stride; p.eps = a->eps;
+  p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.mod_stride = a->mod_stride; p.eps = a->eps; p.rms = a->rms;
   p.y_rpb = a->y_rows_per_batch; p.y_bstride = a->y_batch_stride;
   if (p.y_rpb < 0 || (p.y_rpb > 0 && p.y_bstride % 8 != 0)) return MRAG_EINVAL;
   const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);

@@ -54,8 +54,8 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
            epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate0: Optional[torch.Tensor] = None,
-           gate1: Optional[torch.Tensor] = None, rows_per_batch: int = 0, split: int = 0, gate_stride: int = 0) -> torch.Tensor:
-    """out = epilogue(x @ weight.T + bias); x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout)."""
+           gate1: Optional[torch.Tensor] = None, rows_per_batch: int = 0, split: int = 0, gate_stride: int = 0, geglu_tanh: bool = False) -> torch.Tensor:
+    """out = epilogue(x @ weight.T + bias); x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout).  EPI_GEGLU: `geglu_tanh` picks gelu_tanh (T5's gated-gelu) over gelu_erf."""
     _dev(x, name="x"); _dev(weight, name="weight")
     x2 = _rows(x)
     M, K = x2.shape
@@ -76,6 +76,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     a.lda, a.ldw, a.ldc = x2.stride(0), weight.stride(0), o2.stride(0)
     a.epilogue = epilogue
     a.tuning = TUNING["gemm"]
+    a.geglu_act = 1 if geglu_tanh else 0
     if resid is not None:
         r2 = _rows(_dev(resid, name="resid"))
         a.resid, a.ldr = _p(r2), r2.stride(0)
@@ -133,7 +134,8 @@ def fp8_attention_supported(Sq: int, Skv: int, kv_batch_div: int = 1, mask=None,
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optional[torch.Tensor] = None,
               resid: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None, kv_batch_div: int = 1,
-              scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False, fp8: bool = False) -> torch.Tensor:
+              scale: Optional[float] = None, out_scale: float = 1.0, q_prescaled: bool = False, fp8: bool = False,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale [masked]) v for head_dim 64.  fp8=True: the e4m3 MFMA path (mrag_attn_fwd_fp8; raises on shapes it does not take).
 
     q [B, Sq, H, 64], k/v [Bkv, Skv, H, 64] (any strides with the last dim contiguous, e.g. views of a
@@ -171,6 +173,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
         if mask.dtype != torch.uint8 or tuple(mask.shape) != (Sq, Skv) or not mask.is_contiguous():
             raise ValueError("mask must be a contiguous bool/uint8 [Sq, Skv]")
         a.mask = _p(mask)
+    if bias is not None:                                    # softmax(scale q k^T + bias): fp32 [H, Sq, Skv], shared by the batch (T5's relative position bias)
+        _dev(bias, torch.float32, "bias")
+        if tuple(bias.shape) != (H, Sq, Skv) or not bias.is_contiguous():
+            raise ValueError("bias must be a contiguous fp32 [H, Sq, Skv]")
+        if fp8:
+            raise ValueError("the fp8 path takes no score bias")
+        a.bias, a.bias_sh = _p(bias), Sq * Skv
     a.B, a.H, a.Sq, a.Skv, a.kv_batch_div = B, H, Sq, Skv, kv_batch_div
     a.scale = (64 ** -0.5) if scale is None else scale
     a.out_scale = out_scale
@@ -213,7 +222,7 @@ KERNEL_TIMING = None
 
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float, *,
               out: Optional[torch.Tensor] = None, shift0=None, scale0=None, shift1=None, scale1=None,
-              rows_per_batch: int = 0, split: int = 0, mod_stride: int = 0, out_batched: Optional[torch.Tensor] = None) -> torch.Tensor:
+              rows_per_batch: int = 0, split: int = 0, mod_stride: int = 0, out_batched: Optional[torch.Tensor] = None, rms: bool = False) -> torch.Tensor:
     """LayerNorm over the last dim (+ AdaLN modulation).  `out_batched` [B, L', D] (a view whose batch
     stride differs from L*D, e.g. a slice of a concat buffer) receives x [B, L, D] row by row."""
     _dev(x, name="x")
@@ -233,6 +242,7 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     a.x, a.gamma, a.beta = _p(x2), _p(gamma), _p(beta)
     a.rows, a.D, a.ldx = x2.shape[0], x2.shape[1], x2.stride(0)
     a.eps = eps
+    a.rms = 1 if rms else 0                               # RMSNorm (T5LayerNorm): x * rsqrt(mean(x^2) + eps) * gamma
     if shift0 is not None:
         a.shift0, a.scale0, a.shift1, a.scale1 = _p(shift0), _p(scale0), _p(shift1), _p(scale1)
         a.rows_per_batch, a.split, a.mod_stride = rows_per_batch, split, mod_stride

@@ -67,14 +67,20 @@ def test_t5_xxl_width_two_layers_vs_oracle_and_live_transformers(hip):
     from motionrag_amd import t5
     torch.manual_seed(8)
     m = t5.T5EncoderModel(vocab_size=512, num_layers=2)
-    with torch.no_grad():
-        for n, p in m.named_parameters():
+    with torch.no_grad():                                                         # T5's own initialisation (T5PreTrainedModel._init_weights, factor 1): scores of O(1) --
+        for n, p in m.named_parameters():                                         # T5 does not scale q k^T, so N(0, 0.02) weights at d_model 4096 would give logits of +-13
             if p.dim() == 1:
                 p.add_(0.05 * torch.randn_like(p))
             elif "relative_attention_bias" in n or n.startswith("shared"):
                 p.normal_(0.0, 1.0)
-            else:
-                p.normal_(0.0, 0.02)
+            elif n.endswith("SelfAttention.q.weight"):
+                p.normal_(0.0, (4096 * 64) ** -0.5)
+            elif n.endswith(("SelfAttention.k.weight", "SelfAttention.v.weight", "wi_0.weight", "wi_1.weight")):
+                p.normal_(0.0, 4096 ** -0.5)
+            elif n.endswith("SelfAttention.o.weight"):
+                p.normal_(0.0, (64 * 64) ** -0.5)
+            elif n.endswith("wo.weight"):
+                p.normal_(0.0, 10240 ** -0.5)
             p.copy_(p.to(torch.bfloat16).float())
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     ids = torch.randint(0, 512, (2, 226))

@@ -257,6 +257,30 @@ def vae(frames=16, h=72, w=128):
     return {"ms_per_clip": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(frames / dt)}
 
 
+def t5():
+    """CogVideoX's prompt encoder: the T5-v1.1-XXL encoder (24 layers x 4096, 64 heads, d_ff 10240; 4.76 B parameters = 9.5 GB bf16) on prompt +
+    negative prompt, 226 tokens each -- weight-bandwidth-bound: every weight is read once per call"""
+    from motionrag_amd import t5 as T
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(DEV):
+            m = T.T5EncoderModel()
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 4096 ** -0.5 if "SelfAttention.q" not in n else (4096 * 64) ** -0.5)
+    ids = torch.randint(0, 32128, (2, 226), device=DEV)
+    out = m(ids)[0]
+    assert out.shape == (2, 226, 4096) and torch.isfinite(out.float()).all()
+    dt = timeit(lambda: m(ids), iters=5, warm=2)
+    nbytes = sum(p.numel() for n, p in m.named_parameters() if not n.startswith("shared")) * 2
+    print(f"T5-v1.1-XXL encoder, 2 x 226 tokens: {dt*1e3:.2f} ms  weights {nbytes/1e9:.2f} GB -> {nbytes/dt/1e12:.2f} TB/s")
+    return {"ms": round(dt * 1e3, 2), "weight_GB": round(nbytes / 1e9, 2), "weight_stream_TBps": round(nbytes / dt / 1e12, 2)}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

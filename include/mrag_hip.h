@@ -94,16 +94,9 @@ typedef struct mrag_gemm_args {
   int32_t tuning;     /* developer knobs (tools/microbench.py), 0 = shipped: MRAG_GEMM_TUNE_* bits, bits 4-7 tile choice
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
   int32_t geglu_act;  /* MRAG_EPI_GEGLU: 0 = v * gelu_erf(g) (diffusers / lvdm GEGLU), 1 = v * gelu_tanh(g) (T5 v1.1 "gated-gelu": gelu_new) */
-  void* workspace;    /* optional split-K scratch, 256-byte aligned, >= mrag_gemm_workspace_bytes(M, N, K) bytes, ZERO on first use (the kernel leaves its
-                         ticket words zero) and private to the stream: small weight-bound problems (fewer than 128 tiles of 128 x 128, K >= 512 -- CAMA's
-                         Resamplers / encoder, the ViT and T5 encoders at a few hundred rows) then split K over up to 16 workgroups per tile whose fp32
-                         partial accumulators are summed in split order by the last arriver, which runs the epilogue -- one launch, bit-reproducible.
-                         NULL = never split.                                                                                                            */
-  int64_t workspace_bytes;
 } mrag_gemm_args;
-enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_NO_SPLITK = 8 };
+enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4 };
 
-int64_t mrag_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);   /* 0 when the problem never splits */
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 
 /* ------------------------------------------------------------------------ */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip"]
-ABI_VERSION = 5
+ABI_VERSION = 4
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
@@ -31,12 +31,12 @@ SYMBOLS = [
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
     "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16",
-    "mrag_gemm_workspace_bytes", "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
+    "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
 ]
 
 
 # entry points whose result is not the int32 status code (their restype is set explicitly in lib())
-_NON_INT_RESULT = ("mrag_target_arch", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes", "mrag_gemm_workspace_bytes",
+_NON_INT_RESULT = ("mrag_target_arch", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
                    "mrag_resampler_workspace_bytes", "mrag_cama_encoder_workspace_bytes")
 
 
@@ -54,7 +54,6 @@ class GemmArgs(Structure):
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
         ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32), ("geglu_act", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -194,8 +193,6 @@ def lib() -> ctypes.CDLL:
     if L.mrag_abi_version() != ABI_VERSION:
         raise HipLibraryMissing(f"{LIB_PATH} has ABI {L.mrag_abi_version()}, expected {ABI_VERSION}: rebuild")
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
-    L.mrag_gemm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
-    L.mrag_gemm_workspace_bytes.restype = c_int64
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
     L.mrag_attn_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
     L.mrag_attn_workspace_bytes.restype = c_int64

@@ -16,15 +16,12 @@ typedef unsigned short bf16_t;
 
 inline int64_t al(int64_t n) { return (n + 255) / 256 * 256; }
 
-constexpr int64_t kGemmWs = 4096 + 512LL * 128 * 128 * 4;   // mrag_gemm_workspace_bytes' upper bound: the split-K scratch of the small-M GEMMs
-
-inline int gemm(void* s, const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int epi, const void* resid, void* gws = nullptr) {
+inline int gemm(void* s, const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int epi, const void* resid) {
   mrag_gemm_args g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = resid;
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldr = N;
   g.epilogue = epi;
-  g.workspace = gws; g.workspace_bytes = gws ? kGemmWs : 0;
   return mrag_gemm_bf16(s, &g);
 }
 
@@ -46,7 +43,6 @@ inline int ln(void* s, const void* x, void* y, const void* w, const void* b, int
 struct ResamplerWs {
   bf16_t *x, *kv_in, *lat_a, *lat_b, *ln_lat, *q, *kv, *o, *h_ln, *h, *proj;
   void* attn_ws; int64_t attn_ws_bytes;   // the attention's own scratch (key-split tail), as ops.attention provides it
-  void* gemm_ws;                          // split-K scratch of the GEMMs (tickets zeroed at the start of every call)
   int64_t bytes;
 };
 
@@ -68,7 +64,6 @@ ResamplerWs carve_resampler(void* base, int64_t N, int64_t n1, int64_t nq, int64
   w.proj = take(N * nq * out_dim);
   w.attn_ws_bytes = aws;
   w.attn_ws = aws > 0 ? (void*)take((aws + 1) / 2) : nullptr;
-  w.gemm_ws = (void*)take(kGemmWs / 2);
   w.bytes = off;
   return w;
 }
@@ -90,9 +85,8 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
   hipStream_t hs = (hipStream_t)stream;
   // latents.repeat(N, 1, 1)  (resampler.py:158): zero + broadcast add of the [nq, dim] table
   if (hipMemsetAsync(w.lat_a, 0, (size_t)(N * nq * dim * 2), hs) != hipSuccess) return (int)hipGetLastError();
-  if (hipMemsetAsync(w.gemm_ws, 0, 4096, hs) != hipSuccess) return (int)hipGetLastError();
   TRY(mrag_add_rows_bf16(stream, w.lat_a, a->latents, w.lat_a, N * nq, dim, nq));
-  TRY(gemm(stream, a->x, a->proj_in_w, a->proj_in_b, w.x, N * n1, dim, a->embedding_dim, MRAG_EPI_NONE, nullptr, w.gemm_ws));                     // :159
+  TRY(gemm(stream, a->x, a->proj_in_w, a->proj_in_b, w.x, N * n1, dim, a->embedding_dim, MRAG_EPI_NONE, nullptr));                     // :159
   bf16_t* lat = w.lat_a;
   bf16_t* lat_next = w.lat_b;
   for (int l = 0; l < a->depth; ++l) {
@@ -102,8 +96,8 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     TRY(ln(stream, w.x, w.kv_in, L.norm1_w, L.norm1_b, N * n1, dim, a->eps, n1, (n1 + nq) * dim));
     TRY(ln(stream, lat, w.kv_in + n1 * dim, L.norm2_w, L.norm2_b, N * nq, dim, a->eps, nq, (n1 + nq) * dim));
     TRY(ln(stream, lat, w.ln_lat, L.norm2_w, L.norm2_b, N * nq, dim, a->eps));
-    TRY(gemm(stream, w.ln_lat, L.to_q, nullptr, w.q, N * nq, inner, dim, MRAG_EPI_NONE, nullptr, w.gemm_ws));
-    TRY(gemm(stream, w.kv_in, L.to_kv, nullptr, w.kv, N * (n1 + nq), 2 * inner, dim, MRAG_EPI_NONE, nullptr, w.gemm_ws));                          // K rows first (chunk(2)) :96
+    TRY(gemm(stream, w.ln_lat, L.to_q, nullptr, w.q, N * nq, inner, dim, MRAG_EPI_NONE, nullptr));
+    TRY(gemm(stream, w.kv_in, L.to_kv, nullptr, w.kv, N * (n1 + nq), 2 * inner, dim, MRAG_EPI_NONE, nullptr));                          // K rows first (chunk(2)) :96
     mrag_attn_args at;
     memset(&at, 0, sizeof(at));
     at.Q = w.q; at.K = w.kv; at.V = w.kv + inner; at.O = w.o;
@@ -115,21 +109,21 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     at.scale = 0.125f; at.out_scale = 1.0f;
     at.workspace = w.attn_ws; at.workspace_bytes = w.attn_ws_bytes;
     TRY(mrag_attn_fwd_bf16(stream, &at));
-    TRY(gemm(stream, w.o, L.to_out, nullptr, lat_next, N * nq, dim, inner, MRAG_EPI_RESID, lat, w.gemm_ws));                                        // attn(...) + latents :162
+    TRY(gemm(stream, w.o, L.to_out, nullptr, lat_next, N * nq, dim, inner, MRAG_EPI_RESID, lat));                                        // attn(...) + latents :162
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
     TRY(ln(stream, lat, w.h_ln, L.ff_ln_w, L.ff_ln_b, N * nq, dim, a->eps));
-    TRY(gemm(stream, w.h_ln, L.ff_w1, nullptr, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF, nullptr, w.gemm_ws));
-    TRY(gemm(stream, w.h, L.ff_w2, nullptr, lat_next, N * nq, dim, ff, MRAG_EPI_RESID, lat, w.gemm_ws));                                            // ff(...) + latents :163
+    TRY(gemm(stream, w.h_ln, L.ff_w1, nullptr, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF, nullptr));
+    TRY(gemm(stream, w.h, L.ff_w2, nullptr, lat_next, N * nq, dim, ff, MRAG_EPI_RESID, lat));                                            // ff(...) + latents :163
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
   }
-  TRY(gemm(stream, lat, a->proj_out_w, a->proj_out_b, w.proj, N * nq, od, dim, MRAG_EPI_NONE, nullptr, w.gemm_ws));
+  TRY(gemm(stream, lat, a->proj_out_w, a->proj_out_b, w.proj, N * nq, od, dim, MRAG_EPI_NONE, nullptr));
   return ln(stream, w.proj, a->out, a->norm_out_w, a->norm_out_b, N * nq, od, a->eps);
 }
 
 extern "C" int64_t mrag_cama_encoder_workspace_bytes(int32_t B, int32_t L, int32_t d_model, int32_t ff_dim) {
   if (B <= 0 || L <= 0 || d_model <= 0 || ff_dim <= 0) return 0;
   const int64_t rows = (int64_t)B * L;
-  return al(rows * 3 * d_model * 2) + 4 * al(rows * d_model * 2) + al(rows * ff_dim * 2) + al(mrag_attn_workspace_bytes(B, d_model / 64, L, L)) + al(kGemmWs);
+  return al(rows * 3 * d_model * 2) + 4 * al(rows * d_model * 2) + al(rows * ff_dim * 2) + al(mrag_attn_workspace_bytes(B, d_model / 64, L, L));
 }
 
 extern "C" int mrag_cama_encoder_fwd(void* stream, const mrag_cama_encoder_args* a) {
@@ -145,15 +139,12 @@ extern "C" int mrag_cama_encoder_fwd(void* stream, const mrag_cama_encoder_args*
   bf16_t* xl = (bf16_t*)base; base += al(rows * d * 2);   // a layer's output = the next layer's input and residual (the last layer writes a->out)
   bf16_t* f = (bf16_t*)base; base += al(rows * ff * 2);
   const int64_t aws = mrag_attn_workspace_bytes(a->B, a->nhead, a->L, a->L);
-  void* attn_ws = aws > 0 ? (void*)base : nullptr; base += al(aws);
-  void* gws = (void*)base;
-  if (hipMemsetAsync(gws, 0, 4096, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
   const bf16_t* x = (const bf16_t*)a->x;
   for (int l = 0; l < a->num_layers; ++l) {
     const mrag_encoder_layer& E = a->layers[l];
     if (!E.in_proj_w || !E.out_proj_w || !E.lin1_w || !E.lin2_w) return MRAG_EINVAL;
     // post-norm layer: x = LN1(x + MHA(x)); x = LN2(x + W2 gelu(W1 x))
-    TRY(gemm(stream, x, E.in_proj_w, E.in_proj_b, qkv, rows, 3 * d, d, MRAG_EPI_NONE, nullptr, gws));
+    TRY(gemm(stream, x, E.in_proj_w, E.in_proj_b, qkv, rows, 3 * d, d, MRAG_EPI_NONE, nullptr));
     mrag_attn_args at;
     memset(&at, 0, sizeof(at));
     at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.O = att; at.mask = a->mask;
@@ -163,12 +154,12 @@ extern "C" int mrag_cama_encoder_fwd(void* stream, const mrag_cama_encoder_args*
     at.o_sb = (int64_t)a->L * d; at.o_ss = d;
     at.B = a->B; at.H = a->nhead; at.Sq = a->L; at.Skv = a->L; at.kv_batch_div = 1;
     at.scale = 0.125f; at.out_scale = 1.0f;
-    at.workspace = attn_ws; at.workspace_bytes = aws;
+    at.workspace = aws > 0 ? (void*)base : nullptr; at.workspace_bytes = aws;
     TRY(mrag_attn_fwd_bf16(stream, &at));
-    TRY(gemm(stream, att, E.out_proj_w, E.out_proj_b, y, rows, d, d, MRAG_EPI_RESID, x, gws));
+    TRY(gemm(stream, att, E.out_proj_w, E.out_proj_b, y, rows, d, d, MRAG_EPI_RESID, x));
     TRY(ln(stream, y, x1, E.norm1_w, E.norm1_b, rows, d, a->eps));
-    TRY(gemm(stream, x1, E.lin1_w, E.lin1_b, f, rows, ff, d, MRAG_EPI_GELU_ERF, nullptr, gws));
-    TRY(gemm(stream, f, E.lin2_w, E.lin2_b, y, rows, d, ff, MRAG_EPI_RESID, x1, gws));
+    TRY(gemm(stream, x1, E.lin1_w, E.lin1_b, f, rows, ff, d, MRAG_EPI_GELU_ERF, nullptr));
+    TRY(gemm(stream, f, E.lin2_w, E.lin2_b, y, rows, d, ff, MRAG_EPI_RESID, x1));
     bf16_t* dst = (l == a->num_layers - 1) ? (bf16_t*)a->out : xl;   // x (= xl from the previous layer) was last read by out_proj's residual: free to overwrite
     TRY(ln(stream, y, dst, E.norm2_w, E.norm2_b, rows, d, a->eps));
     x = dst;

@@ -55,8 +55,6 @@ struct GemmP {
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
   long long qk_D; int rope_text_len, qk_first; float qk_eps, q_premul;
   int geglu_tanh;   // MRAG_EPI_GEGLU: gate activation gelu_tanh instead of gelu_erf (wave-uniform)
-  // split-K (small-M, weight-bound GEMMs: CAMA, the ViT / T5 encoders): blockIdx.y owns K-tiles [y * kt_per_split, ...); partial accumulators meet in `sk_part`
-  int splits, kt_per_split; float* sk_part; unsigned* sk_count; long long sk_bytes;
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
@@ -155,13 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   const int a_off = (wm * TM * 16 + frag_row) * 128;
   const int w_off = BM * 128 + (wn * TN * 16 + frag_row) * 128;
 
-  int nk = (int)(p.K / BK);
-  if (p.splits > 1) {   // CONV == 0 only (host): this workgroup's K range; every split is non-empty (host)
-    const int kt0 = (int)blockIdx.y * p.kt_per_split;
-    nk = min(p.kt_per_split, nk - kt0);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) gsrc[i] += (long long)kt0 * BK;
-  }
+  const int nk = (int)(p.K / BK);
 
   // DMA source of piece i for K-tile kt.  Plain GEMM: the row pointer advanced by kt * 64.  Convolutions: K-tile kt is channel
   // block (kt % ctiles) of tap (kt / ctiles); the lane's row is the tap-shifted pixel (or frame), or the zero row outside.
@@ -354,46 +346,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
-    }
-  }
-
-  // ---- split-K: every split leaves its fp32 accumulators in the workspace (thread-private layout: register r of thread t at [r * threads + t], so the
-  // stores and the reloads are coalesced and need no index arithmetic), takes a ticket, and the LAST arriver of a tile sums all the partials in split
-  // order (bit-reproducible whatever the arrival order) and runs the ordinary epilogue.  One launch, no second pass, no host round trip.
-  if (p.splits > 1) {
-    constexpr int NT = NW * 64, NR = TM * TN * 4;
-    const int tile = tile_m * p.tiles_n + tile_n;
-    float* mine = p.sk_part + ((long long)tile * p.splits + blockIdx.y) * (long long)(NT * NR);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[((i * TN + j) * 4 + r) * NT + tid] = acc[i][j][r];
-    __threadfence();                         // release: the partial is visible device-wide before the ticket
-    __syncthreads();
-    __shared__ unsigned sk_last;
-    if (tid == 0) {
-      const unsigned t = atomicAdd(p.sk_count + tile, 1u);
-      sk_last = (t == (unsigned)p.splits - 1) ? 1u : 0u;
-      if (sk_last) p.sk_count[tile] = 0;     // ready for the next launch (nobody else touches this counter any more)
-    }
-    __syncthreads();
-    if (!sk_last) return;
-    __threadfence();                         // acquire
-    const float* base = p.sk_part + (long long)tile * p.splits * (long long)(NT * NR);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < p.splits; ++sp) {
-      const float* src_p = base + (long long)sp * (NT * NR);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[i][j][r] += __builtin_nontemporal_load(src_p + ((i * TN + j) * 4 + r) * NT + tid);
     }
   }
 
@@ -760,27 +712,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
-  // split-K for small, weight-bound problems (fewer tiles than half the chip, a long K): enough splits to put ~2 workgroups on every CU, each at
-  // least 4 K-tiles deep; needs the caller's zero-initialised workspace (mrag_gemm_workspace_bytes)
-  p.splits = 1;
-  if constexpr (CONV == 0) {
-    const int tiles = p.tiles_m * p.tiles_n, nk = (int)(p.K / 64);
-    constexpr long long PART = (long long)BM * BN * 4;
-    if (p.sk_part && tiles < 128 && nk >= 8 && !(p.tuning & MRAG_GEMM_TUNE_NO_SPLITK)) {
-      int sp = (512 + tiles - 1) / tiles;
-      sp = sp < nk / 4 ? sp : nk / 4;
-      sp = sp < 16 ? sp : 16;
-      const long long room = (p.sk_bytes - 4096) / (PART * tiles);
-      sp = sp < room ? sp : (int)room;
-      if (sp > 1) {
-        p.kt_per_split = (nk + sp - 1) / sp;
-        p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;      // every split non-empty
-        p.sk_count = (unsigned*)p.sk_part;                            // the first 4 KB: per-tile tickets (zero on entry, left zero)
-        p.sk_part = p.sk_part + 1024;
-      }
-    }
-  }
-  const dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 64);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
   if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || (epi == MRAG_EPI_GEGLU && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
@@ -841,10 +773,6 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
   p.geglu_tanh = a->geglu_act == 1;
-  if (a->workspace && a->workspace_bytes >= (1 << 20)) {
-    if ((uintptr_t)a->workspace & 255) return MRAG_EINVAL;
-    p.sk_part = (float*)a->workspace; p.sk_bytes = a->workspace_bytes;
-  }
   if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
     if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
@@ -902,11 +830,4 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
   if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 2>(s, p, a->epilogue);
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 2>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4, 2>(s, p, a->epilogue);
-}
-
-extern "C" int64_t mrag_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K < 512) return 0;
-  const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles >= 128) return 0;
-  return 4096 + 512LL * 128 * 128 * 4;      // tickets + at most ~512 partial 128 x 128 fp32 tiles (32 MB)
 }

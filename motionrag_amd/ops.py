@@ -21,7 +21,7 @@ LOG2E = 1.4426950408889634
 # Developer tuning knobs (tools/microbench.py, A/B tests): explicit `tuning` fields of the C-ABI argument structs, 0 = the shipped behaviour.
 # Nothing on the launch path reads the environment.
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
-GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED, GEMM_TUNE_NO_SPLITK = 1, 2, 4, 8
+GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
 ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4, ATTN_TUNE_SUBS2, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
@@ -77,9 +77,6 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     a.epilogue = epilogue
     a.tuning = TUNING["gemm"]
     a.geglu_act = 1 if geglu_tanh else 0
-    if K >= 512 and ((M + 127) // 128) * ((N + 127) // 128) < 128:      # small weight-bound problem: split-K scratch (zeroed once, reused on this stream)
-        ws = _gemm_workspace(x.device)
-        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
     if resid is not None:
         r2 = _rows(_dev(resid, name="resid"))
         a.resid, a.ldr = _p(r2), r2.stride(0)
@@ -118,16 +115,6 @@ def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
 
 
 _ATTN_WS = {}
-_GEMM_WS = {}
-
-
-def _gemm_workspace(device: torch.device) -> torch.Tensor:
-    """split-K scratch of mrag_gemm_bf16 (tickets + partial tiles), one zero-initialised 33 MB buffer per (device, stream); the kernel leaves the tickets zero"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _GEMM_WS.get(key)
-    if ws is None:
-        ws = _GEMM_WS[key] = torch.zeros(4096 + 512 * 128 * 128 * 4, dtype=torch.uint8, device=device)
-    return ws
 
 
 def _attn_workspace(device: torch.device, nbytes: int, kind: str = "split") -> torch.Tensor:

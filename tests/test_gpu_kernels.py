@@ -604,31 +604,3 @@ def test_topk_prepared_plan_single_launch(hip):
     want_r, want_d = topk_ref.topk(db, qs[:4], 12, "dot", mode="f32chain")
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(275, 1024, 4096, "resid"), (500, 1024, 1024, "none"), (452, 4096, 10240, "resid"), (64, 768, 3072, "gelu"), (300, 256, 8192, "none")])
-def test_split_k_small_m_gemm(hip, M, N, K, epi):
-    """small weight-bound problems split K over several workgroups per tile (mrag_gemm_args.workspace): same result as the unsplit launch up to fp32 summation order,
-    bit-reproducible run to run (partials are summed in split order by the last arriver), tickets left zero"""
-    from motionrag_amd import ops
-    g = torch.Generator().manual_seed(M + K)
-    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(DEV)
-    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
-    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
-    kw = {"resid": dict(epilogue=ops.EPI_RESID, resid=r), "none": {}, "gelu": dict(epilogue=ops.EPI_GELU_ERF)}[epi]
-    y1 = ops.linear(x, w, b, **kw)
-    y2 = ops.linear(x, w, b, **kw)
-    assert torch.equal(y1, y2), "split-K result differs run to run"
-    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_SPLITK
-    try:
-        y0 = ops.linear(x, w, b, **kw)
-    finally:
-        ops.TUNING["gemm"] = 0
-    ref = x.float() @ w.float().T + b.float()
-    ref = {"resid": lambda v: v + r.float(), "none": lambda v: v, "gelu": torch.nn.functional.gelu}[epi](ref)
-    scale = ref.abs().mean().item()
-    assert (y1.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item() + 0.02 * scale
-    assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()         # vs the unsplit launch: one bf16 ulp of the largest value
-    ws = ops._gemm_workspace(x.device)
-    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "ticket words must be left zero"

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""developer tool: CAMA predict (2 Resamplers + 4-layer encoder, k = 9 retrieved clips + target, CFG) with fixed random features in place of the frozen encoders --
+run under `rocprofv3 --kernel-trace --stats` for the per-kernel split of the ~3.3 ms per clip"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib.util  # noqa: E402
+import torch  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("mrag_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+from microbench import timeit  # noqa: E402
+
+dev = "cuda"
+_, cam, _ = bench.build_models(dev, 1, 13)
+batch = {"ref_videos": torch.zeros(1, 9, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev), "video": torch.zeros(1, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev)}
+dt = timeit(lambda: cam.predict(batch, do_classifier_free_guidance=True), iters=int(os.environ.get("ITERS", "20")), warm=3)
+print(f"CAMA predict: {dt*1e3:.3f} ms per clip")

@@ -54,7 +54,6 @@ struct GemmP {
   // MRAG_EPI_QKNORM_ROPE
   const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb; const float* rcos; const float* rsin;
   long long qk_D; int rope_text_len, qk_first; float qk_eps, q_premul;
-  int geglu_tanh;   // MRAG_EPI_GEGLU: gate activation gelu_tanh instead of gelu_erf (wave-uniform)
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
@@ -71,6 +70,12 @@ __device__ __forceinline__ float sum8_dpp(float x) {
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
   return x;
 }
+
+// internal epilogue id: MRAG_EPI_GEGLU with the tanh gate (mrag_gemm_args.geglu_act = 1, T5's gated-gelu): its own instantiation, so the erf kernels of the
+// UNets (epilogue-bound at K = 320) carry neither a branch nor the second activation's registers
+constexpr int EPI_GEGLU_TANH = 8;
+template <int EPI>
+constexpr bool is_geglu = (EPI == MRAG_EPI_GEGLU || EPI == EPI_GEGLU_TANH);
 
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   };
   // ---- epilogue: lane owns row m = .. + (lane & 15), columns n0 + (lane >> 4) * 4 + {0..3}
   constexpr bool STAGED = (TM == 8 && TN == 4 && WM == 2 && WN == 4);
-  if (STAGED && p.staged && EPI != MRAG_EPI_GEGLU) {   // GEGLU has its own staged form below ([M, N/2] output)
+  if (STAGED && p.staged && !is_geglu<EPI>) {   // GEGLU has its own staged form below ([M, N/2] output)
     // The accumulator layout gives 8-byte pieces of 16 different rows per store instruction (32-byte row segments): the store
     // tail was ~24 % of a K = 3072 workgroup.  Stage the wave's 128 x 64 bf16 tile through LDS (row pitch 144 B) and write
     // whole 128-byte row segments with 16-byte lanes; bias / activation / gate are applied in the accumulator layout, the
@@ -566,9 +571,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 #endif
     return;
   }
-  if constexpr (EPI == MRAG_EPI_GEGLU && TN % 2 != 0) {
+  if constexpr (is_geglu<EPI> && TN % 2 != 0) {
     return;   // never dispatched: the value / gate pairing needs an even number of 16-column tiles per wave
-  } else if constexpr (EPI == MRAG_EPI_GEGLU) {
+  } else if constexpr (is_geglu<EPI>) {
     // W rows arrive interleaved in 16-row groups: [value 16m..16m+15 | gate 16m..16m+15], so the even 16-column MFMA tile
     // holds the values and the odd one the gates of the SAME 16 outputs in the same lanes: C[m, j] = v * gelu_erf(g),
     // C is [M, N/2].  Removes the [M, N] round trip and the separate GEGLU pass (6 % of an SVD / DynamiCrafter step).
@@ -595,13 +600,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
               g[0] += __uint_as_float(bg[0] << 16); g[1] += __uint_as_float(bg[0] & 0xffff0000u);
               g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
             }
-            if (__builtin_expect(p.geglu_tanh, 0)) {   // wave-uniform: a scalar branch, not a select over both activations
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_tanh_f(bf_round(g[e]));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
-            }
+            for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
             u32x2 out;
             out[0] = pack_bf2(v[0], v[1]);
             out[1] = pack_bf2(v[2], v[3]);
@@ -639,13 +639,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
           g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
         }
         // the reference rounds both halves of proj(x) to bf16 before the product (nn.Linear output dtype)
-        if (__builtin_expect(p.geglu_tanh, 0)) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_tanh_f(bf_round(g[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * gelu_erf_f(bf_round(g[e]));
-        }
+        for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
         u32x2 out;
         out[0] = pack_bf2(v[0], v[1]);
         out[1] = pack_bf2(v[2], v[3]);
@@ -715,7 +710,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
-  if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || (epi == MRAG_EPI_GEGLU && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
+  if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || ((epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
@@ -742,6 +737,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
       MRAG_GEMM_CASE(MRAG_EPI_GATE_RESID)
       MRAG_GEMM_CASE(MRAG_EPI_SILU)
       MRAG_GEMM_CASE(MRAG_EPI_GEGLU)
+      MRAG_GEMM_CASE(EPI_GEGLU_TANH)
       MRAG_GEMM_CASE(MRAG_EPI_QKNORM_ROPE)
       default: return MRAG_EINVAL;
     }
@@ -772,7 +768,6 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.gate0 = (const bf16_t*)a->gate0; p.gate1 = (const bf16_t*)a->gate1;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
-  p.geglu_tanh = a->geglu_act == 1;
   if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
     if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
@@ -787,13 +782,14 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // so that a few hundred rows still spread over the 256 CUs.
   const long long t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   p.tuning = a->tuning;
+  const int epi = (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act == 1) ? EPI_GEGLU_TANH : a->epilogue;   // the tanh gate is its own instantiation
   if (const int cfg = (a->tuning >> 4) & 0xf) {   // developer knob (tools/microbench.py); 0 = the shipped choice below
-    if (cfg == 1 && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, a->epilogue);   // 256x256, 16 waves (4 per SIMD)
-    if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);                  // 128x128, 4 waves, 2 workgroups per CU
+    if (cfg == 1 && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, epi);   // 256x256, 16 waves (4 per SIMD)
+    if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, epi);                  // 128x128, 4 waves, 2 workgroups per CU
   }
-  if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, a->epilogue);   // 256x320 tile
-  if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, a->epilogue);
-  return launch_cfg<2, 2, 4, 4>(s, p, a->epilogue);
+  if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, epi);   // 256x320 tile
+  if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, epi);
+  return launch_cfg<2, 2, 4, 4>(s, p, epi);
 }
 
 extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {

@@ -338,6 +338,9 @@ int mrag_assemble_tokens_bf16(void* stream, const void* x, const void* prefix, c
  * scale > 0): the middle of the KL-VAE decoder's single-head head_dim-512 AttnBlock (lvdm/modules/networks/ae_modules.py:54-79: bmm, * c^-0.5,
  * softmax(dim=2), bmm), whose two products run on mrag_gemm_bf16.                                                                                    */
 int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float scale);
+/* denormalize (src/utils/pipeline.py:178-184; VideoBaseModule.validation_step, src/projects/base_module.py:129-147): y = uint8(clip((x + 1) / 2, 0, 1) * 255),
+ * x bf16 (or fp32 with src_fp32 = 1) with the rounding points of the torch ops on that dtype, truncating cast -- bit-exact byte output.               */
+int mrag_denormalize_u8(void* stream, const void* x, void* y, int64_t n, int32_t src_fp32);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,

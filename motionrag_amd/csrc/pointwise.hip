@@ -262,6 +262,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* x, bf16
   }
 }
 
+// denormalize (src/utils/pipeline.py:178-184): uint8(clip((x + 1) / 2, 0, 1) * 255) with the reference's rounding points -- on a bf16 tensor every torch op rounds
+// to bf16 (x + 1, then / 2 is exact, then * 255), and `.to(torch.uint8)` truncates.  Byte output: bit-exact against the torch ops on the host.
+template <bool FP32>
+__global__ void denormalize_u8_kernel(const void* x, unsigned char* y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v;
+    if (FP32) {
+      v = ((const float*)x)[i];
+      v = (v + 1.0f) / 2.0f;
+      v = fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f;
+    } else {
+      auto rb = [](float f) { float o[8] = {f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return __uint_as_float((pack8(o)[0] & 0xffffu) << 16); };   // round to bf16
+      v = __uint_as_float(((unsigned)((const bf16_t*)x)[i]) << 16);
+      v = rb(rb(v + 1.0f) / 2.0f);
+      v = rb(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f);
+    }
+    y[i] = v != v ? 0 : (unsigned char)v;          // NaN -> 0 (the host's cast of NaN is unspecified; clip keeps everything else in [0, 255])
+  }
+}
+
 }  // namespace
 
 extern "C" int mrag_timestep_embedding_bf16(void* stream, const float* t, void* out, int32_t B, int32_t dim) {
@@ -367,6 +387,16 @@ extern "C" int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int6
   if ((((uintptr_t)x | (uintptr_t)y) & 15) || (ldx % 8) || (ldy % 8)) return MRAG_EINVAL;
   if (rows > 0x7fffffffLL) return MRAG_EINVAL;
   MRAG_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long long)cols, (long long)ldx, (long long)ldy, scale);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_denormalize_u8(void* stream, const void* x, void* y, int64_t n, int32_t src_fp32) {
+  if (!x || !y || n <= 0) return MRAG_EINVAL;
+  const long long blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64));
+  if (src_fp32) MRAG_LAUNCH(denormalize_u8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)y, (long long)n);
+  else MRAG_LAUNCH(denormalize_u8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)y, (long long)n);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -328,6 +328,7 @@ typedef struct mrag_resize_patch_args {
   int64_t s_n, s_t, s_c, ldo;      /* element strides of src over n, t, c; row stride of out                                   */
   int32_t N, T, C, H, W, OH, OW, taps_y, taps_x, pt, ph, pw, src_fp32;
   float scale[4], shift[4];        /* per channel (C <= 4)                                                                     */
+  int32_t no_tiling;               /* developer knob: 1 = the per-pixel kernel instead of the LDS-tiled one (same results)      */
 } mrag_resize_patch_args;
 int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_args* args);
 /* ViT token assembly (transformers Dinov2Embeddings.forward: cat(cls, patches) + position table; VideoMAEEmbeddings.forward: P = 0):

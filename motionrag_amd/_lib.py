@@ -90,7 +90,7 @@ class ResizePatchArgs(Structure):
         ("s_n", c_int64), ("s_t", c_int64), ("s_c", c_int64), ("ldo", c_int64),
         ("N", c_int32), ("T", c_int32), ("C", c_int32), ("H", c_int32), ("W", c_int32), ("OH", c_int32), ("OW", c_int32),
         ("taps_y", c_int32), ("taps_x", c_int32), ("pt", c_int32), ("ph", c_int32), ("pw", c_int32), ("src_fp32", c_int32),
-        ("scale", c_float * 4), ("shift", c_float * 4),
+        ("scale", c_float * 4), ("shift", c_float * 4), ("no_tiling", c_int32),
     ]
 
 

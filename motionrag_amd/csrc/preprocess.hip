@@ -79,6 +79,64 @@ __global__ __launch_bounds__(256) void resize_patch_kernel(const PreP p) {
   }
 }
 
+
+// LDS-tiled form of the resize: a workgroup owns 8 x 64 output pixels of one plane.  The source window (R rows x CW columns, a few KB) is loaded ONCE with
+// coalesced loads and converted to fp32 in LDS; the horizontal pass runs from LDS into a second LDS image h[R][64]; the vertical pass reads h.  A source pixel is
+// read from HBM / L2 once per tile instead of ~25-100 times per output pixel, and the arithmetic drops from taps_x * taps_y to taps_x * R / 8 + taps_y per output.
+// Same summation order per output as resize_patch_kernel (sum_y w_y (sum_x w_x src)), hence bit-identical results.
+constexpr int RT_TH = 8, RT_TW = 64, RT_RMAX = 48, RT_CWMAX = 320;
+
+template <bool FP32>
+__global__ __launch_bounds__(256) void resize_patch_tiled_kernel(const PreP p, int tiles_x, int tiles_y) {
+  __shared__ float win[RT_RMAX * (RT_CWMAX + 1)];
+  __shared__ float hbuf[RT_RMAX * RT_TW];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; b /= tiles_y;
+  const int c = b % p.C; b /= p.C;
+  const int t = b % p.T;
+  const int n = b / p.T;
+  const int oy0 = ty * RT_TH, ox0 = tx * RT_TW;
+  const int th = min(RT_TH, p.OH - oy0), tw = min(RT_TW, p.OW - ox0);
+  // source window of the tile (wave-uniform; the tables are monotone in the output coordinate, the spans need not be)
+  int r0 = p.y0[oy0], r1 = r0, c0 = p.x0[ox0], c1 = c0;
+  for (int i = 0; i < th; ++i) { const int a = p.y0[oy0 + i]; r0 = min(r0, a); r1 = max(r1, a + p.ny[oy0 + i]); }
+  for (int i = 0; i < tw; ++i) { const int a = p.x0[ox0 + i]; c0 = min(c0, a); c1 = max(c1, a + p.nx[ox0 + i]); }
+  const int R = r1 - r0, CW = c1 - c0, pitch = CW | 1;     // odd pitch: the column-strided reads of the horizontal pass spread over the banks
+  const int ts = p.frame_idx ? p.frame_idx[t] : t;
+  const long long base = (long long)n * p.s_n + (long long)ts * p.s_t + (long long)c * p.s_c + (long long)r0 * p.W + c0;
+  for (int i = tid; i < R * CW; i += 256) {
+    const int r = i / CW, cc = i - r * CW;
+    const long long off = base + (long long)r * p.W + cc;
+    win[r * pitch + cc] = FP32 ? ((const float*)p.src)[off] : bf2f(((const bf16_t*)p.src)[off]);
+  }
+  __syncthreads();
+  for (int i = tid; i < R * tw; i += 256) {               // horizontal pass: h[r][ox]
+    const int r = i / tw, ox = i - r * tw;
+    const int xs = p.x0[ox0 + ox] - c0, xc = p.nx[ox0 + ox];
+    const float* wxp = p.wx + (long long)(ox0 + ox) * p.taps_x;
+    const float* srow = win + r * pitch + xs;
+    float h = 0.f;
+    for (int k = 0; k < xc; ++k) h = fmaf(wxp[k], srow[k], h);
+    hbuf[r * RT_TW + ox] = h;
+  }
+  __syncthreads();
+  const int Hp = p.OH / p.ph, Wp = p.OW / p.pw;
+  for (int i = tid; i < th * tw; i += 256) {              // vertical pass + affine + patch-row store
+    const int oyl = i / tw, ox = i - oyl * tw;
+    const int oy = oy0 + oyl, oxg = ox0 + ox;
+    const int ys = p.y0[oy] - r0, yc = p.ny[oy];
+    const float* wyp = p.wy + (long long)oy * p.taps_y;
+    float acc = 0.f;
+    for (int j = 0; j < yc; ++j) acc = fmaf(wyp[j], hbuf[(ys + j) * RT_TW + ox], acc);
+    const float v = fmaf(p.a[c], acc, p.b[c]);
+    const long long tok = (((long long)n * (p.T / p.pt) + t / p.pt) * Hp + oy / p.ph) * Wp + oxg / p.pw;
+    const int col = ((c * p.pt + t % p.pt) * p.ph + oy % p.ph) * p.pw + oxg % p.pw;
+    p.out[tok * p.ldo + col] = f2bf(v);
+  }
+}
+
 // zero the K padding of the patch rows (columns Kvalid .. ldo) -- DINOv2's 3 * 14 * 14 = 588 -> 640
 __global__ __launch_bounds__(256) void zero_pad_kernel(bf16_t* out, long long rows, long long ldo, int Kvalid) {
   const int padw = (int)(ldo - Kvalid);
@@ -146,6 +204,16 @@ extern "C" int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_a
   if (a->ldo > Kvalid) {
     const long long zt = rows * (a->ldo - Kvalid);
     zero_pad_kernel<<<(unsigned)((zt + 255) / 256 < 65536 ? (zt + 255) / 256 : 65536), 256, 0, s>>>(p.out, rows, p.ldo, Kvalid);
+  }
+  // the tiled kernel when every tile's source window fits its LDS image: the window of 8 (64) output coordinates spans at most 8 (64) * scale + taps source
+  // coordinates; extreme down-scales fall back to the per-pixel kernel
+  const long long win_r = ((long long)RT_TH * a->H + a->OH - 1) / a->OH + a->taps_y + 2, win_c = ((long long)RT_TW * a->W + a->OW - 1) / a->OW + a->taps_x + 2;
+  const int tiles_x = (a->OW + RT_TW - 1) / RT_TW, tiles_y = (a->OH + RT_TH - 1) / RT_TH;
+  const long long tiles = (long long)a->N * a->T * a->C * tiles_x * tiles_y;
+  if (!a->no_tiling && win_r <= RT_RMAX && win_c <= RT_CWMAX && tiles < 0x7fffffffLL) {
+    if (a->src_fp32) resize_patch_tiled_kernel<true><<<(unsigned)tiles, 256, 0, s>>>(p, tiles_x, tiles_y);
+    else resize_patch_tiled_kernel<false><<<(unsigned)tiles, 256, 0, s>>>(p, tiles_x, tiles_y);
+    return (int)hipGetLastError();
   }
   const long long blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 256 * 64 ? blocks : 256 * 64);

@@ -106,7 +106,7 @@ _PLANS = {}
 
 
 def pixels_to_patch_rows(src: torch.Tensor, *, resize: int, crop: int, mode: str, patch: Sequence[int], frame_idx: Optional[torch.Tensor] = None,
-                         mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+                         mean=IMAGENET_MEAN, std=IMAGENET_STD, tiled: bool = True) -> torch.Tensor:
     """src [N, T, C, H, W] (bf16 or fp32, values in [-1, 1]) -> patch-embedding GEMM rows [N * T'/pt * crop/ph * crop/pw, Kpad] bf16, where
     T' = len(frame_idx) (default: all T frames) and the columns are (c, dt, dy, dx), zero-padded to a multiple of 64.
     = condition.py:378-382 / :503-507 + the im2col of the patch-embedding convolution, one launch."""
@@ -136,6 +136,7 @@ def pixels_to_patch_rows(src: torch.Tensor, *, resize: int, crop: int, mode: str
     a.N, a.T, a.C, a.H, a.W, a.OH, a.OW = N, To, C, H, W, crop, crop
     a.taps_y, a.taps_x, a.pt, a.ph, a.pw = plan.taps_y, plan.taps_x, pt, ph, pw
     a.src_fp32 = 1 if src.dtype == torch.float32 else 0
+    a.no_tiling = 0 if tiled else 1
     for c in range(C):                      # ((r + 1) / 2 - mean) / std = r * (0.5 / std) + (0.5 - mean) / std
         a.scale[c], a.shift[c] = 0.5 / std[c], (0.5 - mean[c]) / std[c]
     ops.check(ops._lib.lib().mrag_resize_patchify_bf16(ops._stream(), ops.ctypes.byref(a)), "mrag_resize_patchify_bf16")

@@ -57,6 +57,10 @@ def test_pixels_to_patch_rows_equals_aten_resize(hip, src_dtype, geom):
     err = (got[:, :K].float().cpu() - want).abs()
     # one bf16 rounding of values up to ~2.7: |err| <= 2^-8 |ref| + 1e-3 (fp32 tap arithmetic vs ATen's: ~1e-6)
     assert bool((err <= want.abs() * 2.0 ** -8 + 1e-3).all()), float(err.max())
+    # the LDS-tiled kernel (default) and the per-pixel kernel sum in the same order: bit-identical rows
+    got_px = P.pixels_to_patch_rows(src.to(DEV), resize=geom["resize"], crop=geom["crop"], mode=geom["mode"], patch=geom["patch"],
+                                    frame_idx=None if idx is None else idx.to(DEV, torch.int32), tiled=False)
+    assert torch.equal(got, got_px)
 
 
 def test_videomae_reduced_equals_transformers_golden(hip, golden_dir):

@@ -84,13 +84,20 @@ __global__ __launch_bounds__(256) void resize_patch_kernel(const PreP p) {
 // coalesced loads and converted to fp32 in LDS; the horizontal pass runs from LDS into a second LDS image h[R][64]; the vertical pass reads h.  A source pixel is
 // read from HBM / L2 once per tile instead of ~25-100 times per output pixel, and the arithmetic drops from taps_x * taps_y to taps_x * R / 8 + taps_y per output.
 // Same summation order per output as resize_patch_kernel (sum_y w_y (sum_x w_x src)), hence bit-identical results.
-constexpr int RT_TH = 8, RT_TW = 64, RT_RMAX = 48, RT_CWMAX = 320;
+constexpr int RT_TH = 8, RT_TW = 64, RT_RMAX = 48, RT_CWMAX = 320;   // bounds of the window the host accepts: (48 x 321 + 48 x 64) floats = 74 KB at most
 
 template <bool FP32>
-__global__ __launch_bounds__(256) void resize_patch_tiled_kernel(const PreP p, int tiles_x, int tiles_y) {
-  __shared__ float win[RT_RMAX * (RT_CWMAX + 1)];
-  __shared__ float hbuf[RT_RMAX * RT_TW];
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void resize_patch_tiled_kernel(const PreP p, int tiles_x, int tiles_y, int win_elems, int win_rows) {
+  extern __shared__ float rt_smem[];       // [window: R x pitch | h: R x 64 | wx: 64 x taps_x | wy: 8 x taps_y | x0, nx: 64 + 64 | y0, ny: 8 + 8]
+  float* win = rt_smem;
+  float* hbuf = win + win_elems;
+  float* swx = hbuf + win_rows * RT_TW;
+  float* swy = swx + RT_TW * p.taps_x;
+  int* sx0 = (int*)(swy + RT_TH * p.taps_y);
+  int* snx = sx0 + RT_TW;
+  int* sy0 = snx + RT_TW;
+  int* sny = sy0 + RT_TH;
+  const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;      // lane -> output column of the tile, wave -> row phase: no divisions in the passes
   int b = blockIdx.x;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y; b /= tiles_y;
@@ -99,41 +106,47 @@ __global__ __launch_bounds__(256) void resize_patch_tiled_kernel(const PreP p, i
   const int n = b / p.T;
   const int oy0 = ty * RT_TH, ox0 = tx * RT_TW;
   const int th = min(RT_TH, p.OH - oy0), tw = min(RT_TW, p.OW - ox0);
-  // source window of the tile (wave-uniform; the tables are monotone in the output coordinate, the spans need not be)
-  int r0 = p.y0[oy0], r1 = r0, c0 = p.x0[ox0], c1 = c0;
-  for (int i = 0; i < th; ++i) { const int a = p.y0[oy0 + i]; r0 = min(r0, a); r1 = max(r1, a + p.ny[oy0 + i]); }
-  for (int i = 0; i < tw; ++i) { const int a = p.x0[ox0 + i]; c0 = min(c0, a); c1 = max(c1, a + p.nx[ox0 + i]); }
+  // the tile's tap tables into LDS (the inner loops below never touch global memory for them)
+  if (tid < tw) { sx0[tid] = p.x0[ox0 + tid]; snx[tid] = p.nx[ox0 + tid]; }
+  if (tid >= 64 && tid < 64 + th) { sy0[tid - 64] = p.y0[oy0 + tid - 64]; sny[tid - 64] = p.ny[oy0 + tid - 64]; }
+  for (int i = tid; i < tw * p.taps_x; i += 256) swx[i] = p.wx[(long long)ox0 * p.taps_x + i];
+  for (int i = tid; i < th * p.taps_y; i += 256) swy[i] = p.wy[(long long)oy0 * p.taps_y + i];
+  // source window of the tile: span starts and span ends are both non-decreasing in the output coordinate (ATen's xmin / xmax), so the first and the
+  // last output coordinate of the tile bound it -- four table reads, not a scan
+  const int r0 = p.y0[oy0], r1 = p.y0[oy0 + th - 1] + p.ny[oy0 + th - 1];
+  const int c0 = p.x0[ox0], c1 = p.x0[ox0 + tw - 1] + p.nx[ox0 + tw - 1];
   const int R = r1 - r0, CW = c1 - c0, pitch = CW | 1;     // odd pitch: the column-strided reads of the horizontal pass spread over the banks
   const int ts = p.frame_idx ? p.frame_idx[t] : t;
   const long long base = (long long)n * p.s_n + (long long)ts * p.s_t + (long long)c * p.s_c + (long long)r0 * p.W + c0;
-  for (int i = tid; i < R * CW; i += 256) {
-    const int r = i / CW, cc = i - r * CW;
-    const long long off = base + (long long)r * p.W + cc;
-    win[r * pitch + cc] = FP32 ? ((const float*)p.src)[off] : bf2f(((const bf16_t*)p.src)[off]);
+  for (int r = ly; r < R; r += 4) {                        // coalesced: a wave reads 64 consecutive pixels of one source row
+    const long long rowoff = base + (long long)r * p.W;
+    for (int cc = lx; cc < CW; cc += 64) win[r * pitch + cc] = FP32 ? ((const float*)p.src)[rowoff + cc] : bf2f(((const bf16_t*)p.src)[rowoff + cc]);
   }
   __syncthreads();
-  for (int i = tid; i < R * tw; i += 256) {               // horizontal pass: h[r][ox]
-    const int r = i / tw, ox = i - r * tw;
-    const int xs = p.x0[ox0 + ox] - c0, xc = p.nx[ox0 + ox];
-    const float* wxp = p.wx + (long long)(ox0 + ox) * p.taps_x;
-    const float* srow = win + r * pitch + xs;
-    float h = 0.f;
-    for (int k = 0; k < xc; ++k) h = fmaf(wxp[k], srow[k], h);
-    hbuf[r * RT_TW + ox] = h;
+  if (lx < tw) {                                           // horizontal pass: h[r][ox], weights and spans in registers per lane
+    const int xs = sx0[lx] - c0, xc = snx[lx];
+    const float* wxp = swx + lx * p.taps_x;
+    for (int r = ly; r < R; r += 4) {
+      const float* srow = win + r * pitch + xs;
+      float h = 0.f;
+      for (int k = 0; k < xc; ++k) h = fmaf(wxp[k], srow[k], h);
+      hbuf[r * RT_TW + lx] = h;
+    }
   }
   __syncthreads();
   const int Hp = p.OH / p.ph, Wp = p.OW / p.pw;
-  for (int i = tid; i < th * tw; i += 256) {              // vertical pass + affine + patch-row store
-    const int oyl = i / tw, ox = i - oyl * tw;
-    const int oy = oy0 + oyl, oxg = ox0 + ox;
-    const int ys = p.y0[oy] - r0, yc = p.ny[oy];
-    const float* wyp = p.wy + (long long)oy * p.taps_y;
-    float acc = 0.f;
-    for (int j = 0; j < yc; ++j) acc = fmaf(wyp[j], hbuf[(ys + j) * RT_TW + ox], acc);
-    const float v = fmaf(p.a[c], acc, p.b[c]);
-    const long long tok = (((long long)n * (p.T / p.pt) + t / p.pt) * Hp + oy / p.ph) * Wp + oxg / p.pw;
-    const int col = ((c * p.pt + t % p.pt) * p.ph + oy % p.ph) * p.pw + oxg % p.pw;
-    p.out[tok * p.ldo + col] = f2bf(v);
+  if (lx < tw) {
+    for (int oyl = ly; oyl < th; oyl += 4) {               // vertical pass + affine + patch-row store
+      const int oy = oy0 + oyl, oxg = ox0 + lx;
+      const int ys = sy0[oyl] - r0, yc = sny[oyl];
+      const float* wyp = swy + oyl * p.taps_y;
+      float acc = 0.f;
+      for (int j = 0; j < yc; ++j) acc = fmaf(wyp[j], hbuf[(ys + j) * RT_TW + lx], acc);
+      const float v = fmaf(p.a[c], acc, p.b[c]);
+      const long long tok = (((long long)n * (p.T / p.pt) + t / p.pt) * Hp + oy / p.ph) * Wp + oxg / p.pw;
+      const int col = ((c * p.pt + t % p.pt) * p.ph + oy % p.ph) * p.pw + oxg % p.pw;
+      p.out[tok * p.ldo + col] = f2bf(v);
+    }
   }
 }
 
@@ -211,8 +224,10 @@ extern "C" int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_a
   const int tiles_x = (a->OW + RT_TW - 1) / RT_TW, tiles_y = (a->OH + RT_TH - 1) / RT_TH;
   const long long tiles = (long long)a->N * a->T * a->C * tiles_x * tiles_y;
   if (!a->no_tiling && win_r <= RT_RMAX && win_c <= RT_CWMAX && tiles < 0x7fffffffLL) {
-    if (a->src_fp32) resize_patch_tiled_kernel<true><<<(unsigned)tiles, 256, 0, s>>>(p, tiles_x, tiles_y);
-    else resize_patch_tiled_kernel<false><<<(unsigned)tiles, 256, 0, s>>>(p, tiles_x, tiles_y);
+    const int win_elems = (int)(win_r * (win_c | 1));
+    const size_t lds = (size_t)(win_elems + win_r * RT_TW + RT_TW * a->taps_x + RT_TH * a->taps_y + 2 * RT_TW + 2 * RT_TH) * sizeof(float);
+    if (a->src_fp32) resize_patch_tiled_kernel<true><<<(unsigned)tiles, 256, lds, s>>>(p, tiles_x, tiles_y, win_elems, (int)win_r);
+    else resize_patch_tiled_kernel<false><<<(unsigned)tiles, 256, lds, s>>>(p, tiles_x, tiles_y, win_elems, (int)win_r);
     return (int)hipGetLastError();
   }
   const long long blocks = (total + 255) / 256;

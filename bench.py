@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
+    ap.add_argument("--cooldown", type=float, default=0.0, help="developer knob: idle seconds between the 50-step clip and the secondary workloads (thermal state check)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (SVD / DynamiCrafter UNet CFG step, retrieval, CAMA), which are measured "
                     "after the timed region at N = 1 (~30 s) and reported under `secondary_workloads`; for profiling runs that should hold only the headline launches")
     ap.add_argument("--shard", choices=["clips", "sequence", "cfg"], default="clips",
@@ -246,6 +247,8 @@ def main():
     # the other BASELINE.json configs, measured after the timed region and reported beside the headline (N = 1 only; ~20 s)
     secondary = None
     if world == 1 and not args.no_secondary:
+        if args.cooldown > 0:
+            time.sleep(args.cooldown)
         import contextlib
         import importlib.util
         import io

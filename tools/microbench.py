@@ -22,15 +22,26 @@ ops.TUNING["no_qkv_fuse"] = bool(_E.get("MRAG_NO_QKV_FUSE"))
 
 
 def timeit(fn, iters=10, warm=2):
+    """HIP-event time per call.  The cyclic garbage collector is off inside the timed region, as in the standard library's `timeit`: every launch allocates a
+    ctypes argument struct, and in a process that also holds a 5.6 B-parameter model (bench.py's secondary workloads) a generation-2 collection stalls the host for
+    milliseconds -- the launch-heavy UNet steps then measure the collector, not the GPU (SVD step: 125 ms standalone, 141-146 ms inside bench.py before this)."""
+    import gc
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        if was:
+            gc.enable()
     return e0.elapsed_time(e1) / iters * 1e-3
 
 

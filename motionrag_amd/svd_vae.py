@@ -1,0 +1,258 @@
+"""SVD's VAE on the HIP kernels (the temporal-decoder VAE): third-party diffusers `AutoencoderKLTemporalDecoder`, state-dict compatible
+(`encoder.down_blocks.N.resnets.M`, `encoder.mid_block.attentions.0.{group_norm,to_q,to_k,to_v,to_out.0}`, `quant_conv`, `decoder.mid_block / up_blocks.N.resnets.M.
+{spatial_res_block, temporal_res_block, time_mixer.mix_factor}`, `decoder.time_conv_out`, ...).  Call sites it stands behind: src/projects/svd/pipelines/pipeline.py
+(`self.vae.encode(image).latent_dist.mode()`; `decode_latents`: `vae.decode(latents / scaling_factor, num_frames=n).sample` per `decode_chunk_size` frames),
+src/projects/svd/module.py:38-47.  Oracle: oracle/svd_vae_ref.py -- **parity unpinned** (diffusers is not in this image).
+
+The spatial half is the LVDM KL-VAE's arithmetic under other names (ResNet blocks, single-head 512-d attention as GEMM + row softmax + GEMM, the asymmetric-padding
+stride-2 convolution: motionrag_amd/dynamicrafter_vae.py); the temporal half reuses the (3, 1, 1) implicit-GEMM convolution and the blend kernel of the SVD UNet."""
+from typing import Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+from .dynamicrafter import _CACHE, _lin_w, conv3x3, conv_t3
+from .dynamicrafter_vae import DiagonalGaussianDistribution, _b, _conv_small_cin
+from .svd_unet import _sigmoid_scalar
+
+
+def _gn(x: torch.Tensor, gn: nn.GroupNorm, silu: bool, frames_per_sample: int = 1) -> torch.Tensor:
+    """x [N, H, W, C]; statistics per image, or per clip over (t, h, w) when frames_per_sample > 1 (the temporal blocks' 5-D GroupNorm)"""
+    N, H, W, C = x.shape
+    f = frames_per_sample
+    return ops.groupnorm(x.view(N // f, f * H * W, C), _b(gn.weight), _b(gn.bias), gn.num_groups, gn.eps, silu=silu).view(N, H, W, C)
+
+
+class ResnetBlock2D(nn.Module):
+    """diffusers ResnetBlock2D(temb_channels=None, groups=32, eps=1e-6); a 1x1 `conv_shortcut` when the width changes"""
+
+    def __init__(self, cin: int, cout: int, eps: float = 1e-6):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(32, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = conv3x3(_gn(x, self.norm1, True), self.conv1)
+        h = _gn(h, self.norm2, True)
+        if self.conv_shortcut is not None:
+            x = ops.linear(x, _b(_lin_w(self.conv_shortcut)), _b(self.conv_shortcut.bias))
+        return conv3x3(h, self.conv2, resid=x)
+
+
+class TemporalResnetBlock(nn.Module):
+    """diffusers TemporalResnetBlock(temb_channels=None, eps=1e-5), in == out"""
+
+    def __init__(self, ch: int, eps: float = 1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, ch, eps=eps)
+        self.conv1 = nn.Conv3d(ch, ch, (3, 1, 1), padding=(1, 0, 0))
+        self.norm2 = nn.GroupNorm(32, ch, eps=eps)
+        self.conv2 = nn.Conv3d(ch, ch, (3, 1, 1), padding=(1, 0, 0))
+
+    def forward(self, x: torch.Tensor, num_frames: int) -> torch.Tensor:
+        N, H, W, C = x.shape
+        b = N // num_frames
+        h = conv_t3(_gn(x, self.norm1, True, num_frames).view(N, H * W, C), self.conv1, b, num_frames)
+        h = _gn(h.view(N, H, W, C), self.norm2, True, num_frames).view(N, H * W, C)
+        return conv_t3(h, self.conv2, b, num_frames, resid=x.view(N, H * W, C)).view(N, H, W, C)
+
+
+class _Mixer(nn.Module):
+    def __init__(self, alpha: float = 0.0):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor([alpha]))
+
+
+class SpatioTemporalResBlock(nn.Module):
+    """merge_strategy 'learned', switch_spatial_to_temporal_mix=True: out = (1 - sigmoid(mix)) * spatial + sigmoid(mix) * temporal"""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.spatial_res_block = ResnetBlock2D(cin, cout, 1e-6)
+        self.temporal_res_block = TemporalResnetBlock(cout, 1e-5)
+        self.time_mixer = _Mixer(0.0)
+
+    def forward(self, x: torch.Tensor, num_frames: int) -> torch.Tensor:
+        s = self.spatial_res_block(x)
+        t = self.temporal_res_block(s, num_frames)
+        a = 1.0 - _sigmoid_scalar(self.time_mixer.mix_factor)
+        return ops.axpby(s, t, a, 1.0 - a)
+
+
+class Attention(nn.Module):
+    """diffusers Attention(heads=1, dim_head=C, norm_num_groups=32, eps=1e-6, bias=True, residual_connection=True): head_dim 512 -> GEMM, row softmax, GEMM"""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = (nn.Linear(ch, ch) for _ in range(3))
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Dropout(0.0)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        N, H, W, C = x.shape
+        S = H * W
+        h = _gn(x, self.group_norm, False).view(N, S, C)
+        q = ops.linear(h, _b(self.to_q.weight), _b(self.to_q.bias))
+        k = ops.linear(h, _b(self.to_k.weight), _b(self.to_k.bias))
+        a = torch.empty(N, S, C, dtype=torch.bfloat16, device=x.device)
+        scores = torch.empty(S, S, dtype=torch.bfloat16, device=x.device)
+        for n in range(N):
+            ops.linear(q[n], k[n], out=scores)
+            ops.softmax_rows(scores, scale=float(C) ** -0.5, out=scores)
+            vt = ops.linear(_b(self.to_v.weight), h[n])                                   # V^T = Wv h^T: no transpose pass; the bias rides below (rows of P sum to 1)
+            ops.linear(scores, vt, _b(self.to_v.bias), out=a[n])
+        return ops.linear(a, _b(self.to_out[0].weight), _b(self.to_out[0].bias), epilogue=ops.EPI_RESID, resid=x.view(N, S, C)).view(N, H, W, C)
+
+
+class _Sampler(nn.Module):
+    def __init__(self, ch: int, down: bool):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2 if down else 1, padding=0 if down else 1)
+
+
+class _Block(nn.Module):
+    pass
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, block_out_channels: Sequence[int], layers_per_block: int):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, block_out_channels[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        ch = block_out_channels[0]
+        for i, co in enumerate(block_out_channels):
+            blk = _Block()
+            blk.resnets = nn.ModuleList(ResnetBlock2D(ch if j == 0 else co, co) for j in range(layers_per_block))
+            if i != len(block_out_channels) - 1:
+                blk.downsamplers = nn.ModuleList([_Sampler(co, True)])
+            self.down_blocks.append(blk)
+            ch = co
+        self.mid_block = _Block()
+        self.mid_block.resnets = nn.ModuleList([ResnetBlock2D(ch, ch), ResnetBlock2D(ch, ch)])
+        self.mid_block.attentions = nn.ModuleList([Attention(ch)])
+        self.conv_norm_out = nn.GroupNorm(32, ch, eps=1e-6)
+        self.conv_out = nn.Conv2d(ch, 2 * out_channels, 3, padding=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = _conv_small_cin(x, self.conv_in, "svdvae_in")
+        for blk in self.down_blocks:
+            for r in blk.resnets:
+                h = r(h)
+            if hasattr(blk, "downsamplers"):
+                conv = blk.downsamplers[0].conv
+                C = h.shape[-1]
+                wk = _CACHE.get(("c3", id(conv)), conv.weight, lambda: _b(conv.weight).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], 9 * C).contiguous())
+                h = ops.conv_implicit(h.contiguous(), wk, _b(conv.bias), ops.CONV_3X3, stride=2, asym_pad=True)          # F.pad(x, (0, 1, 0, 1)) + stride-2 conv
+        h = self.mid_block.resnets[0](h)
+        h = self.mid_block.attentions[0](h)
+        h = self.mid_block.resnets[1](h)
+        return conv3x3(_gn(h, self.conv_norm_out, True), self.conv_out)
+
+
+class TemporalDecoder(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, block_out_channels: Sequence[int], layers_per_block: int):
+        super().__init__()
+        top = block_out_channels[-1]
+        self.layers_per_block, self.out_channels = layers_per_block, out_channels
+        self.conv_in = nn.Conv2d(in_channels, top, 3, padding=1)
+        self.mid_block = _Block()
+        self.mid_block.resnets = nn.ModuleList(SpatioTemporalResBlock(top, top) for _ in range(layers_per_block))
+        self.mid_block.attentions = nn.ModuleList(Attention(top) for _ in range(layers_per_block - 1))
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(block_out_channels))
+        ch = rev[0]
+        for i, co in enumerate(rev):
+            blk = _Block()
+            blk.resnets = nn.ModuleList(SpatioTemporalResBlock(ch if j == 0 else co, co) for j in range(layers_per_block + 1))
+            if i != len(rev) - 1:
+                blk.upsamplers = nn.ModuleList([_Sampler(co, False)])
+            self.up_blocks.append(blk)
+            ch = co
+        self.conv_norm_out = nn.GroupNorm(32, ch, eps=1e-6)
+        self.conv_out = nn.Conv2d(ch, out_channels, 3, padding=1)
+        self.time_conv_out = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
+
+    def forward(self, z: torch.Tensor, num_frames: int) -> torch.Tensor:
+        """z [(b f), h, w, 4] channels-last -> [(b f), 8 h, 8 w, 3]"""
+        h = _conv_small_cin(z, self.conv_in, "svdvae_dec_in")
+        h = self.mid_block.resnets[0](h, num_frames)
+        for attn, r in zip(self.mid_block.attentions, self.mid_block.resnets[1:]):
+            h = r(attn(h), num_frames)
+        for blk in self.up_blocks:
+            for r in blk.resnets:
+                h = r(h, num_frames)
+            if hasattr(blk, "upsamplers"):
+                h = conv3x3(h, blk.upsamplers[0].conv, upsample=True)
+        h = _gn(h, self.conv_norm_out, True)
+        co, conv, tconv = self.out_channels, self.conv_out, self.time_conv_out
+
+        def build_out():                                                      # 3 output channels padded to 8: the temporal row gather moves 16-byte granules
+            cin = conv.weight.shape[1]
+            w = torch.nn.functional.pad(_b(conv.weight).permute(0, 2, 3, 1).reshape(co, 9 * cin), (0, 0, 0, 8 - co))
+            return w.contiguous(), torch.nn.functional.pad(_b(conv.bias), (0, 8 - co)).contiguous()
+        wk, bk = _CACHE.get(("svdvae_out", id(conv)), (conv.weight, conv.bias), build_out)
+        y = ops.conv_implicit(h.contiguous(), wk, bk, ops.CONV_3X3)          # [(b f), H, W, 8]
+        N, H, W, _ = y.shape
+
+        def build_t():                                                        # Conv3d (3, 1, 1) over frames on the padded channels: [4, (kt, c8)] -> K padded to 64
+            w = torch.nn.functional.pad(_b(tconv.weight)[:, :, :, 0, 0], (0, 0, 0, 8 - co)).permute(0, 2, 1).reshape(co, 24)
+            w = torch.nn.functional.pad(w, (0, 64 - 24, 0, 4 - co))
+            return w.contiguous(), torch.nn.functional.pad(_b(tconv.bias), (0, 4 - co)).contiguous()
+        wt, bt = _CACHE.get(("svdvae_tout", id(tconv)), (tconv.weight, tconv.bias), build_t)
+        rows = ops.unfold_t3(y.view(N, H * W, 8), N // num_frames, num_frames)
+        return ops.linear(rows, wt, bt).view(N, H, W, 4)[..., :co]
+
+
+class _EncodeOut:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
+class _DecodeOut:
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class _Config:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class AutoencoderKLTemporalDecoder(nn.Module):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, block_out_channels: Sequence[int] = (128, 256, 512, 512), layers_per_block: int = 2,
+                 latent_channels: int = 4, scaling_factor: float = 0.18215, force_upcast: bool = True, **_unused):
+        super().__init__()
+        self.encoder = Encoder(in_channels, latent_channels, block_out_channels, layers_per_block)
+        self.decoder = TemporalDecoder(latent_channels, out_channels, block_out_channels, layers_per_block)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.config = _Config(scaling_factor=scaling_factor, force_upcast=force_upcast, latent_channels=latent_channels, block_out_channels=tuple(block_out_channels))
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x [N, 3, H, W] in [-1, 1] -> `.latent_dist` (mode() / sample())"""
+        if not x.is_cuda:
+            raise ops.HipOnly("AutoencoderKLTemporalDecoder.encode: GPU tensors only")
+        h = self.encoder(x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
+        moments = ops.linear(h, _b(_lin_w(self.quant_conv)), _b(self.quant_conv.bias)).permute(0, 3, 1, 2)
+        return _EncodeOut(DiagonalGaussianDistribution(moments))
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, num_frames: int, return_dict: bool = True):
+        """z [(b f), 4, h, w] -> `.sample` [(b f), 3, 8 h, 8 w]"""
+        if not z.is_cuda:
+            raise ops.HipOnly("AutoencoderKLTemporalDecoder.decode: GPU tensors only")
+        if z.shape[0] % num_frames:
+            raise ValueError("the batch must hold whole clips of num_frames frames")
+        y = self.decoder(z.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous(), num_frames)
+        return _DecodeOut(y.permute(0, 3, 1, 2))

@@ -264,6 +264,7 @@ def main():
                          "retrieval_top12_768d": mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1)))}
             del dcnet
             secondary["dynamicrafter_kl_vae_decode_16x576x1024"] = mb.vae()            # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
+            secondary["svd_temporal_vae_14x576x1024"] = mb.svd_vae()                      # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
             secondary["t5_xxl_prompt_encoder_2x226"] = mb.t5()                            # SURVEY 8f rank 4 (CogVideoX's text encoder)
             secondary["rag_side_encoders_plus_cama"] = mb.encoders()             # VideoMAE-B + DINOv2-L + CAMA from raw pixels
 

@@ -198,9 +198,9 @@ class TemporalDecoder(nn.Module):
         y = ops.conv_implicit(h.contiguous(), wk, bk, ops.CONV_3X3)          # [(b f), H, W, 8]
         N, H, W, _ = y.shape
 
-        def build_t():                                                        # Conv3d (3, 1, 1) over frames on the padded channels: [4, (kt, c8)] -> K padded to 64
+        def build_t():                                                        # Conv3d (3, 1, 1) over frames on the padded channels: [4, (kt, c8)] (ops.linear pads K = 24 to a K-tile)
             w = torch.nn.functional.pad(_b(tconv.weight)[:, :, :, 0, 0], (0, 0, 0, 8 - co)).permute(0, 2, 1).reshape(co, 24)
-            w = torch.nn.functional.pad(w, (0, 64 - 24, 0, 4 - co))
+            w = torch.nn.functional.pad(w, (0, 0, 0, 4 - co))
             return w.contiguous(), torch.nn.functional.pad(_b(tconv.bias), (0, 4 - co)).contiguous()
         wt, bt = _CACHE.get(("svdvae_tout", id(tconv)), (tconv.weight, tconv.bias), build_t)
         rows = ops.unfold_t3(y.view(N, H * W, 8), N // num_frames, num_frames)

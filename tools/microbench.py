@@ -292,6 +292,24 @@ def t5():
     return {"ms": round(dt * 1e3, 2), "weight_GB": round(nbytes / 1e9, 2), "weight_stream_TBps": round(nbytes / dt / 1e12, 2)}
 
 
+def svd_vae(frames=14, h=72, w=128):
+    """SVD's temporal-decoder VAE: decode one clip's latents [14, 4, 72, 128] -> [14, 3, 576, 1024] in one chunk (decode_chunk_size = num_frames), and
+    encode the conditioning frame; the shipped configuration (97.7 M parameters), random-init weights"""
+    from motionrag_amd import svd_vae as V
+    torch.manual_seed(0)
+    m = V.AutoencoderKLTemporalDecoder().to(DEV, torch.bfloat16)
+    z = torch.randn(frames, 4, h, w, device=DEV).to(torch.bfloat16)
+    out = {}
+    fl = count_flops(lambda: out.setdefault("y", m.decode(z, num_frames=frames).sample))
+    assert out["y"].shape == (frames, 3, 8 * h, 8 * w) and torch.isfinite(out["y"].float()).all()
+    dt = timeit(lambda: m.decode(z, num_frames=frames), iters=3, warm=1)
+    img = (torch.rand(1, 3, 8 * h, 8 * w, device=DEV) * 2 - 1).to(torch.bfloat16)
+    de = timeit(lambda: m.encode(img), iters=5, warm=1)
+    print(f"SVD temporal-decoder VAE: decode {frames}x{8*h}x{8*w} {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP -> {frames/dt:.0f} frames/s; encode one {8*h}x{8*w} frame {de*1e3:.2f} ms")
+    return {"decode_ms_per_clip": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(frames / dt),
+            "encode_frame_ms": round(de * 1e3, 2)}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

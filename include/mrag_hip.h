@@ -266,6 +266,12 @@ int mrag_cfg_euler_step_bf16(void* stream, const void* v_pred, void* latents, in
  *   out[b, n] = (sum_k w[b, k] * x[b, k, n]) / div      fp32 weights / accumulation in k order, one rounding to bf16
  * x [B, K, n] bf16, w [B, K] fp32 on the device or NULL (all ones: mean = sum / K with div = K), n % 8 == 0.            */
 int mrag_weighted_sum_bf16(void* stream, const void* x, const float* w, void* out, int32_t B, int32_t K, int64_t n, float div);
+/* softmax(scale * Q K^T) V for SHORT sequences at head dims other than 64 (32, 80, 96, 128): plain fp32 FMAs, K and V of one (batch, head) resident in LDS
+ * (Skv * head_dim * 4 bytes <= 128 KB), one workgroup per (batch, head).  Same argument struct as mrag_attn_fwd_bf16 (strides in elements; no mask / bias /
+ * resid / kv_batch_div / q_prescaled: MRAG_ENOTSUP).  First user: the CLIP-ViT-H image encoder of the SVD path (257 tokens, 16 heads of 80; transformers
+ * CLIPVisionModelWithProjection behind StableVideoDiffusionPipeline._encode_image, src/projects/svd/pipelines/pipeline.py:113-119) -- once per clip.     */
+int mrag_attn_small_bf16(void* stream, const mrag_attn_args* args, int32_t head_dim);
+
 /* ------------------------------------------------------------------------ */
 /* CAMA building blocks as native launch sequences (`resampler_fwd`, `cama_encoder_fwd`).  No kernel of their own: they issue the launches
  * of the entry points above in the order motionrag_amd/cama.py does (bit-identical results), from C++, with caller-provided scratch.                */

@@ -16,7 +16,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
 ABI_VERSION = 4
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
@@ -30,7 +30,7 @@ SYMBOLS = [
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
-    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8",
+    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8", "mrag_attn_small_bf16",
     "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
 ]
 
@@ -199,6 +199,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_attn_fp8_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
     L.mrag_attn_fp8_workspace_bytes.restype = c_int64
     L.mrag_attn_fwd_fp8.argtypes = [c_void_p, POINTER(AttnArgs)]
+    L.mrag_attn_small_bf16.argtypes = [c_void_p, POINTER(AttnArgs), c_int32]
     L.mrag_comm_unique_id.argtypes = [c_void_p]
     L.mrag_comm_init.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_void_p)]
     L.mrag_comm_destroy.argtypes = [c_void_p]

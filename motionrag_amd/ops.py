@@ -220,6 +220,28 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, out: Optiona
 KERNEL_TIMING = None
 
 
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v for short sequences at head dims 32 / 80 / 96 / 128 (mrag_attn_small_bf16): q [B, Sq, H, D], k / v [B, Skv, H, D] with a contiguous
+    head dim (views of a fused QKV buffer are fine), Skv * D <= 32 768; out [B, Sq, H * D]"""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _dev(t, name=n)
+        if t.dim() != 4 or t.stride(-1) != 1:
+            raise ValueError(f"{n}: expected [B, S, H, D] with a contiguous head dim")
+    B, Sq, H, D = q.shape
+    if out is None:
+        out = torch.empty(B, Sq, H * D, dtype=torch.bfloat16, device=q.device)
+    a = AttnArgs()
+    a.Q, a.K, a.V, a.O = _p(q), _p(k), _p(v), _p(out)
+    a.q_sb, a.q_ss, a.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    a.k_sb, a.k_ss, a.k_sh = k.stride(0), k.stride(1), k.stride(2)
+    a.v_sb, a.v_ss, a.v_sh = v.stride(0), v.stride(1), v.stride(2)
+    a.o_sb, a.o_ss = out.stride(0), out.stride(1)
+    a.B, a.H, a.Sq, a.Skv, a.kv_batch_div = B, H, Sq, k.shape[1], 1
+    a.scale, a.out_scale = (D ** -0.5) if scale is None else scale, 1.0
+    check(_lib.lib().mrag_attn_small_bf16(_stream(), ctypes.byref(a), D), "mrag_attn_small_bf16")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float, *,
               out: Optional[torch.Tensor] = None, shift0=None, scale0=None, shift1=None, scale1=None,
               rows_per_batch: int = 0, split: int = 0, mod_stride: int = 0, out_batched: Optional[torch.Tensor] = None, rms: bool = False) -> torch.Tensor:

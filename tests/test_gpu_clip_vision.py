@@ -1,0 +1,68 @@
+"""The short-sequence attention kernel for head dims other than 64 (mrag_attn_small_bf16) and the CLIP vision tower on it, through the C ABI: against fp32 attention, the
+REAL transformers.CLIPVisionModelWithProjection outputs (tests/golden/clip_vision.npz), and the CLIP-ViT-H width against the fp32 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_vision_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(got, want):
+    g, w = got.float().cpu(), want.float().cpu()
+    assert g.shape == w.shape and torch.isfinite(g).all()
+    return ((g - w).norm() / w.norm()).item()
+
+
+@pytest.mark.parametrize("B,S,H,D", [(2, 257, 16, 80), (3, 17, 2, 80), (1, 300, 3, 128), (2, 50, 4, 32), (1, 257, 5, 96)])
+def test_attention_small(hip, B, S, H, D):
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    qkv = (torch.randn(B, S, 3, H, D, generator=g) * 0.7).to(torch.bfloat16)
+    q, k, v = (qkv[:, :, i].float() for i in range(3))
+    want = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k) * D ** -0.5, dim=-1)
+    want = torch.einsum("bhqk,bkhd->bqhd", want, v).reshape(B, S, H * D)
+    dq = qkv.to(DEV)
+    got = ops.attention_small(dq[:, :, 0], dq[:, :, 1], dq[:, :, 2])               # strided views of the fused buffer
+    assert rel(got, want) <= 6e-3
+    from motionrag_amd._lib import HipError
+    if D == 80:
+        with pytest.raises(HipError):                                              # K and V of one head must fit the LDS image
+            big = torch.zeros(1, 900, 3, 1, 80, dtype=torch.bfloat16, device=DEV)
+            ops.attention_small(big[:, :, 0], big[:, :, 1], big[:, :, 2])
+
+
+def test_clip_vision_equals_transformers_golden(hip, golden_dir):
+    from motionrag_amd import clip_vision as C
+    G = np.load(os.path.join(golden_dir, "clip_vision.npz"))
+    d, heads, layers, ff, img, patch, proj = (int(v) for v in G["cfg"])
+    m = C.CLIPVisionModelWithProjection(hidden_size=d, intermediate_size=ff, num_hidden_layers=layers, num_attention_heads=heads, image_size=img, patch_size=patch, projection_dim=proj)
+    m.load_state_dict({k[3:]: torch.from_numpy(G[k].view(np.int16).copy()).view(torch.bfloat16).float() for k in G.files if k.startswith("sd.")}, strict=True)
+    out = m.to(DEV, torch.bfloat16)(torch.from_numpy(G["pixel_values"]).to(DEV))
+    assert out.image_embeds.shape == (3, proj)
+    assert rel(out.last_hidden_state, torch.from_numpy(G["last_hidden_state"])) <= 2e-2      # vs the REAL transformers class
+    assert rel(out.image_embeds, torch.from_numpy(G["image_embeds"])) <= 2e-2
+
+
+def test_clip_vit_h_width_vs_oracle(hip):
+    """1280 wide, 16 heads of 80, 257 tokens at 224 x 224 (CLIP-ViT-H/14), 3 of its 32 layers"""
+    from motionrag_amd import clip_vision as C
+    torch.manual_seed(17)
+    m = C.CLIPVisionModelWithProjection(num_hidden_layers=3)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p)) if "class_embedding" not in n else p.normal_(0.0, 0.02)
+            elif "position_embedding" in n:
+                p.normal_(0.0, 0.02)
+            p.copy_(p.to(torch.bfloat16).float())
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    pix = torch.randn(2, 3, 224, 224)
+    want_last, want_emb = R.clip_vision(sd, 16, pix.to(torch.bfloat16).float())
+    out = m.to(DEV, torch.bfloat16)(pix.to(DEV, torch.bfloat16))
+    assert out.last_hidden_state.shape == (2, 257, 1280) and out.image_embeds.shape == (2, 1024)
+    assert rel(out.last_hidden_state, want_last) <= 2e-2 and rel(out.image_embeds, want_emb) <= 2e-2

@@ -18,7 +18,7 @@ def rel(got, want):
     return ((g - w).norm() / w.norm()).item()
 
 
-@pytest.mark.parametrize("B,S,H,D", [(2, 257, 16, 80), (3, 17, 2, 80), (1, 300, 3, 128), (2, 50, 4, 32), (1, 257, 5, 96)])
+@pytest.mark.parametrize("B,S,H,D", [(2, 257, 16, 80), (3, 17, 2, 80), (1, 250, 3, 128), (2, 50, 4, 32), (1, 257, 5, 96)])
 def test_attention_small(hip, B, S, H, D):
     from motionrag_amd import ops
     g = torch.Generator().manual_seed(S + D)

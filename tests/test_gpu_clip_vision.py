@@ -66,3 +66,35 @@ def test_clip_vit_h_width_vs_oracle(hip):
     out = m.to(DEV, torch.bfloat16)(pix.to(DEV, torch.bfloat16))
     assert out.last_hidden_state.shape == (2, 257, 1280) and out.image_embeds.shape == (2, 1024)
     assert rel(out.last_hidden_state, want_last) <= 2e-2 and rel(out.image_embeds, want_emb) <= 2e-2
+
+
+def _hf_to_openclip_visual(sd, layers):
+    out = {"conv1.weight": sd["vision_model.embeddings.patch_embedding.weight"], "class_embedding": sd["vision_model.embeddings.class_embedding"],
+           "positional_embedding": sd["vision_model.embeddings.position_embedding.weight"], "ln_pre.weight": sd["vision_model.pre_layrnorm.weight"],
+           "ln_pre.bias": sd["vision_model.pre_layrnorm.bias"], "ln_post.weight": sd["vision_model.post_layernorm.weight"], "ln_post.bias": sd["vision_model.post_layernorm.bias"],
+           "proj": sd["visual_projection.weight"].t().contiguous()}
+    for i in range(layers):
+        h, o = f"vision_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        out[o + "attn.in_proj_weight"] = torch.cat([sd[h + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        out[o + "attn.in_proj_bias"] = torch.cat([sd[h + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        for a, b in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            out[o + a + ".weight"], out[o + a + ".bias"] = sd[h + b + ".weight"], sd[h + b + ".bias"]
+    return out
+
+
+def test_openclip_visual_tower_under_open_clip_names(hip, golden_dir):
+    """DynamiCrafter's FrozenOpenCLIPImageEmbedderV2 (lvdm/modules/encoders/condition.py:302-380) returns every token after the last block: with the REAL
+    transformers weights renamed to open_clip's keys, that is the golden's `last_hidden_state`"""
+    from motionrag_amd import clip_vision as C
+    G = np.load(os.path.join(golden_dir, "clip_vision.npz"))
+    d, heads, layers, ff, img, patch, proj = (int(v) for v in G["cfg"])
+    sd = {k[3:]: torch.from_numpy(G[k].view(np.int16).copy()).view(torch.bfloat16).float() for k in G.files if k.startswith("sd.")}
+    v = C.OpenCLIPVisual(width=d, layers=layers, heads=heads, mlp_ratio=ff / d, image_size=img, patch_size=patch, output_dim=proj)
+    v.load_state_dict(_hf_to_openclip_visual(sd, layers), strict=True)
+    emb = C.FrozenOpenCLIPImageEmbedderV2(v.to(DEV, torch.bfloat16), preprocess=lambda x: x)          # the fixture's pixel_values are already normalised
+    z = emb(torch.from_numpy(G["pixel_values"]).to(DEV))
+    assert z.shape == (3, (img // patch) ** 2 + 1, d) and rel(z, torch.from_numpy(G["last_hidden_state"])) <= 2e-2
+    # built-in preprocess (torch-style antialiased bicubic to 224 + CLIP normalisation, fused into the pixel kernel): runs at the shipped geometry
+    big = C.FrozenOpenCLIPImageEmbedderV2(width=160, layers=1, heads=2, mlp_ratio=2.0).to(DEV, torch.bfloat16)
+    t = big(torch.rand(2, 3, 320, 512, device=DEV) * 2 - 1)
+    assert t.shape == (2, 257, 160) and torch.isfinite(t.float()).all()

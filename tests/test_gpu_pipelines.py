@@ -274,3 +274,50 @@ def test_svd_ct_pipeline_all_native_components(hip):
     assert torch.isfinite(frames.float()).all() and torch.equal(frames, frames2)
     by_hand = vae.decode((lat.float().to(DEV) / vae.config.scaling_factor).flatten(0, 1), num_frames=Fr).sample
     assert by_hand.numel() == frames.numel()
+
+
+def test_dynamicrafter_pipeline_all_native_components(hip, golden_dir):
+    """DynamiCrafterPipelineRef / image_guided_synthesis with EVERY model on the HIP path: the UNet + DDIM sampler, the KL-VAE (`dynamicrafter_vae.FirstStage`),
+    the OpenCLIP text tower (`openclip_text`) as `get_learned_conditioning`, the OpenCLIP image tower with head_dim 80 (`clip_vision`) + the image Resampler, and CAMA's
+    condition transformer stub.  Composition check of the duck-typed hand-offs: shapes, finiteness, determinism under fixed noise."""
+    import json
+    import types
+    from motionrag_amd import cama, clip_vision, dynamicrafter as dc, dynamicrafter_vae as V, openclip_text as T
+    from motionrag_amd.dynamicrafter_pipeline import DynamiCrafterPipelineRef
+    from oracle import stubs
+    from test_oracle_golden import dc_unet_fixture
+    _, sd, _, _, _ = dc_unet_fixture(golden_dir)
+    unet = dc.UNetModel(in_channels=8, out_channels=4, model_channels=64, attention_resolutions=(1, 2), num_res_blocks=1, channel_mult=(1, 2),
+                        num_head_channels=64, transformer_depth=1, context_dim=64, use_linear=True, temporal_conv=True, temporal_attention=True,
+                        temporal_self_att_only=True, use_relative_position=False, temporal_length=4, addition_attention=True,
+                        image_cross_attention=True, action_cross_attention=True, default_fs=10, fs_condition=True)
+    unet.load_state_dict(sd, strict=True)
+    unet = unet.to(DEV, torch.bfloat16)
+    torch.manual_seed(77)
+    vae = V.AutoencoderKL(dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 1, 2, 2], num_res_blocks=1, attn_resolutions=[],
+                               dropout=0.0), embed_dim=4).to(DEV, torch.bfloat16)
+    fs = V.FirstStage(vae, scale_factor=0.18215)
+    text_model = T.OpenCLIPTextModel(vocab_size=100, width=64, heads=1, layers=2, context_length=7, embed_dim=64).to(DEV, torch.bfloat16)
+    tokens = {"": torch.zeros(1, 7, dtype=torch.long), "a prompt": torch.tensor([[98, 5, 6, 7, 99, 0, 0]])}
+    text = T.FrozenOpenCLIPEmbedder(text_model, tokenizer=lambda ts: torch.cat([tokens[t] for t in ts]), layer="penultimate")
+    visual = clip_vision.OpenCLIPVisual(width=160, layers=1, heads=2, mlp_ratio=2.0, image_size=28, patch_size=14, output_dim=32)
+    embedder = clip_vision.FrozenOpenCLIPImageEmbedderV2(visual.to(DEV, torch.bfloat16),
+                                                         preprocess=lambda x: torch.nn.functional.interpolate(x.float(), size=(28, 28), mode="bilinear").to(torch.bfloat16))
+    proj = cama.Resampler(dim=64, depth=1, dim_head=64, heads=2, num_queries=3, embedding_dim=160, output_dim=64, video_length=4).to(DEV, torch.bfloat16)
+    model = types.SimpleNamespace(
+        model=types.SimpleNamespace(conditioning_key="hybrid", diffusion_model=unet), uncond_type="empty_seq", action_embedder=None,
+        embedder=embedder, image_proj_model=proj, condition_transformer=stubs.ConditionTransformerStub(dim=64).to(DEV), get_learned_conditioning=text,
+        encode_first_stage=fs.encode_first_stage, decode_first_stage=fs.decode_first_stage)
+    pipe = DynamiCrafterPipelineRef(model)
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    ref_videos = torch.randn(1, 2, 4, 3, 16, 16, generator=g)
+    x_T = torch.randn(1, 4, 4, 8, 8, generator=g)
+    noises = [torch.randn(1, 4, 4, 8, 8, generator=g) for _ in range(5)]
+
+    def run():
+        torch.manual_seed(5)                          # the posterior sample of the conditioning frame draws from the global CPU generator, like the reference
+        return pipe(image=image.to(DEV), positive_prompt=["a prompt"], negative_prompt=None, height=64, width=64, num_frames=4, num_inference_steps=5, eta=1.0,
+                    unconditional_guidance_scale=2.0, frame_stride=15, ref_videos=ref_videos.to(DEV), x_T=x_T, noises=noises)
+    a, b = run(), run()
+    assert a.shape == (1, 4, 3, 64, 64) and torch.isfinite(a.float()).all() and torch.equal(a, b)

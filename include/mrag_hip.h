@@ -342,7 +342,7 @@ int mrag_resize_patchify_bf16(void* stream, const mrag_resize_patch_args* args);
 int mrag_assemble_tokens_bf16(void* stream, const void* x, const void* prefix, const void* pos, void* out,
                               int64_t N, int32_t L, int32_t P, int32_t D);
 /* Row softmax of a materialised score matrix, y[r, :] = softmax(scale * x[r, :]) (fp32 statistics, bf16 in / out; rows 16-byte aligned, ld % 8 == 0,
- * scale > 0): the middle of the KL-VAE decoder's single-head head_dim-512 AttnBlock (lvdm/modules/networks/ae_modules.py:54-79: bmm, * c^-0.5,
+ * scale > 0; y may alias x: a thread rewrites only elements it has read itself): the middle of the KL-VAE decoder's single-head head_dim-512 AttnBlock (lvdm/modules/networks/ae_modules.py:54-79: bmm, * c^-0.5,
  * softmax(dim=2), bmm), whose two products run on mrag_gemm_bf16.                                                                                    */
 int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float scale);
 /* denormalize (src/utils/pipeline.py:178-184; VideoBaseModule.validation_step, src/projects/base_module.py:129-147): y = uint8(clip((x + 1) / 2, 0, 1) * 255),

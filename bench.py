@@ -254,19 +254,36 @@ def main():
         import io
         spec = importlib.util.spec_from_file_location("mrag_microbench", os.path.join(ROOT, "tools", "microbench.py"))
         mb = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mb)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(mb)
+
+        def guarded(name, fn):
+            """a secondary workload must never cost the headline line: its failure is reported in its slot (and on stderr), nothing else"""
+            try:
+                torch.cuda.empty_cache()
+                secondary[name] = fn()
+            except Exception as e:                                       # noqa: BLE001
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                print(f"bench.py: secondary workload {name} failed: {e!r}", file=sys.stderr)
+
+        secondary = {}
         with contextlib.redirect_stdout(io.StringIO()):          # bench.py prints ONE line
             from motionrag_amd import workloads as W
-            dcnet = W.dynamicrafter1024_unet(dev)
-            secondary = {"svd_unet_14x576x1024_cfg_step": mb.svd(),
-                         "dynamicrafter1024_unet_16x576x1024_cfg_step": mb.unet("bf16", dcnet),
-                         "dynamicrafter1024_unet_16x576x1024_cfg_step_fp8_attention": mb.unet("fp8", dcnet),     # BASELINE config #5, same weights / inputs
-                         "retrieval_top12_768d": mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1)))}
-            del dcnet
-            secondary["dynamicrafter_kl_vae_decode_16x576x1024"] = mb.vae()            # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
-            secondary["svd_temporal_vae_14x576x1024"] = mb.svd_vae()                      # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
-            secondary["t5_xxl_prompt_encoder_2x226"] = mb.t5()                            # SURVEY 8f rank 4 (CogVideoX's text encoder)
-            secondary["rag_side_encoders_plus_cama"] = mb.encoders()             # VideoMAE-B + DINOv2-L + CAMA from raw pixels
+            holder = {}
+
+            def dc(precision):
+                if "net" not in holder:
+                    holder["net"] = W.dynamicrafter1024_unet(dev)
+                return mb.unet(precision, holder["net"])
+            guarded("svd_unet_14x576x1024_cfg_step", mb.svd)
+            guarded("dynamicrafter1024_unet_16x576x1024_cfg_step", lambda: dc("bf16"))
+            guarded("dynamicrafter1024_unet_16x576x1024_cfg_step_fp8_attention", lambda: dc("fp8"))        # BASELINE config #5, same weights / inputs
+            holder.clear()
+            guarded("retrieval_top12_768d", lambda: mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1))))
+            guarded("dynamicrafter_kl_vae_decode_16x576x1024", mb.vae)                 # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
+            guarded("svd_temporal_vae_14x576x1024", mb.svd_vae)                         # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
+            guarded("t5_xxl_prompt_encoder_2x226", mb.t5)                               # SURVEY 8f rank 4 (CogVideoX's text encoder)
+            guarded("rag_side_encoders_plus_cama", mb.encoders)                         # SURVEY 8f rank 1: VideoMAE-B + DINOv2-L + CAMA from raw pixels
 
     if world > 1:
         import torch.distributed as dist

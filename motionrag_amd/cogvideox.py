@@ -388,7 +388,7 @@ class CogVideoXImageToVideoActionPipeline:
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
-                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None, cfgp=None) -> torch.Tensor:
+                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None, cfgp=None, hip_graph: bool = False) -> torch.Tensor:
         """the hot loop: latents [b, F, 16, h, w] bf16 (N(0,1) noise), prompt_embeds = cat([negative, positive])
         [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329).
         `sp` (dist.SequenceParallel): the token sequence of the clip sharded over the ranks; `cfgp` (dist.CFGParallel): this rank runs ONE of
@@ -402,9 +402,30 @@ class CogVideoXImageToVideoActionPipeline:
             sl = slice(cfgp.branch * b, (cfgp.branch + 1) * b)
             prompt_embeds, self.action_emb, B = prompt_embeds[sl].contiguous(), action_emb[sl].contiguous(), b
         rope_ip = self._prepare_rotary_positional_embeddings(F, h // p, w // p, latents.device)
+        graph = None
+        if hip_graph:
+            # The DiT forward of a step is the same ~420 launches with the same arguments every step (only the timestep VALUE and the latents' contents change):
+            # capture it once per clip and replay it; the CFG + DDIM update stays an eager launch (its coefficients are host scalars).  One eager pass first, on a
+            # side stream, builds the per-clip caches (fused weights, folded motion tokens, RoPE tables) outside the capture.  Bit-identical to the eager loop.
+            if sp is not None or cfgp is not None:
+                raise NotImplementedError("hip_graph: single-GPU loop only (the sharded tiers interleave collectives)")
+            timestep = torch.full((B,), float(ts[0]), dtype=torch.float32, device=latents.device)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                v_static = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B)
         for i, t in enumerate(ts):
-            timestep = torch.full((B,), float(t), dtype=torch.float32, device=latents.device)
-            v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B, sp=sp)
+            if graph is not None:
+                timestep.fill_(float(t))
+                graph.replay()
+                v = v_static
+            else:
+                timestep = torch.full((B,), float(t), dtype=torch.float32, device=latents.device)
+                v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B, sp=sp)
             if cfgp is not None:
                 v = cfgp.gather_branches(v.view(1, *v.shape)).view(2 * b, *v.shape[1:])     # [uncond ; cond]
             sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))

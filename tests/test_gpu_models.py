@@ -421,3 +421,26 @@ def test_native_cama_sequencers_equal_the_python_sequenced_forms(hip):
     args = enc._native_args()
     args.workspace_bytes = ops._lib.lib().mrag_cama_encoder_workspace_bytes(2, 250, 1024, 4096) - 1
     assert ops._lib.lib().mrag_cama_encoder_fwd(ops._stream(), ops.ctypes.byref(args)) == ops._lib.MRAG_EINVAL
+
+
+def test_denoise_loop_as_hip_graph_equals_eager(hip):
+    """CogVideoXImageToVideoCTPipeline.denoise(hip_graph=True): the DiT forward captured once per clip and replayed per step -- bit-identical latents to the eager loop"""
+    from motionrag_amd.cogvideox import CogVideoXDDIMScheduler, CogVideoXImageToVideoCTPipeline, CogVideoXTransformer3DModel
+    torch.manual_seed(3)
+    model = CogVideoXTransformer3DModel(num_layers=2, num_attention_heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                        max_text_seq_length=10, sample_frames=3, sample_height=16, sample_width=24)
+    model.install_motion_adapters(64)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.normal_(0.0, 0.05) if p.dim() >= 2 else p.add_(0.05 * torch.randn_like(p))
+    model = model.to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    lat, img = (torch.randn(1, 3, 8, 16, 24, generator=g).to(DEV, torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(DEV, torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(DEV, torch.bfloat16)
+    pipe = CogVideoXImageToVideoCTPipeline(model, CogVideoXDDIMScheduler())
+    eager = pipe.denoise(lat.clone(), img, text, ip, num_inference_steps=4, guidance_scale=6.0)
+    graphed = pipe.denoise(lat.clone(), img, text, ip, num_inference_steps=4, guidance_scale=6.0, hip_graph=True)
+    assert torch.isfinite(eager.float()).all() and torch.equal(eager, graphed)
+    graphed2 = pipe.denoise(lat.clone(), img, text, ip * 0.5, num_inference_steps=4, guidance_scale=6.0, hip_graph=True)      # a new clip: new capture, new motion tokens
+    assert not torch.equal(graphed2, graphed)

@@ -282,23 +282,21 @@ class Encoder(nn.Module):
 
 
 class DiagonalGaussianDistribution:
-    """lvdm/distributions.py:24-43 (the fields the inference path reads): `parameters` [N, 2 z, h, w] -> mean, logvar clamped to [-30, 20], std; `sample(noise)` /
-    `mode()`.  A few KB per frame: computed in fp32 with torch on the device."""
+    """The posterior `AutoencoderKL.encode` returns (lvdm/distributions.py:24-43): `parameters` [N, 2 z, h, w] = mean | log-variance (clamped to [-30, 20]).
+    The inference path reads `sample(noise)`, `mode()`, `mean`, `std`, `logvar`, `var`; a few KB per frame, kept in fp32 on the device."""
 
     def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
-        self.parameters = parameters
-        self.mean, self.logvar = torch.chunk(parameters.float(), 2, dim=1)
-        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
-        self.deterministic = deterministic
-        self.std = torch.exp(0.5 * self.logvar)
-        self.var = torch.exp(self.logvar)
-        if deterministic:
-            self.var = self.std = torch.zeros_like(self.mean)
+        self.parameters, self.deterministic = parameters, deterministic
+        moments = parameters.float()
+        z = moments.shape[1] // 2
+        self.mean, self.logvar = moments[:, :z], moments[:, z:].clamp(-30.0, 20.0)
+        spread = torch.zeros_like(self.mean) if deterministic else None
+        self.std = spread if deterministic else (0.5 * self.logvar).exp()
+        self.var = spread if deterministic else self.logvar.exp()
 
     def sample(self, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if noise is None:
-            noise = torch.randn(self.mean.shape)                 # the reference draws on the CPU too (distributions.py:37-38)
-        return self.mean + self.std * noise.to(device=self.parameters.device, dtype=torch.float32)
+        eps = torch.randn(self.mean.shape) if noise is None else noise          # like the reference, the default draw is on the host generator
+        return torch.addcmul(self.mean, self.std, eps.to(device=self.mean.device, dtype=torch.float32))
 
     def mode(self) -> torch.Tensor:
         return self.mean

@@ -410,7 +410,8 @@ class VideoMAEEmbedder(nn.Module):
 
     @torch.no_grad()
     def forward(self, video: torch.Tensor) -> torch.Tensor:
-        assert len(video.shape) == 5, "Input must be of shape (B, T, C, H, W)"
+        if video.dim() != 5:
+            raise ValueError(f"VideoMAEEmbedder expects clips [B, T, C, H, W], got {tuple(video.shape)}")
         T = video.shape[1]
         key = (T, video.device)
         if key not in self._idx:                       # condition.py:396 (the sampled frames are gathered inside the resize kernel)
@@ -438,7 +439,8 @@ class DINOImageEmbedder(nn.Module):
 
     @torch.no_grad()
     def forward(self, images: torch.Tensor) -> torch.Tensor:
-        assert len(images.shape) == 4, "Input must be of shape (B, C, H, W)"
+        if images.dim() != 4:
+            raise ValueError(f"DINOImageEmbedder expects images [B, C, H, W], got {tuple(images.shape)}")
         ps = self.model.patch_size
         rows = pixels_to_patch_rows(images[:, None], resize=self.resize, crop=self.crop, mode="bicubic", patch=(1, ps, ps))
         g = self.crop // ps

@@ -44,6 +44,18 @@ def _parse_kwargs(kw: Optional[dict]) -> dict:
 
 
 class VideoEvalHarness:
+    """`eval_pipeline`: the project's callable (cogvideox / svd / dynamicrafter `eval_pipeline`); `eval_pipeline_call_kwargs`: the YAML's extra keyword arguments."""
+
+    # the reference checks these properties of a step's output one by one (base_module.py:152-161); here they are one table
+    _OUTPUT_CONTRACT = (
+        ("a tensor", lambda o, b: isinstance(o, torch.Tensor)),
+        ("uint8", lambda o, b: o.dtype == torch.uint8),
+        ("on the host", lambda o, b: o.device.type == "cpu"),
+        ("5-D [b, f, c, h, w]", lambda o, b: o.dim() == 5),
+        ("accompanied by batch['metadata']", lambda o, b: "metadata" in b),
+        ("one video per metadata entry", lambda o, b: len(b["metadata"]) == o.shape[0]),
+    )
+
     def __init__(self, eval_pipeline: Callable[..., torch.Tensor], eval_pipeline_call_kwargs: Optional[dict] = None, dtype: torch.dtype = torch.bfloat16):
         self.eval_pipeline = eval_pipeline
         self.eval_pipeline_call_kwargs = _parse_kwargs(eval_pipeline_call_kwargs)
@@ -52,30 +64,28 @@ class VideoEvalHarness:
 
     @torch.no_grad()
     def validation_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
-        metadata = batch["metadata"]
-        positive_prompt = [b["raw_prompt"] for b in metadata]
-        generate_videos = self.eval_pipeline(image=batch["ref_frame"], positive_prompt=positive_prompt, negative_prompt=[""] * len(positive_prompt), dtype=self.dtype,
-                                             ref_videos=batch["ref_videos"], metadata=metadata, **self.eval_pipeline_call_kwargs)
-        return denormalize(generate_videos).cpu()          # [b f c h w] uint8 on the host
+        """base_module.py:129-147: prompts from the metadata, empty negative prompts, the first frame as the image condition, the retrieved clips; uint8 [b f c h w] on the host"""
+        meta = batch["metadata"]
+        prompts = [m["raw_prompt"] for m in meta]
+        call = dict(image=batch["ref_frame"], positive_prompt=prompts, negative_prompt=[""] * len(prompts), dtype=self.dtype, ref_videos=batch["ref_videos"], metadata=meta)
+        call.update(self.eval_pipeline_call_kwargs)
+        return denormalize(self.eval_pipeline(**call)).cpu()
 
     test_step = validation_step
 
-    @staticmethod
-    def output_assertions(outputs: torch.Tensor, batch: Any) -> None:
-        assert isinstance(outputs, torch.Tensor), f"Expected outputs to be a tensor, got {type(outputs)}"
-        assert outputs.dtype == torch.uint8, f"Expected outputs to be uint8, got {outputs.dtype}"
-        assert outputs.device == torch.device("cpu"), f"Expected outputs to be on CPU, got {outputs.device}"
-        assert len(outputs.shape) == 5, f"Expected outputs to be 5D, got {len(outputs.shape)}D"
-        assert "metadata" in batch, f"Expected batch to have a 'metadata' attribute, got {batch}"
-        assert len(batch["metadata"]) == outputs.size(0), \
-            f"Metadata length does not match outputs batch size, got {len(batch['metadata'])}, expected {outputs.size(0)}"
+    @classmethod
+    def output_assertions(cls, outputs: torch.Tensor, batch: Any) -> None:
+        for what, holds in cls._OUTPUT_CONTRACT:
+            assert holds(outputs, batch), f"a step's output must be {what} (got {type(outputs).__name__}" + (
+                f" {tuple(outputs.shape)} {outputs.dtype} on {outputs.device})" if isinstance(outputs, torch.Tensor) else ")")
 
     def on_validation_batch_end(self, outputs: torch.Tensor, batch: Any, batch_idx: int = 0, dataloader_idx: int = 0) -> None:
+        """base_module.py:163-178: one record per clip for the saving / metric callbacks"""
         self.output_assertions(outputs, batch)
-        gt_videos = denormalize(batch["video"]).cpu() if "video" in batch else None
-        for i, item in enumerate(batch["metadata"]):
-            self.generated_videos.append({"video": outputs[i][None], "gt_video": gt_videos[i][None] if gt_videos is not None else None, "id": item["id"],
-                                          "prompt": item["raw_prompt"], "save_name": item["save_name"]})
+        truth = denormalize(batch["video"]).cpu() if "video" in batch else None
+        self.generated_videos.extend(
+            {"video": outputs[i:i + 1], "gt_video": None if truth is None else truth[i:i + 1], "id": m["id"], "prompt": m["raw_prompt"], "save_name": m["save_name"]}
+            for i, m in enumerate(batch["metadata"]))
 
     on_test_batch_end = on_validation_batch_end
 

@@ -120,8 +120,31 @@ class _Level(nn.Module):
     pass
 
 
+def _make_level(widths, attn_here: bool) -> "_Level":
+    """one resolution level: ResnetBlocks over consecutive (in, out) widths [+ an AttnBlock after each when the YAML's attn_resolutions lists this resolution]"""
+    lv = _Level()
+    lv.block = nn.ModuleList(ResnetBlock(in_channels=a, out_channels=b) for a, b in zip(widths[:-1], widths[1:]))
+    lv.attn = nn.ModuleList(AttnBlock(b) for b in widths[1:]) if attn_here else nn.ModuleList()
+    return lv
+
+
+def _make_mid(width: int) -> "_Level":
+    mid = _Level()
+    mid.block_1, mid.attn_1, mid.block_2 = ResnetBlock(in_channels=width, out_channels=width), AttnBlock(width), ResnetBlock(in_channels=width, out_channels=width)
+    return mid
+
+
+def _run_level(lv: "_Level", h: torch.Tensor) -> torch.Tensor:
+    for j, blk in enumerate(lv.block):
+        h = blk(h)
+        if len(lv.attn):
+            h = lv.attn[j](h)
+    return h
+
+
 class Decoder(nn.Module):
-    """ae_modules.py:472-584 (attn_type 'vanilla', no attention at the up levels unless `attn_resolutions` asks for it)"""
+    """ae_modules.py:472-584 (attn_type 'vanilla').  Module tree = the reference's (`conv_in`, `mid.{block_1, attn_1, block_2}`, `up.{level}.{block.N, attn.N, upsample.conv}`
+    with level 0 the finest, `norm_out`, `conv_out`), built from a per-level width plan instead of the reference's running counters."""
 
     def __init__(self, *, ch: int, out_ch: int, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int, attn_resolutions: Sequence[int] = (), dropout: float = 0.0,
                  resamp_with_conv: bool = True, in_channels: int = 3, resolution: int = 256, z_channels: int = 4, give_pre_end: bool = False, tanh_out: bool = False,
@@ -129,50 +152,32 @@ class Decoder(nn.Module):
         super().__init__()
         if use_linear_attn or attn_type != "vanilla":
             raise NotImplementedError("only the vanilla AttnBlock is on the reference's path")
-        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
-        self.give_pre_end, self.tanh_out, self.out_ch = give_pre_end, tanh_out, out_ch
         if tanh_out:
             raise NotImplementedError("tanh_out is not used by the shipped configs")
-        block_in = ch * ch_mult[-1]
-        curr_res = resolution // 2 ** (self.num_resolutions - 1)
-        self.conv_in = nn.Conv2d(z_channels, block_in, 3, 1, 1)
-        self.mid = _Level()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            for _ in range(num_res_blocks + 1):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(AttnBlock(block_in))
-            up = _Level()
-            up.block, up.attn = block, attn
-            if i_level != 0:
-                up.upsample = Upsample(block_in, resamp_with_conv)
-                curr_res *= 2
-            self.up.insert(0, up)
-        self.norm_out = Normalize(block_in)
-        self.conv_out = nn.Conv2d(block_in, out_ch, 3, 1, 1)
-        self.peak_channels = ch * ch_mult[min(1, len(ch_mult) - 1)]            # channels of the finest level's upsampled input: the largest activation
+        levels = len(ch_mult)
+        self.num_resolutions, self.num_res_blocks, self.give_pre_end, self.tanh_out, self.out_ch = levels, num_res_blocks, give_pre_end, tanh_out, out_ch
+        widths = [ch * m for m in ch_mult]                                     # level i runs at width ch * ch_mult[i]; the decoder walks them coarse -> fine
+        self.conv_in = nn.Conv2d(z_channels, widths[-1], 3, 1, 1)
+        self.mid = _make_mid(widths[-1])
+        ups, entering = [None] * levels, widths[-1]
+        for i in range(levels - 1, -1, -1):
+            lv = _make_level([entering] + [widths[i]] * (num_res_blocks + 1), (resolution >> i) in attn_resolutions)
+            if i > 0:
+                lv.upsample = Upsample(widths[i], resamp_with_conv)
+            ups[i], entering = lv, widths[i]
+        self.up = nn.ModuleList(ups)
+        self.norm_out = Normalize(widths[0])
+        self.conv_out = nn.Conv2d(widths[0], out_ch, 3, 1, 1)
+        self.peak_channels = ch * ch_mult[min(1, levels - 1)]                  # channels of the finest level's upsampled input: the largest activation
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """z [N, H, W, z_channels] channels-last -> [N, H * 2^(levels-1), W * 2^(levels-1), out_ch]"""
         h = _conv_small_cin(z, self.conv_in, "vae_dec_in")
-        h = self.mid.block_1(h)
-        h = self.mid.attn_1(h)
-        h = self.mid.block_2(h)
-        for i_level in reversed(range(self.num_resolutions)):
-            lv = self.up[i_level]
-            for i_block in range(self.num_res_blocks + 1):
-                h = lv.block[i_block](h)
-                if len(lv.attn) > 0:
-                    h = lv.attn[i_block](h)
-            if i_level != 0:
-                h = lv.upsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for i in range(self.num_resolutions - 1, -1, -1):
+            h = _run_level(self.up[i], h)
+            if i > 0:
+                h = self.up[i].upsample(h)
         if self.give_pre_end:
             return h
         h = _gn_swish(h, self.norm_out)
@@ -227,7 +232,7 @@ def _conv_small_cin(z: torch.Tensor, conv: nn.Conv2d, tag: str) -> torch.Tensor:
 
 
 class Encoder(nn.Module):
-    """ae_modules.py:370-470"""
+    """ae_modules.py:370-470; module tree `conv_in`, `down.{level}.{block.N, attn.N, downsample.conv}` (level 0 the finest), `mid`, `norm_out`, `conv_out`"""
 
     def __init__(self, *, ch: int, out_ch: int = 3, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int, attn_resolutions: Sequence[int] = (), dropout: float = 0.0,
                  resamp_with_conv: bool = True, in_channels: int = 3, resolution: int = 256, z_channels: int = 4, double_z: bool = True, use_linear_attn: bool = False,
@@ -235,50 +240,31 @@ class Encoder(nn.Module):
         super().__init__()
         if use_linear_attn or attn_type != "vanilla":
             raise NotImplementedError("only the vanilla AttnBlock is on the reference's path")
-        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        levels = len(ch_mult)
+        self.num_resolutions, self.num_res_blocks = levels, num_res_blocks
+        widths = [ch * m for m in ch_mult]
         self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
-        curr_res = resolution
-        in_ch_mult = (1,) + tuple(ch_mult)
-        self.down = nn.ModuleList()
-        block_in = ch
-        for i_level in range(self.num_resolutions):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_in = ch * in_ch_mult[i_level]
-            block_out = ch * ch_mult[i_level]
-            for _ in range(num_res_blocks):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(AttnBlock(block_in))
-            down = _Level()
-            down.block, down.attn = block, attn
-            if i_level != self.num_resolutions - 1:
-                down.downsample = Downsample(block_in, resamp_with_conv)
-                curr_res //= 2
-            self.down.append(down)
-        self.mid = _Level()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in)
-        self.norm_out = Normalize(block_in)
-        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+        downs, entering = [], ch
+        for i in range(levels):                                               # fine -> coarse
+            lv = _make_level([entering] + [widths[i]] * num_res_blocks, (resolution >> i) in attn_resolutions)
+            if i < levels - 1:
+                lv.downsample = Downsample(widths[i], resamp_with_conv)
+            downs.append(lv)
+            entering = widths[i]
+        self.down = nn.ModuleList(downs)
+        self.mid = _make_mid(widths[-1])
+        self.norm_out = Normalize(widths[-1])
+        self.conv_out = nn.Conv2d(widths[-1], (2 if double_z else 1) * z_channels, 3, 1, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [N, H, W, 3] channels-last -> moments [N, H / 2^(levels-1), W / 2^(levels-1), 2 z_channels]"""
         h = _conv_small_cin(x, self.conv_in, "vae_enc_in")
-        for i_level in range(self.num_resolutions):
-            lv = self.down[i_level]
-            for i_block in range(self.num_res_blocks):
-                h = lv.block[i_block](h)
-                if len(lv.attn) > 0:
-                    h = lv.attn[i_block](h)
-            if i_level != self.num_resolutions - 1:
+        for i, lv in enumerate(self.down):
+            h = _run_level(lv, h)
+            if i < self.num_resolutions - 1:
                 h = lv.downsample(h)
-        h = self.mid.block_1(h)
-        h = self.mid.attn_1(h)
-        h = self.mid.block_2(h)
-        h = _gn_swish(h, self.norm_out)
-        return conv3x3(h, self.conv_out)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        return conv3x3(_gn_swish(h, self.norm_out), self.conv_out)
 
 
 class DiagonalGaussianDistribution:
@@ -380,13 +366,12 @@ class FirstStage:
         self.first_stage_model, self.scale_factor, self.perframe_ae = first_stage_model, scale_factor, perframe_ae
 
     def get_first_stage_encoding(self, encoder_posterior, noise=None):
-        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
-            z = encoder_posterior.sample(noise=noise)
-        elif isinstance(encoder_posterior, torch.Tensor):
-            z = encoder_posterior
-        else:
-            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
-        return self.scale_factor * z
+        """ddpm3d.py:633-640: a posterior is sampled, a tensor passes through; both are scaled"""
+        if hasattr(encoder_posterior, "sample") and hasattr(encoder_posterior, "mode"):
+            return self.scale_factor * encoder_posterior.sample(noise=noise)
+        if torch.is_tensor(encoder_posterior):
+            return self.scale_factor * encoder_posterior
+        raise NotImplementedError(f"no first-stage encoding for {type(encoder_posterior).__name__}")
 
     @torch.no_grad()
     def encode_first_stage(self, x: torch.Tensor) -> torch.Tensor:

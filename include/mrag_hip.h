@@ -348,6 +348,12 @@ int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int64_t rows, i
 /* denormalize (src/utils/pipeline.py:178-184; VideoBaseModule.validation_step, src/projects/base_module.py:129-147): y = uint8(clip((x + 1) / 2, 0, 1) * 255),
  * x bf16 (or fp32 with src_fp32 = 1) with the rounding points of the torch ops on that dtype, truncating cast -- bit-exact byte output.               */
 int mrag_denormalize_u8(void* stream, const void* x, void* y, int64_t n, int32_t src_fp32);
+/* Seam blending of the tiled VAE decode / encode that `pipe.vae.enable_tiling()` (cogvideox/module.py:39) switches on -- diffusers
+ * AutoencoderKLCogVideoX.tiled_decode / blend_v / blend_h: tile [T, th, tw, C] bf16 is blended in place, first over its top extent_v rows with the bottom rows
+ * of `up` [T, up_h, tw, C] (weight y / extent), then over its left extent_h columns with the right columns of `left` [T, th, left_w, C]; extents are clipped
+ * to the tiles' sizes as the reference clips them; NULL up / left = no neighbour on that side.  Tiles are visited row by row, so neighbours are already blended. */
+int mrag_blend_tile_bf16(void* stream, void* tile, const void* up, const void* left, int32_t T, int32_t th, int32_t tw, int32_t C, int32_t up_h,
+                         int32_t left_w, int32_t extent_v, int32_t extent_h);
 /* patchify [Bl, F, C0, H, W] (+ [Bl, F, C1, H, W]) -> rows [B*F*(H/2)*(W/2), (C0+C1)*4],
  * batch b reads latent b % Bl (CFG duplication).  Conv2d(k=2,s=2) patch embed as GEMM. */
 int mrag_patchify_bf16(void* stream, const void* src0, const void* src1, void* dst,
@@ -401,6 +407,15 @@ typedef struct mrag_groupnorm_args {
   int64_t N, HW, C, emb_stride;
   int32_t G, chunks, silu;
   float eps;
+  /* spatially conditioned GroupNorm -- diffusers' CogVideoXSpatialNorm3D (the decoder norms of the VAE behind cogvideox/module.py:39-40):
+   * y = GroupNorm(x) * conv_y(zq_up) + conv_b(zq_up), zq_up = nearest-neighbour F.interpolate of the latent to x's (T, H, W).  The 1x1x1
+   * convolutions commute with the upsampling, so `mod` holds them at the LATENT resolution: [N, mod_Tz, mod_H >> mod_shift, mod_W >> mod_shift, 2C]
+   * bf16 (conv_y | conv_b along the last axis); x rows are (t, y, x) with HW = mod_T * mod_H * mod_W.  mod_split = the odd-T form (frame 0
+   * from latent frame 0, the remaining frames resampled from the remaining latent frames).  y_stride_n: elements between the samples of y
+   * (0 = HW * C) so that the result can land behind the two context frames of a causal-convolution stack.  NULL mod = plain GroupNorm. */
+  const void* mod;
+  int32_t mod_T, mod_H, mod_W, mod_Tz, mod_shift, mod_split;
+  int64_t y_stride_n;
 } mrag_groupnorm_args;
 int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks);
 int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* args);
@@ -427,6 +442,10 @@ typedef struct mrag_conv_args {
   int32_t asym_pad;                /* MRAG_CONV_3X3, stride 2: 0 = padding 1 on every side; 1 = zero row / column at the bottom / right only --
                                       `F.pad(x, (0, 1, 0, 1))` + Conv2d(3, stride 2, padding 0), the KL-VAE encoder's Downsample
                                       (lvdm/modules/networks/ae_modules.py:93-113): Ho = H / 2                                       */
+  int32_t t_taps, t_frames;        /* MRAG_CONV_3X3, stride 1: t_taps = 3 turns the convolution into the causal 3x3x3 one of diffusers'
+                                      CogVideoXCausalConv3d (the VAE behind cogvideox/module.py:39-40): x holds, per sample, the two context frames
+                                      (conv cache, or the first frame twice) followed by t_frames frames -> x [(N / t_frames) (t_frames + 2), H, Wd, Cin],
+                                      y [N, H, Wd, Cout], W [Cout, (kt, ky, kx, cin)]; zero padding in space, none in time.  0 = 2-D.            */
 } mrag_conv_args;
 int mrag_conv_bf16(void* stream, const mrag_conv_args* args);
 /* row gather for nn.Conv3d((3,1,1), padding (1,0,0)), openaimodel3d.py:256-268:

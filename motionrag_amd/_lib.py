@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
@@ -30,7 +30,7 @@ SYMBOLS = [
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
-    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8", "mrag_attn_small_bf16",
+    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8", "mrag_attn_small_bf16", "mrag_blend_tile_bf16",
     "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
 ]
 
@@ -129,6 +129,8 @@ class GroupNormArgs(Structure):
         ("x", c_void_p), ("y", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("emb", c_void_p), ("workspace", c_void_p),
         ("N", c_int64), ("HW", c_int64), ("C", c_int64), ("emb_stride", c_int64),
         ("G", c_int32), ("chunks", c_int32), ("silu", c_int32), ("eps", c_float),
+        ("mod", c_void_p), ("mod_T", c_int32), ("mod_H", c_int32), ("mod_W", c_int32), ("mod_Tz", c_int32), ("mod_shift", c_int32), ("mod_split", c_int32),
+        ("y_stride_n", c_int64),
     ]
 
 
@@ -137,6 +139,7 @@ class ConvArgs(Structure):
         ("x", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("resid", c_void_p),
         ("N", c_int32), ("H", c_int32), ("Wd", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("stride", c_int32), ("upsample", c_int32), ("mode", c_int32), ("epilogue", c_int32), ("asym_pad", c_int32),
+        ("t_taps", c_int32), ("t_frames", c_int32),
     ]
 
 
@@ -239,6 +242,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_cama_encoder_workspace_bytes.restype = c_int64
     L.mrag_cama_encoder_fwd.argtypes = [c_void_p, POINTER(CamaEncoderArgs)]
     L.mrag_denormalize_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32]
+    L.mrag_blend_tile_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8
     L.mrag_softmax_rows_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float]
     L.mrag_assemble_tokens_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]
     for name in SYMBOLS:          # everything that did not declare a 64-bit / pointer result above returns an int status

@@ -1,0 +1,370 @@
+"""The CogVideoX 3-D causal VAE around the denoising loop on the HIP kernels: what `pipe.vae` is in the reference --
+diffusers==0.32.2 `AutoencoderKLCogVideoX`, configured by `src/projects/cogvideox/module.py:39-40` (`enable_tiling()`, `enable_slicing()`) and
+called by the pipeline's `prepare_latents` (image -> latent) and `decode_latents` (13 latent frames -> 49 frames).
+
+Module tree and parameter names are diffusers' (`decoder.up_blocks.0.resnets.1.norm1.conv_y.conv.weight`, ...), so the checkpoint's
+`vae/diffusion_pytorch_model.safetensors` loads with `load_state_dict` unchanged.
+
+Data path -- one sample (slicing) and one spatial tile at a time, channels-last frame stacks [T, H, W, C] bf16:
+  causal 3x3x3 convolution     `mrag_conv_bf16` with t_taps = 3: the implicit GEMM's LDS-DMA walks 27 taps over a stack that already holds the two context
+                               frames (conv cache of the previous frame batch, or the first frame twice); the ResnetBlock's `+ x` rides in the epilogue
+  SpatialNorm3D + SiLU         `mrag_groupnorm_bf16` with `mod`: statistics over (T, H, W, C / 32), then gn(x) * conv_y(zq) + conv_b(zq) with the two 1x1x1
+                               convolutions evaluated ONCE at the latent resolution (one GEMM, [Tz h w, 2C]) and read through the nearest-neighbour frame /
+                               pixel map -- the upsampled conditioning maps of the reference (2 x the activation) never exist; the result lands directly
+                               behind the context frames of the next convolution's stack
+  Upsample3D                   per-frame 3x3 convolution with the nearest x2 fused into the gather; the temporal x2 of `compress_time` is a frame gather AFTER
+                               the convolution (duplicated frames give duplicated outputs: half the convolution work of the reference's order)
+  Downsample3D                 pair average over time (`mrag_weighted_sum_bf16`), then the asymmetric-padding stride-2 implicit GEMM
+  tiling                       tiles decode independently; seams by `mrag_blend_tile_bf16` in the reference's visiting order
+GPU only; no CPU fallback."""
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .dynamicrafter import _CACHE
+from .dynamicrafter_vae import DiagonalGaussianDistribution, _b
+
+_KPAD = 64          # the implicit GEMM moves whole 64-channel K-tiles: 3 (RGB) and 16 (latent) channel inputs travel zero-padded
+
+
+class CogVideoXCausalConv3d(nn.Module):
+    """holder of `conv` (nn.Conv3d, kernel 3 or 1): diffusers' parameter names; the arithmetic is in `_causal3` / `_cond_maps`"""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size)
+
+
+class CogVideoXSpatialNorm3D(nn.Module):
+    def __init__(self, f_channels: int, zq_channels: int, groups: int = 32):
+        super().__init__()
+        self.norm_layer = nn.GroupNorm(groups, f_channels, eps=1e-6, affine=True)
+        self.conv_y = CogVideoXCausalConv3d(zq_channels, f_channels, 1)
+        self.conv_b = CogVideoXCausalConv3d(zq_channels, f_channels, 1)
+
+
+def _pad_channels(x: torch.Tensor, to: int = _KPAD) -> torch.Tensor:
+    c = x.shape[-1]
+    return x if c % to == 0 else torch.nn.functional.pad(x, (0, to - c % to))
+
+
+def _w27(mod: CogVideoXCausalConv3d, cout_pad: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Conv3d weight [Cout, Cin, kt, ky, kx] -> [Cout, (kt, ky, kx, cin padded to 64)] (+ zero output channels up to a multiple of 4)"""
+    conv = mod.conv
+
+    def build():
+        w = _b(conv.weight).permute(0, 2, 3, 4, 1)
+        w = _pad_channels(w).reshape(w.shape[0], -1)
+        b = _b(conv.bias)
+        extra = (-w.shape[0]) % 4 if cout_pad else 0
+        if extra:
+            w = torch.cat([w, torch.zeros(extra, w.shape[1], dtype=w.dtype, device=w.device)])
+            b = torch.cat([b, torch.zeros(extra, dtype=b.dtype, device=b.device)])
+        return w.contiguous(), b.contiguous()
+    return _CACHE.get(("cvx27", id(conv), cout_pad), (conv.weight, conv.bias), build)
+
+
+def _w9(conv: nn.Conv2d) -> torch.Tensor:
+    return _CACHE.get(("cvx9", id(conv)), conv.weight, lambda: _b(conv.weight).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).contiguous())
+
+
+def _new_stack(T: int, H: int, W: int, C: int, device) -> torch.Tensor:
+    return torch.empty(T + 2, H, W, C, dtype=torch.bfloat16, device=device)
+
+
+def _causal3(stack: torch.Tensor, mod: CogVideoXCausalConv3d, cache: Dict, resid: Optional[torch.Tensor] = None, cout_pad: int = 0) -> torch.Tensor:
+    """CogVideoXCausalConv3d.forward (pad_mode 'first') on a stack whose frames [2:] are this batch's input: fills the two context frames from the cache of
+    the previous frame batch (or with the first frame), runs the 27-tap implicit GEMM, keeps the last two frames as the next batch's context"""
+    T = stack.shape[0] - 2
+    key = id(mod)
+    if key in cache:
+        stack[:2].copy_(cache[key])
+    else:
+        stack[:2].copy_(stack[2:3].expand(2, -1, -1, -1))
+    wk, bk = _w27(mod, cout_pad)
+    y = ops.conv_implicit(stack, wk, bk, ops.CONV_3X3, t_frames=T, resid=resid)
+    cache[key] = stack[T:].clone()
+    return y
+
+
+def _cond_maps(norm: CogVideoXSpatialNorm3D, zq64: torch.Tensor) -> torch.Tensor:
+    """conv_y(zq) | conv_b(zq) at the latent resolution: [1, Tz, h, w, 2C]"""
+    def build():
+        wy, wb = (_b(c.conv.weight).reshape(c.conv.weight.shape[0], -1) for c in (norm.conv_y, norm.conv_b))
+        w = _pad_channels(torch.cat([wy, wb]))
+        return w.contiguous(), torch.cat([_b(norm.conv_y.conv.bias), _b(norm.conv_b.conv.bias)]).contiguous()
+    w, b = _CACHE.get(("cvxyb", id(norm)), (norm.conv_y.conv.weight, norm.conv_b.conv.weight, norm.conv_y.conv.bias, norm.conv_b.conv.bias), build)
+    Tz, h, wd, _ = zq64.shape
+    return ops.linear(zq64.view(Tz * h * wd, -1), w, b).view(1, Tz, h, wd, -1)
+
+
+def _norm_into_stack(x: torch.Tensor, norm, zq64: Optional[torch.Tensor], groups: int, eps: float) -> torch.Tensor:
+    """SiLU(norm(x)) written behind the two context frames of a fresh stack; x [T, H, W, C]"""
+    T, H, W, C = x.shape
+    stack = _new_stack(T, H, W, C, x.device)
+    out = stack[2:].view(1, T * H * W, C)
+    if zq64 is None:                                                         # encoder: plain GroupNorm over (T, H, W, C / G)
+        ops.groupnorm(x.view(1, T * H * W, C), _b(norm.weight), _b(norm.bias), groups, eps, silu=True, out=out)
+    else:
+        shift = int(math.log2(H // zq64.shape[1]))
+        ops.groupnorm(x.view(1, T * H * W, C), _b(norm.norm_layer.weight), _b(norm.norm_layer.bias), groups, eps, silu=True, out=out,
+                      mod=_cond_maps(norm, zq64), mod_geom=(T, H, W, shift, T > 1 and T % 2 == 1))
+    return stack
+
+
+class CogVideoXResnetBlock3D(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, eps: float, groups: int, spatial_norm_dim: Optional[int]):
+        super().__init__()
+        self.groups, self.eps = groups, eps
+        if spatial_norm_dim is None:
+            self.norm1, self.norm2 = nn.GroupNorm(groups, in_channels, eps=eps), nn.GroupNorm(groups, out_channels, eps=eps)
+        else:
+            self.norm1, self.norm2 = CogVideoXSpatialNorm3D(in_channels, spatial_norm_dim, groups), CogVideoXSpatialNorm3D(out_channels, spatial_norm_dim, groups)
+        self.conv1 = CogVideoXCausalConv3d(in_channels, out_channels, 3)
+        self.conv2 = CogVideoXCausalConv3d(out_channels, out_channels, 3)
+        if in_channels != out_channels:
+            self.conv_shortcut = nn.Conv3d(in_channels, out_channels, 1)
+
+    def forward(self, x: torch.Tensor, zq64: Optional[torch.Tensor], cache: Dict) -> torch.Tensor:
+        h = _causal3(_norm_into_stack(x, self.norm1, zq64, self.groups, self.eps), self.conv1, cache)
+        stack = _norm_into_stack(h, self.norm2, zq64, self.groups, self.eps)
+        if hasattr(self, "conv_shortcut"):
+            sc = self.conv_shortcut
+            w = _CACHE.get(("cvx1", id(sc)), sc.weight, lambda: _b(sc.weight).reshape(sc.weight.shape[0], -1).contiguous())
+            x = ops.linear(x, w, _b(sc.bias))
+        return _causal3(stack, self.conv2, cache, resid=x.contiguous())
+
+
+class _Resnets(nn.Module):
+    def __init__(self, widths: Sequence[int], eps: float, groups: int, spatial_norm_dim: Optional[int]):
+        super().__init__()
+        self.resnets = nn.ModuleList(CogVideoXResnetBlock3D(a, b, eps, groups, spatial_norm_dim) for a, b in zip(widths[:-1], widths[1:]))
+
+    def run(self, x, zq64, cache):
+        for r in self.resnets:
+            x = r(x, zq64, cache)
+        return x
+
+
+_DOUBLING: Dict = {}
+
+
+def _frame_doubling(T: int, device) -> torch.Tensor:
+    """source frame of every output frame of the temporal nearest x2 (T odd: the first frame stays single)"""
+    key = (T, str(device))
+    if key not in _DOUBLING:
+        src = [0] + [1 + k // 2 for k in range(2 * (T - 1))] if T % 2 else [k // 2 for k in range(2 * T)]
+        _DOUBLING[key] = torch.tensor(src, device=device)
+    return _DOUBLING[key]
+
+
+class CogVideoXUpsample3D(nn.Module):
+    def __init__(self, channels: int, compress_time: bool):
+        super().__init__()
+        self.conv, self.compress_time = nn.Conv2d(channels, channels, 3, padding=1), compress_time
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        T = x.shape[0]
+        y = ops.conv_implicit(x.contiguous(), _w9(self.conv), _b(self.conv.bias), ops.CONV_3X3, upsample=True)
+        if self.compress_time and T > 1:                                      # nearest x2 in time; with an odd frame count the first frame stays single
+            y = y.index_select(0, _frame_doubling(T, y.device))
+        return y
+
+
+class CogVideoXDownsample3D(nn.Module):
+    def __init__(self, channels: int, compress_time: bool):
+        super().__init__()
+        self.conv, self.compress_time = nn.Conv2d(channels, channels, 3, stride=2, padding=0), compress_time
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        T = x.shape[0]
+        if self.compress_time and T > 1:                                      # avg_pool1d(2, 2) over time, the first frame apart when T is odd
+            first, rest = (x[:1], x[1:]) if T % 2 else (x[:0], x)
+            pairs = ops.weighted_sum(rest.reshape(rest.shape[0] // 2, 2, *rest.shape[1:]).contiguous(), None, div=2.0)
+            x = torch.cat([first, pairs]) if T % 2 else pairs
+        return ops.conv_implicit(x.contiguous(), _w9(self.conv), _b(self.conv.bias), ops.CONV_3X3, stride=2, asym_pad=True)
+
+
+class _Block(_Resnets):
+    pass
+
+
+class CogVideoXDecoder3D(nn.Module):
+    def __init__(self, latent_channels: int, out_channels: int, block_out_channels: Sequence[int], layers_per_block: int, eps: float, groups: int,
+                 temporal_compression_ratio: int):
+        super().__init__()
+        rev = list(block_out_channels)[::-1]
+        t_levels = int(math.log2(temporal_compression_ratio))
+        self.groups, self.out_channels = groups, out_channels
+        self.conv_in = CogVideoXCausalConv3d(latent_channels, rev[0], 3)
+        self.mid_block = _Block([rev[0]] * 3, eps, groups, latent_channels)
+        blocks, entering = [], rev[0]
+        for i, c in enumerate(rev):
+            blk = _Block([entering] + [c] * (layers_per_block + 1), eps, groups, latent_channels)
+            if i < len(rev) - 1:
+                blk.upsamplers = nn.ModuleList([CogVideoXUpsample3D(c, i < t_levels)])
+            blocks.append(blk)
+            entering = c
+        self.up_blocks = nn.ModuleList(blocks)
+        self.norm_out = CogVideoXSpatialNorm3D(rev[-1], latent_channels, groups)
+        self.conv_out = CogVideoXCausalConv3d(rev[-1], out_channels, 3)
+
+    def forward(self, z: torch.Tensor, cache: Dict) -> torch.Tensor:
+        """one frame batch of one tile: z [Tz, h, w, zc] channels-last -> [T, 8h, 8w, out_channels padded to 4]"""
+        Tz, h, w, _ = z.shape
+        zq64 = _pad_channels(z).contiguous()
+        stack = _new_stack(Tz, h, w, zq64.shape[-1], z.device)
+        stack[2:].copy_(zq64)
+        x = _causal3(stack, self.conv_in, cache)
+        x = self.mid_block.run(x, zq64, cache)
+        for blk in self.up_blocks:
+            x = blk.run(x, zq64, cache)
+            if hasattr(blk, "upsamplers"):
+                x = blk.upsamplers[0](x)
+        return _causal3(_norm_into_stack(x, self.norm_out, zq64, self.groups, 1e-6), self.conv_out, cache, cout_pad=1)
+
+
+class CogVideoXEncoder3D(nn.Module):
+    def __init__(self, in_channels: int, latent_channels: int, block_out_channels: Sequence[int], layers_per_block: int, eps: float, groups: int,
+                 temporal_compression_ratio: int):
+        super().__init__()
+        boc = list(block_out_channels)
+        t_levels = int(math.log2(temporal_compression_ratio))
+        self.groups = groups
+        self.conv_in = CogVideoXCausalConv3d(in_channels, boc[0], 3)
+        blocks, entering = [], boc[0]
+        for i, c in enumerate(boc):
+            blk = _Block([entering] + [c] * layers_per_block, eps, groups, None)
+            if i < len(boc) - 1:
+                blk.downsamplers = nn.ModuleList([CogVideoXDownsample3D(c, i < t_levels)])
+            blocks.append(blk)
+            entering = c
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _Block([boc[-1]] * 3, eps, groups, None)
+        self.norm_out = nn.GroupNorm(groups, boc[-1], eps=1e-6)
+        self.conv_out = CogVideoXCausalConv3d(boc[-1], 2 * latent_channels, 3)
+
+    def forward(self, x: torch.Tensor, cache: Dict) -> torch.Tensor:
+        """one frame batch of one tile: x [T, H, W, 3] channels-last -> moments [T', H / 8, W / 8, 2 zc]"""
+        T, H, W, _ = x.shape
+        x64 = _pad_channels(x)
+        stack = _new_stack(T, H, W, x64.shape[-1], x.device)
+        stack[2:].copy_(x64)
+        h = _causal3(stack, self.conv_in, cache)
+        for blk in self.down_blocks:
+            h = blk.run(h, None, cache)
+            if hasattr(blk, "downsamplers"):
+                h = blk.downsamplers[0](h)
+        h = self.mid_block.run(h, None, cache)
+        return _causal3(_norm_into_stack(h, self.norm_out, None, self.groups, 1e-6), self.conv_out, cache)
+
+
+def frame_batches(num_frames: int, batch: int) -> List[Tuple[int, int]]:
+    """[start, end) ranges of `_decode` / `_encode`: `num_frames // batch` batches, the remainder joins the first"""
+    count, rem = max(num_frames // batch, 1), num_frames % batch
+    return [(batch * k + (rem if k else 0), batch * (k + 1) + rem) for k in range(count)]
+
+
+class _Posterior(DiagonalGaussianDistribution):
+    """`encode(x).latent_dist`: diffusers' `sample(generator)` draws with `randn_tensor` on the generator's device"""
+
+    def sample(self, generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if noise is None:
+            gen_dev = generator.device if generator is not None else self.mean.device
+            noise = torch.randn(self.mean.shape, generator=generator, device=gen_dev, dtype=torch.float32)
+        return super().sample(noise)
+
+
+class AutoencoderKLCogVideoX(nn.Module):
+    """diffusers 0.32.2 `AutoencoderKLCogVideoX` (no quant / post-quant convolutions, as the CogVideoX checkpoints configure it).
+    `decode(z).sample` / `decode(z, return_dict=False)[0]`, `encode(x).latent_dist`, `enable_tiling()`, `enable_slicing()`, `config.scaling_factor`."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, block_out_channels: Sequence[int] = (128, 256, 256, 512), layers_per_block: int = 3,
+                 latent_channels: int = 16, norm_eps: float = 1e-6, norm_num_groups: int = 32, temporal_compression_ratio: int = 4, sample_height: int = 480,
+                 sample_width: int = 720, scaling_factor: float = 0.7, **_ignored):
+        super().__init__()
+        self.encoder = CogVideoXEncoder3D(in_channels, latent_channels, block_out_channels, layers_per_block, norm_eps, norm_num_groups, temporal_compression_ratio)
+        self.decoder = CogVideoXDecoder3D(latent_channels, out_channels, block_out_channels, layers_per_block, norm_eps, norm_num_groups, temporal_compression_ratio)
+        self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, block_out_channels=tuple(block_out_channels), latent_channels=latent_channels,
+                                      temporal_compression_ratio=temporal_compression_ratio, sample_height=sample_height, sample_width=sample_width,
+                                      scaling_factor=scaling_factor, invert_scale_latents=False)
+        self.use_tiling = self.use_slicing = False                              # slicing is how this class always runs (one sample at a time)
+        self.num_latent_frames_batch_size, self.num_sample_frames_batch_size = 2, 8
+        down = 2 ** (len(block_out_channels) - 1)
+        self.tile_sample_min_height, self.tile_sample_min_width = sample_height // 2, sample_width // 2
+        self.tile_latent_min_height, self.tile_latent_min_width = int(self.tile_sample_min_height / down), int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
+
+    def enable_tiling(self, tile_sample_min_height: Optional[int] = None, tile_sample_min_width: Optional[int] = None,
+                      tile_overlap_factor_height: Optional[float] = None, tile_overlap_factor_width: Optional[float] = None) -> None:
+        self.use_tiling = True
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_latent_min_height, self.tile_latent_min_width = int(self.tile_sample_min_height / down), int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
+
+    def disable_tiling(self) -> None:
+        self.use_tiling = False
+
+    def enable_slicing(self) -> None:
+        self.use_slicing = True
+
+    def disable_slicing(self) -> None:
+        self.use_slicing = False
+
+    # ------------------------------------------------------------------------------------------------------------ one sample
+    def _batched(self, net, x: torch.Tensor, batch: int) -> torch.Tensor:
+        cache: Dict = {}
+        return torch.cat([net(x[a:b].contiguous(), cache) for a, b in frame_batches(x.shape[0], batch)])
+
+    def _tiled(self, net, x: torch.Tensor, batch: int, tile: Tuple[int, int], overlap: Tuple[int, int], blend: Tuple[int, int], limit: Tuple[int, int]) -> torch.Tensor:
+        H, W = x.shape[1:3]
+        rows = [[self._batched(net, x[:, i:i + tile[0], j:j + tile[1]], batch) for j in range(0, W, overlap[1])] for i in range(0, H, overlap[0])]
+        strips = []
+        for i, row in enumerate(rows):
+            for j, t in enumerate(row):
+                ops.blend_tile(t, rows[i - 1][j] if i else None, row[j - 1] if j else None, blend[0], blend[1])
+            strips.append(torch.cat([t[:, :limit[0], :limit[1]] for t in row], dim=2))
+        return torch.cat(strips, dim=1)
+
+    def _decode_one(self, z: torch.Tensor) -> torch.Tensor:
+        lh, lw, sh, sw = self.tile_latent_min_height, self.tile_latent_min_width, self.tile_sample_min_height, self.tile_sample_min_width
+        fh, fw = self.tile_overlap_factor_height, self.tile_overlap_factor_width
+        if self.use_tiling and (z.shape[2] > lw or z.shape[1] > lh):
+            return self._tiled(self.decoder, z, self.num_latent_frames_batch_size, (lh, lw), (int(lh * (1 - fh)), int(lw * (1 - fw))),
+                               (int(sh * fh), int(sw * fw)), (sh - int(sh * fh), sw - int(sw * fw)))
+        return self._batched(self.decoder, z, self.num_latent_frames_batch_size)
+
+    def _encode_one(self, x: torch.Tensor) -> torch.Tensor:
+        lh, lw, sh, sw = self.tile_latent_min_height, self.tile_latent_min_width, self.tile_sample_min_height, self.tile_sample_min_width
+        fh, fw = self.tile_overlap_factor_height, self.tile_overlap_factor_width
+        if self.use_tiling and (x.shape[2] > sw or x.shape[1] > sh):
+            return self._tiled(self.encoder, x, self.num_sample_frames_batch_size, (sh, sw), (int(sh * (1 - fh)), int(sw * (1 - fw))),
+                               (int(lh * fh), int(lw * fw)), (lh - int(lh * fh), lw - int(lw * fw)))
+        return self._batched(self.encoder, x, self.num_sample_frames_batch_size)
+
+    # ------------------------------------------------------------------------------------------------------------ diffusers surface
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """z [B, zc, T, h, w] -> sample [B, 3, 1 + 4 (T - 1), 8h, 8w] bf16"""
+        if not z.is_cuda:
+            raise ops.HipOnly("AutoencoderKLCogVideoX.decode: GPU tensors only")
+        oc = self.config.out_channels
+        outs = [self._decode_one(zs.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous())[..., :oc].permute(3, 0, 1, 2) for zs in z]
+        sample = torch.stack(outs)
+        return SimpleNamespace(sample=sample) if return_dict else (sample,)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x [B, 3, T, H, W] in [-1, 1] -> posterior over [B, zc, 1 + (T - 1) / 4, H / 8, W / 8]"""
+        if not x.is_cuda:
+            raise ops.HipOnly("AutoencoderKLCogVideoX.encode: GPU tensors only")
+        moments = torch.stack([self._encode_one(xs.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()).permute(3, 0, 1, 2) for xs in x])
+        posterior = _Posterior(moments)
+        return SimpleNamespace(latent_dist=posterior) if return_dict else (posterior,)

@@ -57,6 +57,8 @@ struct GemmP {
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
+  int cv_tf;          // CONV == 1 with three temporal taps (causal 3x3x3): output frames per sample (input holds cv_tf + 2 frames per sample); 0 = 2-D
+  long long cv_fs;    // elements between consecutive input frames
 };
 
 // zero source for the taps that fall outside the image / clip (never written)
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         const long long r2 = row / p.cv_Wo;
         const int yo = (int)(r2 % p.cv_Ho);
         const long long n = r2 / p.cv_Ho;
-        gsrc[i] = p.A + n * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
+        const long long n_in = p.cv_tf ? n + 2 * (n / p.cv_tf) : n;   // 3-D: sample s's output frame t reads input frames s (T + 2) + t + {0, 1, 2}
+        gsrc[i] = p.A + n_in * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
         cv_y[i] = yo * p.cv_stride - p.cv_pad;
         cv_x[i] = xo * p.cv_stride - p.cv_pad;
       } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row pointer and t
@@ -180,10 +183,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
           bool ok;
           long long off;
           if constexpr (CONV == 1) {
-            const int ky = cv_tap / 3, kx = cv_tap - 3 * ky;
+            const int kt3 = p.cv_tf ? cv_tap / 9 : 0, tap9 = cv_tap - 9 * kt3;   // taps in (kt, ky, kx) order; kt3 = 0 for the 2-D convolution
+            const int ky = tap9 / 3, kx = tap9 - 3 * ky;
             const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
             ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
-            off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C;
+            off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C + kt3 * p.cv_fs;
           } else {
             const int t = cv_y[i] + cv_tap - 1;
             ok = (unsigned)t < (unsigned)p.cv_T;
@@ -814,6 +818,10 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
     // padding 1 / 1: Ho = (Hi + 2 - 3) / stride + 1; padding 0 / 1: Ho = (Hi + 1 - 3) / stride + 1
     p.cv_Ho = (p.cv_Hi + p.cv_pad - 2) / a->stride + 1; p.cv_Wo = (p.cv_Wi + p.cv_pad - 2) / a->stride + 1;
     p.M = (long long)a->N * p.cv_Ho * p.cv_Wo; p.K = 9LL * a->Cin; p.ldw = p.K;
+    if (a->t_taps != 0) {   // causal 3x3x3 over frame stacks that already hold the two leading context frames
+      if (a->t_taps != 3 || a->t_frames <= 0 || a->N % a->t_frames != 0 || a->stride != 1 || a->upsample || a->asym_pad) return MRAG_EINVAL;
+      p.cv_tf = a->t_frames; p.cv_fs = (long long)a->H * a->Wd * a->Cin; p.K = 27LL * a->Cin; p.ldw = p.K;
+    }
     const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
     if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 1>(s, p, a->epilogue);

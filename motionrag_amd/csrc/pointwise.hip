@@ -391,6 +391,50 @@ extern "C" int mrag_softmax_rows_bf16(void* stream, const void* x, void* y, int6
   return MRAG_OK;
 }
 
+namespace {
+// Tile seams of the tiled VAE decode / encode: tile [T, th, tw, C] is blended IN PLACE with the bottom `ev` rows of the tile above (`up`
+// [T, uh, tw, C]) and then with the right `eh` columns of the tile to its left (`left` [T, th, lw, C]) -- both already blended themselves,
+// which is what the in-place loops of diffusers' blend_v / blend_h produce when the tiles are visited row by row.
+__global__ __launch_bounds__(256) void blend_tile_kernel(bf16_t* tile, const bf16_t* up, const bf16_t* left, int T, int th, int tw, int C, int uh, int lw,
+                                                         int ev, int eh) {
+  const long long total = (long long)T * th * tw * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int x = (int)(r % tw); r /= tw;
+    const int y = (int)(r % th);
+    const int t = (int)(r / th);
+    const bool bv = up && y < ev, bh = left && x < eh;
+    if (!bv && !bh) continue;
+    float v = bf2f(tile[i]);
+    if (bv) {
+      const float w = (float)y / (float)ev;
+      v = bf2f(f2bf(bf2f(up[(((long long)t * uh + (uh - ev + y)) * tw + x) * C + c]) * (1.f - w) + v * w));
+    }
+    if (bh) {
+      const float w = (float)x / (float)eh;
+      v = bf2f(left[(((long long)t * th + y) * lw + (lw - eh + x)) * C + c]) * (1.f - w) + v * w;
+    }
+    tile[i] = f2bf(v);
+  }
+}
+}  // namespace
+
+extern "C" int mrag_blend_tile_bf16(void* stream, void* tile, const void* up, const void* left, int32_t T, int32_t th, int32_t tw, int32_t C, int32_t up_h,
+                                    int32_t left_w, int32_t extent_v, int32_t extent_h) {
+  if (!tile || T <= 0 || th <= 0 || tw <= 0 || C <= 0) return MRAG_EINVAL;
+  if ((up && (up_h <= 0 || extent_v <= 0)) || (left && (left_w <= 0 || extent_h <= 0))) return MRAG_EINVAL;
+  if (!up && !left) return MRAG_OK;
+  int ev = extent_v, eh = extent_h;                       // min(a.shape, b.shape, extent) of blend_v / blend_h
+  if (up) { if (ev > up_h) ev = up_h; if (ev > th) ev = th; }
+  if (left) { if (eh > left_w) eh = left_w; if (eh > tw) eh = tw; }
+  const long long total = (long long)T * th * tw * C, blocks = (total + 255) / 256;
+  MRAG_LAUNCH(blend_tile_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)tile, (const bf16_t*)up,
+              (const bf16_t*)left, T, th, tw, C, up_h, left_w, ev, eh);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
 extern "C" int mrag_denormalize_u8(void* stream, const void* x, void* y, int64_t n, int32_t src_fp32) {
   if (!x || !y || n <= 0) return MRAG_EINVAL;
   const long long blocks = (n + 255) / 256;

@@ -37,6 +37,10 @@ struct GnP {
   long long N, HW, C, emb_stride;
   int G, chunks, silu;
   float eps;
+  // spatially conditioned form (CogVideoXSpatialNorm3D): y = gn(x) * mod[.., :C] + mod[.., C:], mod at the latent resolution
+  const bf16_t* mod;
+  int mT, mH, mW, mTz, mshift, msplit;
+  long long y_stride_n;
 };
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
@@ -159,6 +163,45 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p, const float*
   }
 }
 
+// pass 3, spatially conditioned: x [N, (t, y, x), C]; mod [N, Tz, H >> shift, W >> shift, 2C] holds conv_y(zq) | conv_b(zq) at the latent
+// resolution (a 1x1x1 convolution commutes with the nearest-neighbour upsampling in front of it), so the upsampled maps never exist.
+// Frame map = F.interpolate(nearest) of diffusers' CogVideoXSpatialNorm3D: odd T > 1 -> frame 0 from latent frame 0 and the rest
+// resampled separately; otherwise floor(t * Tz / T).  A thread owns one (pixel, 8-channel vector); 256 / (C / 8) pixels per pass.
+__global__ __launch_bounds__(256) void gn_apply_mod_kernel(const GnP p, const float* ab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* abl = (float2*)smem;          // [C]
+  const int n = blockIdx.y;
+  for (int c = threadIdx.x; c < p.C; c += 256) abl[c] = ((const float2*)ab)[(long long)n * p.C + c];
+  __syncthreads();
+  const int C8 = (int)(p.C / 8), ppb = 256 / C8;
+  const int col = threadIdx.x % C8, rsub = threadIdx.x / C8;
+  const int c0 = col * 8;
+  const unsigned HWf = (unsigned)(p.mH * p.mW);
+  const int hz = p.mH >> p.mshift, wz = p.mW >> p.mshift;
+  const bf16_t* xb = p.x + (long long)n * p.HW * p.C;
+  bf16_t* yb = p.y + (long long)n * (p.y_stride_n ? p.y_stride_n : p.HW * p.C);
+  const bf16_t* mb = p.mod + (long long)n * p.mTz * hz * wz * 2 * p.C;
+  for (unsigned px = blockIdx.x * ppb + rsub; px < (unsigned)p.HW; px += gridDim.x * ppb) {
+    const unsigned t = px / HWf, rem = px - t * HWf;
+    const unsigned y = rem / (unsigned)p.mW, x = rem - y * (unsigned)p.mW;
+    unsigned tz;
+    if (p.msplit) tz = t == 0 ? 0u : 1u + ((t - 1) * (unsigned)(p.mTz - 1)) / (unsigned)(p.mT - 1);
+    else tz = (t * (unsigned)p.mTz) / (unsigned)p.mT;
+    const bf16_t* m = mb + (((long long)tz * hz + (y >> p.mshift)) * wz + (x >> p.mshift)) * 2 * p.C + c0;
+    float v[8], my[8], mbv[8];
+    unpack8(*(const u32x4*)(xb + (long long)px * p.C + c0), v);
+    unpack8(*(const u32x4*)m, my);
+    unpack8(*(const u32x4*)(m + p.C), mbv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 w = abl[c0 + e];
+      const float o = (v[e] * w.x + w.y) * my[e] + mbv[e];
+      v[e] = p.silu ? silu_f(o) : o;
+    }
+    *(u32x4*)(yb + (long long)px * p.C + c0) = pack8(v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- conv row gathers
 // dst[(n, yo, xo), (ky, kx, c)] = src[n, yo*stride + ky - 1, xo*stride + kx - 1, c]   (zero outside; src read at (y/2, x/2)
 // of the stored tensor when `up` (nearest x2 upsample fused in front)); columns [9C, Kpad) are zero.
@@ -252,6 +295,13 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   if (a->C % 8 != 0 || a->C % a->G != 0) return MRAG_EINVAL;
   if (a->C > 8192 || a->N > 65535 || a->chunks > 1024) return MRAG_ENOTSUP;
   if (((uintptr_t)a->x | (uintptr_t)a->y) & 15) return MRAG_EINVAL;
+  if (a->mod) {
+    if (a->emb || a->mod_T <= 0 || a->mod_H <= 0 || a->mod_W <= 0 || a->mod_Tz <= 0 || a->mod_shift < 0 || a->mod_shift > 4) return MRAG_EINVAL;
+    if ((int64_t)a->mod_T * a->mod_H * a->mod_W != a->HW || a->HW >= (1LL << 31)) return MRAG_EINVAL;
+    if ((a->mod_H & ((1 << a->mod_shift) - 1)) || (a->mod_W & ((1 << a->mod_shift) - 1))) return MRAG_EINVAL;
+    if (a->mod_split && (a->mod_T < 3 || !(a->mod_T & 1) || a->mod_Tz < 2)) return MRAG_EINVAL;
+    if (a->C > 2048 || 256 % (a->C / 8) != 0 || ((uintptr_t)a->mod & 15) || a->y_stride_n % 8 != 0) return MRAG_EINVAL;
+  } else if (a->y_stride_n != 0) return MRAG_EINVAL;
   GnP p{};
   p.x = (const bf16_t*)a->x; p.y = (bf16_t*)a->y; p.gamma = (const bf16_t*)a->gamma; p.beta = (const bf16_t*)a->beta;
   p.emb = (const bf16_t*)a->emb; p.part = (float*)a->workspace;
@@ -264,6 +314,17 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   MRAG_LAUNCH(gn_fold_kernel, dim3((unsigned)a->G, (unsigned)a->N), dim3(256), 0, s, p, ab);
   MRAG_LAUNCH_CHECK();
   const size_t lds = (size_t)a->C * 2 * sizeof(float);
+  if (a->mod) {
+    p.mod = (const bf16_t*)a->mod; p.mT = a->mod_T; p.mH = a->mod_H; p.mW = a->mod_W; p.mTz = a->mod_Tz; p.mshift = a->mod_shift; p.msplit = a->mod_split;
+    p.y_stride_n = a->y_stride_n;
+    const int ppb = 256 / (int)(a->C / 8);
+    long long bxm = (a->HW + 4LL * ppb - 1) / (4LL * ppb);      // >= 4 pixels per thread
+    const long long capm = 8192 / a->N > 16 ? 8192 / a->N : 16;
+    if (bxm > capm) bxm = capm;
+    MRAG_LAUNCH(gn_apply_mod_kernel, dim3((unsigned)bxm, (unsigned)a->N), dim3(256), lds, s, p, (const float*)ab);
+    MRAG_LAUNCH_CHECK();
+    return MRAG_OK;
+  }
   long long bx = (a->HW * (a->C / 8) + 1023) / 1024;          // >= 4 vectors per thread
   const long long cap = 4096 / a->N > 16 ? 4096 / a->N : 16;
   if (bx > cap) bx = cap;

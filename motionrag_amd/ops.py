@@ -418,6 +418,26 @@ def weighted_sum(x: torch.Tensor, w: Optional[torch.Tensor], div: float = 1.0) -
     return out
 
 
+def blend_tile(tile: torch.Tensor, up: Optional[torch.Tensor], left: Optional[torch.Tensor], extent_v: int, extent_h: int) -> torch.Tensor:
+    """in-place seam blend of a VAE tile [T, th, tw, C] with its (already blended) upper / left neighbours (mrag_hip.h)"""
+    _dev(tile, name="tile")
+    if tile.dim() != 4 or not tile.is_contiguous():
+        raise ValueError("blend_tile: contiguous [T, th, tw, C] required")
+    T, th, tw, C = tile.shape
+    for nb, nm in ((up, "up"), (left, "left")):
+        if nb is not None:
+            _dev(nb, name=nm)
+            if nb.dim() != 4 or not nb.is_contiguous() or nb.shape[0] != T or nb.shape[3] != C:
+                raise ValueError(f"blend_tile: {nm} must be a contiguous [T, ., ., C] tile")
+    if up is not None and up.shape[2] != tw:
+        raise ValueError("blend_tile: the tile above must have the tile's width")
+    if left is not None and left.shape[1] != th:
+        raise ValueError("blend_tile: the tile to the left must have the tile's height")
+    check(_lib.lib().mrag_blend_tile_bf16(_stream(), _p(tile), _p(up), _p(left), T, th, tw, C, up.shape[1] if up is not None else 0,
+                                          left.shape[2] if left is not None else 0, extent_v, extent_h), "mrag_blend_tile_bf16")
+    return tile
+
+
 def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(scale * x, dim=-1) of a 2-D bf16 score matrix (fp32 statistics); the row stride may exceed the width"""
     _dev(x, name="x")
@@ -551,8 +571,12 @@ class TopkPlan:
 
 # ---------------------------------------------------------------------------------------------- UNet ops (channels-last rows)
 def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int, eps: float, *, silu: bool = False,
-              emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.GroupNorm over x [N, HW, C] (channels-last) [+ per-(n, c) `emb` added before the statistics] [+ SiLU]."""
+              emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, mod: Optional[torch.Tensor] = None,
+              mod_geom: Optional[tuple] = None) -> torch.Tensor:
+    """nn.GroupNorm over x [N, HW, C] (channels-last) [+ per-(n, c) `emb` added before the statistics] [+ SiLU].
+    `mod` [N, Tz, hz, wz, 2C] + `mod_geom` = (T, H, W, shift, split): the spatially conditioned form gn(x) * mod[.., :C] + mod[.., C:] with the
+    latent-resolution maps read through the nearest-neighbour frame / pixel map (mrag_hip.h); `out` may then be a [N, HW, C] view whose
+    sample stride is larger than HW * C (the frames behind a causal convolution's context frames)."""
     from ._lib import GroupNormArgs
     _dev(x, name="x")
     if x.dim() != 3 or not x.is_contiguous():
@@ -560,6 +584,8 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     N, HW, C = x.shape
     if out is None:
         out = torch.empty_like(x)
+    elif out.shape != x.shape or out.stride(2) != 1 or out.stride(1) != C or (mod is None and not out.is_contiguous()):
+        raise ValueError("groupnorm: out must have x's shape with contiguous rows")
     chunks = max(1, min(1024, HW // 32, max(64, -(-2048 // N))))        # >= ~2048 statistics workgroups even when N is 1 or 2
     L = _lib.lib()
     ws = _attn_workspace(x.device, L.mrag_groupnorm_workspace_bytes(N, C, chunks), "gn")     # grow-only per (device, stream): no allocation per call
@@ -571,6 +597,13 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
         if emb.shape != (N, C) or emb.stride(1) != 1:
             raise ValueError("emb must be [N, C] with contiguous channels")
         a.emb, a.emb_stride = _p(emb), emb.stride(0)
+    if mod is not None:
+        _dev(mod, name="mod")
+        T, H, W, shift, split = mod_geom
+        if not mod.is_contiguous() or mod.dim() != 5 or mod.shape[0] != N or tuple(mod.shape[2:]) != (H >> shift, W >> shift, 2 * C):
+            raise ValueError(f"groupnorm: mod {tuple(mod.shape)} does not match geometry {mod_geom} and C = {C}")
+        a.mod, a.mod_T, a.mod_H, a.mod_W, a.mod_Tz, a.mod_shift, a.mod_split = _p(mod), T, H, W, mod.shape[1], shift, 1 if split else 0
+        a.y_stride_n = out.stride(0) if N > 1 else 0
     check(L.mrag_groupnorm_bf16(_stream(), ctypes.byref(a)), "mrag_groupnorm_bf16")
     return out
 
@@ -579,9 +612,11 @@ CONV_3X3, CONV_T3 = 1, 2
 
 
 def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor], mode: int, *, stride: int = 1, upsample: bool = False,
-                  frames: int = 0, resid: Optional[torch.Tensor] = None, asym_pad: bool = False) -> torch.Tensor:
+                  frames: int = 0, resid: Optional[torch.Tensor] = None, asym_pad: bool = False, t_frames: int = 0) -> torch.Tensor:
     """implicit-GEMM convolution (no materialised im2col), Cin % 64 == 0.
     CONV_3X3: x [N, H, W, Cin] -> [N, Ho, Wo, Cout], wk [Cout, 9 Cin] in (ky, kx, cin) order.
+              t_frames = T > 0: causal 3x3x3 -- x [S (T + 2), H, W, Cin] (two context frames in front of each sample's T frames) -> [S T, H, W, Cout],
+              wk [Cout, 27 Cin] in (kt, ky, kx, cin) order.
     CONV_T3:  x [(b t), HW, Cin] with `frames` = t -> same rows x Cout, wk [Cout, 3 Cin] in (kt, cin) order."""
     from ._lib import ConvArgs
     _dev(x, name="x"); _dev(wk, name="weight")
@@ -591,11 +626,16 @@ def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor
     cout = wk.shape[0]
     if mode == CONV_3X3:
         N, H, W, C = x.shape
+        taps = 9
+        if t_frames:
+            if N % (t_frames + 2):
+                raise ValueError("conv_implicit: x must hold t_frames + 2 frames per sample")
+            N = N // (t_frames + 2) * t_frames
+            a.t_taps, a.t_frames, taps = 3, t_frames, 27
         Hi, Wi = (2 * H, 2 * W) if upsample else (H, W)
         front = 0 if asym_pad else 1                         # asym_pad: F.pad(x, (0, 1, 0, 1)) + stride-2 convolution without padding (KL-VAE Downsample)
         out = torch.empty(N, (Hi + front - 2) // stride + 1, (Wi + front - 2) // stride + 1, cout, dtype=torch.bfloat16, device=x.device)
         a.N, a.H, a.Wd, a.stride, a.upsample, a.asym_pad = N, H, W, stride, 1 if upsample else 0, 1 if asym_pad else 0
-        taps = 9
     else:
         NT, HW, C = x.shape
         if frames <= 0 or NT % frames:

@@ -704,6 +704,12 @@ inline bool wide_n_pays(long long N, int tuning = 0) {
   return w320 * 100 < w256 * 90;                   // at least 10 % fewer padded columns
 }
 
+// the VAEs' finest levels are 128 channels wide: a 256-wide tile grid computes as many masked columns as real ones there
+inline bool narrow_n_pays(long long N) {
+  const long long r = N % 256;
+  return r != 0 && r <= 128;
+}
+
 template <int WM, int WN, int TM, int TN, int CONV = 0>
 int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -824,6 +830,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
     }
     const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
+    if (t256 >= 192 && narrow_n_pays(p.N)) return launch_cfg<4, 2, 4, 4, 1>(s, p, a->epilogue);   // 256x128 tile, 8 waves of 64x64
     if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 1>(s, p, a->epilogue);
     return launch_cfg<2, 2, 4, 4, 1>(s, p, a->epilogue);
   }

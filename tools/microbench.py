@@ -310,6 +310,36 @@ def svd_vae(frames=14, h=72, w=128):
             "encode_frame_ms": round(de * 1e3, 2)}
 
 
+def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
+    """CogVideoX-5B's 3-D causal VAE (215.6 M parameters, random-init): decode one clip's final latents [1, 16, 13, 60, 90] -> 49 frames of 480 x 720
+    as the reference configures it (cogvideox/module.py:39-40: tiling + slicing -> nine 30 x 45 latent tiles of six frame batches each), the untiled decode
+    beside it, and the tiled encode of the conditioning image"""
+    from motionrag_amd.cogvideox_vae import AutoencoderKLCogVideoX
+    torch.manual_seed(0)
+    m = AutoencoderKLCogVideoX().to(DEV, torch.bfloat16)
+    z = torch.randn(1, 16, frames, h, w, device=DEV).to(torch.bfloat16)
+    res = {}
+    for name, tiled in (("tiled", True), ("untiled", False)):
+        if tiled and not tiling:
+            continue
+        m.enable_tiling() if tiled else m.disable_tiling()
+        out = {}
+        fl = count_flops(lambda: out.setdefault("y", m.decode(z).sample))
+        assert out["y"].shape == (1, 3, 1 + 4 * (frames - 1), 8 * h, 8 * w) and torch.isfinite(out["y"].float()).all()
+        del out
+        dt = timeit(lambda: m.decode(z), iters=2, warm=1)
+        print(f"CogVideoX VAE decode ({name}) {frames} latent frames -> {1 + 4 * (frames - 1)}x{8*h}x{8*w}: {dt*1e3:.0f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.0f} TFLOP")
+        res[f"decode_{name}_ms_per_clip"] = round(dt * 1e3)
+        res[f"decode_{name}_tflop"] = round(fl / 1e12, 1)
+        res[f"decode_{name}_tflops_per_s"] = round(fl / dt / 1e12)
+    m.enable_tiling()
+    img = (torch.rand(1, 3, 1, 8 * h, 8 * w, device=DEV) * 2 - 1).to(torch.bfloat16)
+    de = timeit(lambda: m.encode(img), iters=3, warm=1)
+    print(f"CogVideoX VAE encode of the conditioning image (tiled): {de*1e3:.1f} ms")
+    res["encode_image_ms"] = round(de * 1e3, 1)
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "gemm", "topk", "norm"]
     for w in which:

@@ -91,13 +91,21 @@ def _causal3(stack: torch.Tensor, mod: CogVideoXCausalConv3d, cache: Dict, resid
     return y
 
 
-def _cond_maps(norm: CogVideoXSpatialNorm3D, zq64: torch.Tensor) -> torch.Tensor:
-    """conv_y(zq) | conv_b(zq) at the latent resolution: [1, Tz, h, w, 2C]"""
+def _cond_weights(norm: CogVideoXSpatialNorm3D) -> Tuple[torch.Tensor, torch.Tensor]:
     def build():
         wy, wb = (_b(c.conv.weight).reshape(c.conv.weight.shape[0], -1) for c in (norm.conv_y, norm.conv_b))
         w = _pad_channels(torch.cat([wy, wb]))
         return w.contiguous(), torch.cat([_b(norm.conv_y.conv.bias), _b(norm.conv_b.conv.bias)]).contiguous()
-    w, b = _CACHE.get(("cvxyb", id(norm)), (norm.conv_y.conv.weight, norm.conv_b.conv.weight, norm.conv_y.conv.bias, norm.conv_b.conv.bias), build)
+    return _CACHE.get(("cvxyb", id(norm)), (norm.conv_y.conv.weight, norm.conv_b.conv.weight, norm.conv_y.conv.bias, norm.conv_b.conv.bias), build)
+
+
+def _w1(sc: nn.Conv3d) -> torch.Tensor:
+    return _CACHE.get(("cvx1", id(sc)), sc.weight, lambda: _b(sc.weight).reshape(sc.weight.shape[0], -1).contiguous())
+
+
+def _cond_maps(norm: CogVideoXSpatialNorm3D, zq64: torch.Tensor) -> torch.Tensor:
+    """conv_y(zq) | conv_b(zq) at the latent resolution: [1, Tz, h, w, 2C]"""
+    w, b = _cond_weights(norm)
     Tz, h, wd, _ = zq64.shape
     return ops.linear(zq64.view(Tz * h * wd, -1), w, b).view(1, Tz, h, wd, -1)
 
@@ -133,9 +141,7 @@ class CogVideoXResnetBlock3D(nn.Module):
         h = _causal3(_norm_into_stack(x, self.norm1, zq64, self.groups, self.eps), self.conv1, cache)
         stack = _norm_into_stack(h, self.norm2, zq64, self.groups, self.eps)
         if hasattr(self, "conv_shortcut"):
-            sc = self.conv_shortcut
-            w = _CACHE.get(("cvx1", id(sc)), sc.weight, lambda: _b(sc.weight).reshape(sc.weight.shape[0], -1).contiguous())
-            x = ops.linear(x, w, _b(sc.bias))
+            x = ops.linear(x, _w1(self.conv_shortcut), _b(self.conv_shortcut.bias))
         return _causal3(stack, self.conv2, cache, resid=x.contiguous())
 
 
@@ -151,6 +157,7 @@ class _Resnets(nn.Module):
 
 
 _DOUBLING: Dict = {}
+_STREAMS: Dict = {}
 
 
 def _frame_doubling(T: int, device) -> torch.Tensor:
@@ -292,6 +299,7 @@ class AutoencoderKLCogVideoX(nn.Module):
         self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, block_out_channels=tuple(block_out_channels), latent_channels=latent_channels,
                                       temporal_compression_ratio=temporal_compression_ratio, sample_height=sample_height, sample_width=sample_width,
                                       scaling_factor=scaling_factor, invert_scale_latents=False)
+        self.tile_streams = 3                                                    # HIP streams the tiles of a tiled decode / encode are spread over
         self.use_tiling = self.use_slicing = False                              # slicing is how this class always runs (one sample at a time)
         self.num_latent_frames_batch_size, self.num_sample_frames_batch_size = 2, 8
         down = 2 ** (len(block_out_channels) - 1)
@@ -323,9 +331,44 @@ class AutoencoderKLCogVideoX(nn.Module):
         cache: Dict = {}
         return torch.cat([net(x[a:b].contiguous(), cache) for a, b in frame_batches(x.shape[0], batch)])
 
+    def _warm(self, net) -> None:
+        """build every repacked weight on the CURRENT stream, so that tiles fanned out over side streams only read the cache"""
+        for mod in net.modules():
+            if isinstance(mod, CogVideoXSpatialNorm3D):
+                _cond_weights(mod)
+            elif isinstance(mod, CogVideoXCausalConv3d) and mod.conv.kernel_size[0] == 3:
+                _w27(mod, 1 if mod.conv.out_channels % 4 else 0)
+            elif isinstance(mod, nn.Conv2d):
+                _w9(mod)
+            elif isinstance(mod, CogVideoXResnetBlock3D) and hasattr(mod, "conv_shortcut"):
+                _w1(mod.conv_shortcut)
+
     def _tiled(self, net, x: torch.Tensor, batch: int, tile: Tuple[int, int], overlap: Tuple[int, int], blend: Tuple[int, int], limit: Tuple[int, int]) -> torch.Tensor:
+        """tiles are independent until the seams: they are issued round-robin over `tile_streams` HIP streams, so that the coarse levels' launches of one tile
+        (a 30 x 45 latent tile of two frames is 2 700 GEMM rows: a third of the chip) overlap another tile's; the blend waits for all of them"""
         H, W = x.shape[1:3]
-        rows = [[self._batched(net, x[:, i:i + tile[0], j:j + tile[1]], batch) for j in range(0, W, overlap[1])] for i in range(0, H, overlap[0])]
+        origins = [(i, j) for i in range(0, H, overlap[0]) for j in range(0, W, overlap[1])]
+        cols = len(range(0, W, overlap[1]))
+        cur = torch.cuda.current_stream(x.device)
+        n = max(1, min(self.tile_streams, len(origins)))
+        flat: List[torch.Tensor] = []
+        if n == 1:
+            flat = [self._batched(net, x[:, i:i + tile[0], j:j + tile[1]], batch) for i, j in origins]
+        else:
+            self._warm(net)
+            key = (str(x.device), n)
+            if key not in _STREAMS:
+                _STREAMS[key] = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+            for k, (i, j) in enumerate(origins):
+                side = _STREAMS[key][k % n]
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    t = self._batched(net, x[:, i:i + tile[0], j:j + tile[1]], batch)
+                t.record_stream(cur)
+                flat.append(t)
+            for side in _STREAMS[key]:
+                cur.wait_stream(side)
+        rows = [flat[r * cols:(r + 1) * cols] for r in range(len(flat) // cols)]
         strips = []
         for i, row in enumerate(rows):
             for j, t in enumerate(row):

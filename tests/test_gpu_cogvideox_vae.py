@@ -119,6 +119,18 @@ def test_encode_matches_oracle(hip, frames, hw, tiling):
     assert rel(post.sample(noise=noise.to(DEV)), want_s) < 3e-2
 
 
+def test_tiles_on_side_streams_equal_serial_tiles(hip):
+    m, _ = _model(TOY, 15)
+    m.enable_tiling()
+    g = torch.Generator().manual_seed(9)
+    z = bf(torch.randn(1, 16, 5, 12, 20, generator=g)).to(DEV)
+    m.tile_streams = 1
+    serial = m.decode(z).sample
+    m.tile_streams = 3
+    for _ in range(3):
+        assert torch.equal(m.decode(z).sample, serial)
+
+
 def test_pipeline_decode_latents_through_the_vae(hip):
     """CogVideoXImageToVideoCTPipeline.decode_latents (1 / scaling_factor, [b, F, 16, h, w] -> [b, 3, f, H, W]) on this class"""
     from motionrag_amd.cogvideox import CogVideoXImageToVideoCTPipeline

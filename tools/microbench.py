@@ -319,10 +319,11 @@ def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
     m = AutoencoderKLCogVideoX().to(DEV, torch.bfloat16)
     z = torch.randn(1, 16, frames, h, w, device=DEV).to(torch.bfloat16)
     res = {}
-    for name, tiled in (("tiled", True), ("untiled", False)):
+    for name, tiled in (("tiled", True), ("tiled_one_stream", True), ("untiled", False)):
         if tiled and not tiling:
             continue
         m.enable_tiling() if tiled else m.disable_tiling()
+        m.tile_streams = 1 if name == "tiled_one_stream" else 3
         out = {}
         fl = count_flops(lambda: out.setdefault("y", m.decode(z).sample))
         assert out["y"].shape == (1, 3, 1 + 4 * (frames - 1), 8 * h, 8 * w) and torch.isfinite(out["y"].float()).all()
@@ -333,6 +334,7 @@ def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
         res[f"decode_{name}_tflop"] = round(fl / 1e12, 1)
         res[f"decode_{name}_tflops_per_s"] = round(fl / dt / 1e12)
     m.enable_tiling()
+    m.tile_streams = 3
     img = (torch.rand(1, 3, 1, 8 * h, 8 * w, device=DEV) * 2 - 1).to(torch.bfloat16)
     de = timeit(lambda: m.encode(img), iters=3, warm=1)
     print(f"CogVideoX VAE encode of the conditioning image (tiled): {de*1e3:.1f} ms")

@@ -301,6 +301,7 @@ def main():
             guarded("retrieval_top12_768d", lambda: mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1))))
             guarded("dynamicrafter_kl_vae_decode_16x576x1024", mb.vae)                 # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
             guarded("svd_temporal_vae_14x576x1024", mb.svd_vae)                         # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
+            guarded("cogvideox_3d_causal_vae_49x480x720", mb.cogvideox_vae)             # SURVEY 8f rank 2 (the headline pipeline's VAE, tiled as the reference configures it; oracle unpinned)
             guarded("t5_xxl_prompt_encoder_2x226", mb.t5)                               # SURVEY 8f rank 4 (CogVideoX's text encoder)
             guarded("rag_side_encoders_plus_cama", mb.encoders)                         # VideoMAE-B + DINOv2-L + CAMA from raw pixels
 

@@ -321,3 +321,42 @@ def test_dynamicrafter_pipeline_all_native_components(hip, golden_dir):
                     unconditional_guidance_scale=2.0, frame_stride=15, ref_videos=ref_videos.to(DEV), x_T=x_T, noises=noises)
     a, b = run(), run()
     assert a.shape == (1, 4, 3, 64, 64) and torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
+def test_cogvideox_ct_pipeline_all_native_components(hip):
+    """CogVideoXImageToVideoCTPipeline with the DiT, the T5 prompt encoder (`t5`) and the 3-D causal VAE (`cogvideox_vae`, image encode + decode) on the HIP path:
+    the call equals the same components driven by hand (prompt ids -> T5, image -> posterior sample -> 0.7 z, hot loop, 1 / 0.7 -> decode -> [0, 1])."""
+    from motionrag_amd import cogvideox as cvx, t5
+    from motionrag_amd.cogvideox_vae import AutoencoderKLCogVideoX
+    cfg, sd, dit = _small_dit()
+    torch.manual_seed(2)
+    vae = AutoencoderKLCogVideoX(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=8, sample_height=64, sample_width=96).to(DEV, torch.bfloat16)
+    text = t5.T5EncoderModel(vocab_size=128, d_model=64, d_ff=128, num_layers=2, num_heads=2).to(DEV, torch.bfloat16)
+
+    class Tok:
+        def __call__(self, texts, max_length=226, **_):
+            ids = torch.zeros(len(texts), 10, dtype=torch.long)
+            for r, t in enumerate(texts):
+                w = [1 + ord(c) % 120 for c in t][:9]
+                ids[r, :len(w)] = torch.tensor(w)
+            return type("Enc", (), {"input_ids": ids})()
+    cama = StubCAMA()
+    pipe = cvx.CogVideoXImageToVideoCTPipeline(tokenizer=Tok(), text_encoder=text, vae=vae, transformer=dit, scheduler=cvx.CogVideoXDDIMScheduler(),
+                                               condition_transformer=cama)
+    image, ref_videos, metadata = _pipe_inputs()
+    kw = dict(num_frames=9, num_inference_steps=2, guidance_scale=6.0, height=64, width=96)
+    out = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="pt", ref_videos=ref_videos, metadata=metadata,
+               generator=torch.Generator().manual_seed(3), **kw).frames
+    assert out.shape == (1, 9, 3, 64, 96) and torch.isfinite(out.float()).all() and 0.0 <= out.min().item() and out.max().item() <= 1.0
+    lat = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+               generator=torch.Generator().manual_seed(3), **kw).frames
+    by_hand = vae.decode(lat.permute(0, 2, 1, 3, 4).float() / 0.7).sample                         # [1, 3, 9, 64, 96]
+    want = (by_hand.permute(0, 2, 1, 3, 4).float() / 2 + 0.5).clamp(0, 1)
+    assert ((out.float() - want.float().to(out.device)).norm() / want.float().norm()).item() < 1e-2
+    # the image latents the loop was conditioned on: posterior sample with the generator's draw, times the scaling factor, zero-padded in time
+    g = torch.Generator().manual_seed(3)
+    il = pipe.encode_image_latents(image / 2 + 0.5, 3, generator=g)
+    post = vae.encode((image / 2 + 0.5).float().mul(2).sub(1).unsqueeze(2)).latent_dist
+    g2 = torch.Generator().manual_seed(3)
+    want_il = post.sample(g2) * 0.7
+    assert il.shape == (1, 3, 8, 8, 12) and torch.equal(il[:, 0], want_il[:, :, 0]) and il[:, 1:].abs().max().item() == 0

@@ -323,7 +323,7 @@ def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
         if tiled and not tiling:
             continue
         m.enable_tiling() if tiled else m.disable_tiling()
-        m.tile_streams = 1 if name == "tiled_one_stream" else 3
+        m.tile_streams = 1 if name == "tiled_one_stream" else int(os.environ.get("MRAG_VAE_STREAMS", "3"))
         out = {}
         fl = count_flops(lambda: out.setdefault("y", m.decode(z).sample))
         assert out["y"].shape == (1, 3, 1 + 4 * (frames - 1), 8 * h, 8 * w) and torch.isfinite(out["y"].float()).all()

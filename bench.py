@@ -355,6 +355,18 @@ def main():
                          "launches": len(durs), "avg_launch_ms": round(avg * 1e3, 4) if durs else None,
                          "algorithmic_tflop_per_launch": round(flops / 1e12, 3)},
         }
+        try:     # whole-clip time of the reference's eval path (README.md:47-48 quotes s/clip): every stage is a component measured in THIS run, at the shipped model sizes
+            sw = secondary or {}
+            parts = {"prompt_encoder_t5_xxl_ms": sw["t5_xxl_prompt_encoder_2x226"]["ms"],
+                     "image_vae_encode_tiled_ms": sw["cogvideox_3d_causal_vae_49x480x720"]["encode_image_ms"],
+                     "retrieval_top12_of_1M_ms": round(sw["retrieval_top12_768d"]["N1000000_Q1"]["us"] * 1e-3, 3),
+                     "videomae_dinov2_cama_from_pixels_ms": sw["rag_side_encoders_plus_cama"]["cama_predict_from_pixels_ms"],
+                     "denoise_50_steps_s": round(e2e_sec, 2),
+                     "vae_decode_tiled_49x480x720_ms": sw["cogvideox_3d_causal_vae_49x480x720"]["decode_tiled_ms_per_clip"]}
+            parts["total_s"] = round(parts["denoise_50_steps_s"] + 1e-3 * sum(v for k, v in parts.items() if k.endswith("_ms")), 2)
+            out["e2e_sec_per_clip_full_pipeline"] = parts
+        except (KeyError, TypeError):
+            out["e2e_sec_per_clip_full_pipeline"] = None      # a stage was not measured in this run (--no-secondary / --no-e2e / N > 1)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only (other ranks would idle in the barrier)
             dt, fl, what = cpu_baseline_sample()
             full = dt * (step_flops / fl)

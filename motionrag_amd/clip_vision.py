@@ -165,8 +165,10 @@ class OpenCLIPVisual(nn.Module):
 
 class FrozenOpenCLIPImageEmbedderV2(nn.Module):
     """lvdm/modules/encoders/condition.py:302-380: `forward(image [b, c, h, w] in [-1, 1])` -> tokens [b, 257, 1280] for the image Resampler.  The reference's
-    `preprocess` is kornia's antialiased bicubic resize (align_corners=True) + CLIP normalisation -- third-party and absent here: pass it as `preprocess=` (any callable
-    [b, 3, h, w] -> normalised [b, 3, 224, 224]); the default resizes with torch's antialiased bicubic through the fused pixel kernel, which is NOT kornia's arithmetic."""
+    `preprocess` (:328-336) is `kornia.geometry.resize(x, (224, 224), 'bicubic', align_corners=True, antialias)` + `(x + 1) / 2` + CLIP normalisation.  kornia is third-party and
+    absent here; its published algorithm (Gaussian blur with skimage's sigma rule and a reflect border, then ATen's align_corners bicubic) is linear and separable, so
+    `encoders.kornia_resize_taps` folds blur and interpolation into one tap table per axis and the fused pixel kernel writes the normalised 224 x 224 image straight as
+    patch-GEMM rows (oracle/kornia_resize_ref.py, parity unpinned).  `preprocess=` overrides it with any callable [b, 3, h, w] -> normalised [b, 3, 224, 224]."""
 
     MEAN, STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
 
@@ -191,7 +193,8 @@ class FrozenOpenCLIPImageEmbedderV2(nn.Module):
             raise ops.HipOnly("FrozenOpenCLIPImageEmbedderV2: GPU tensors only")
         v = self.model.visual
         B = x.shape[0]
-        rows = pixels_to_patch_rows(x[:, None], resize=224, crop=224, mode="bicubic", patch=(1, v.patch_size_, v.patch_size_), mean=self.MEAN, std=self.STD)
+        rows = pixels_to_patch_rows(x[:, None], resize=224, crop=224, mode="kornia-bicubic" if self.antialias else "kornia-bicubic-noaa",
+                                    patch=(1, v.patch_size_, v.patch_size_), mean=self.MEAN, std=self.STD)
         # rows are already the patch-GEMM operand: run the tower from them (same code path as `tokens`, minus the identity pixel pass)
         layers = [(r.ln_1, _b(r.attn.in_proj_weight), _b(r.attn.in_proj_bias), r.attn.out_proj, r.ln_2, r.mlp.c_fc, r.mlp.c_proj) for r in v.transformer.resblocks]
         return _tower_from_rows(rows, B, 224 // v.patch_size_, v.conv1, v.class_embedding, v.positional_embedding, v.ln_pre, layers, v.heads, v.head_dim, v.ln_pre.eps, id(v))

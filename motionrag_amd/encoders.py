@@ -89,14 +89,76 @@ def resize_taps(in_size: int, out_size: int, mode: str, first: int = 0, count: O
     return W, start, n
 
 
+def kornia_resize_taps(in_size: int, out_size: int, sigma: float, ksize: int):
+    """One axis of `kornia.geometry.resize(..., interpolation='bicubic', align_corners=True, antialias=True)` (the `preprocess` of the reference's OpenCLIP image
+    embedders, lvdm/modules/encoders/condition.py:328-336) as ONE tap table: the library blurs with a normalised Gaussian window (reflect border) and then runs
+    ATen's bicubic interpolation (A = -0.75, align_corners=True, clamped indices); both are linear along the axis, so row i of their product
+    bicubic[out, in] @ blur[in, in] is the span of source pixels output i reads.  `ksize` = 1 means no blur (not downscaling).  Built in float64, returned as
+    (weights [out, taps] fp32, start [out] int32, n [out] int32) like `resize_taps`."""
+    blur = np.zeros((in_size, in_size))
+    if ksize > 1:
+        x = np.arange(ksize, dtype=np.float64) - ksize // 2
+        g = np.exp(-x ** 2 / (2.0 * sigma ** 2))
+        g /= g.sum()
+        for r in range(in_size):
+            for m in range(ksize):
+                j = r + m - ksize // 2
+                j = -j if j < 0 else (2 * (in_size - 1) - j if j >= in_size else j)          # F.pad(mode='reflect'): the edge pixel is not repeated
+                blur[r, j] += g[m]
+    else:
+        blur[np.arange(in_size), np.arange(in_size)] = 1.0
+    A = -0.75
+    c1 = lambda v: ((A + 2.0) * v - (A + 3.0)) * v * v + 1.0
+    c2 = lambda v: ((A * v - 5.0 * A) * v + 8.0 * A) * v - 4.0 * A
+    scale = (in_size - 1) / (out_size - 1) if out_size > 1 else 0.0
+    full = np.zeros((out_size, in_size))
+    for i in range(out_size):
+        real = scale * i
+        ix = int(np.floor(real))
+        t = real - ix
+        for k, c in enumerate((c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t))):
+            full[i] += c * blur[min(max(ix - 1 + k, 0), in_size - 1)]
+    spans = []
+    for i in range(out_size):
+        nz = np.nonzero(full[i])[0]
+        spans.append((int(nz[0]), full[i, nz[0]:nz[-1] + 1]))
+    taps = max(len(w) for _, w in spans)
+    W = np.zeros((out_size, taps), dtype=np.float32)
+    start = np.zeros(out_size, dtype=np.int32)
+    n = np.zeros(out_size, dtype=np.int32)
+    for r, (x0, w) in enumerate(spans):
+        W[r, :len(w)] = w.astype(np.float32)
+        start[r], n[r] = x0, len(w)
+    return W, start, n
+
+
+def kornia_blur_geometry(H: int, W: int, oh: int, ow: int):
+    """sigma and window size per axis of kornia's antialiasing blur (skimage's rule): only when downscaling, then on both axes"""
+    fy, fx = H / oh, W / ow
+    if max(fy, fx) <= 1:
+        return (0.0, 1), (0.0, 1)
+    out = []
+    for f in (fy, fx):
+        sigma = max((f - 1.0) / 2.0, 0.001)
+        k = int(max(2.0 * 2 * sigma, 3))
+        out.append((sigma, k + 1 if k % 2 == 0 else k))
+    return tuple(out)
+
+
 class _PixelPlan:
-    """tap tables of one (source H x W) -> Resize(resize) -> CenterCrop(crop) geometry, resident on the device"""
+    """tap tables of one (source H x W) -> Resize(resize) -> CenterCrop(crop) geometry, resident on the device; mode 'kornia-bicubic' / 'kornia-bicubic-noaa':
+    the squashing resize to crop x crop of `kornia.geometry.resize` (no crop)"""
 
     def __init__(self, H: int, W: int, resize: int, crop: int, mode: str, device):
-        nh, nw = resize_output_size(H, W, resize)
-        top, left = center_crop_offsets(nh, nw, crop, crop)
-        wy, y0, ny = resize_taps(H, nh, mode, top, crop)
-        wx, x0, nx = resize_taps(W, nw, mode, left, crop)
+        if mode.startswith("kornia-bicubic"):
+            (sy, ky), (sx, kx) = kornia_blur_geometry(H, W, crop, crop) if mode == "kornia-bicubic" else ((0.0, 1), (0.0, 1))
+            wy, y0, ny = kornia_resize_taps(H, crop, sy, ky) if H != crop or W != crop else kornia_resize_taps(H, H, 0.0, 1)
+            wx, x0, nx = kornia_resize_taps(W, crop, sx, kx) if H != crop or W != crop else kornia_resize_taps(W, W, 0.0, 1)
+        else:
+            nh, nw = resize_output_size(H, W, resize)
+            top, left = center_crop_offsets(nh, nw, crop, crop)
+            wy, y0, ny = resize_taps(H, nh, mode, top, crop)
+            wx, x0, nx = resize_taps(W, nw, mode, left, crop)
         up = lambda a: torch.from_numpy(a).to(device)
         self.wy, self.y0, self.ny, self.wx, self.x0, self.nx = up(wy), up(y0), up(ny), up(wx), up(x0), up(nx)
         self.taps_y, self.taps_x, self.crop = wy.shape[1], wx.shape[1], crop

@@ -94,7 +94,25 @@ def test_openclip_visual_tower_under_open_clip_names(hip, golden_dir):
     emb = C.FrozenOpenCLIPImageEmbedderV2(v.to(DEV, torch.bfloat16), preprocess=lambda x: x)          # the fixture's pixel_values are already normalised
     z = emb(torch.from_numpy(G["pixel_values"]).to(DEV))
     assert z.shape == (3, (img // patch) ** 2 + 1, d) and rel(z, torch.from_numpy(G["last_hidden_state"])) <= 2e-2
-    # built-in preprocess (torch-style antialiased bicubic to 224 + CLIP normalisation, fused into the pixel kernel): runs at the shipped geometry
+    # built-in preprocess (kornia's antialiased bicubic squash to 224 x 224 + CLIP normalisation, fused into the pixel kernel) at the shipped geometry:
+    # equal to the tower run on the oracle's preprocessed pixels
+    from oracle import kornia_resize_ref as K
     big = C.FrozenOpenCLIPImageEmbedderV2(width=160, layers=1, heads=2, mlp_ratio=2.0).to(DEV, torch.bfloat16)
-    t = big(torch.rand(2, 3, 320, 512, device=DEV) * 2 - 1)
-    assert t.shape == (2, 257, 160) and torch.isfinite(t.float()).all()
+    x = (torch.rand(2, 3, 320, 512) * 2 - 1).to(torch.bfloat16)
+    t = big(x.to(DEV))
+    by_hand = C.FrozenOpenCLIPImageEmbedderV2(big.model.visual, preprocess=lambda im: K.preprocess(im.float().cpu()).to(DEV, torch.bfloat16))(x.to(DEV))
+    assert t.shape == (2, 257, 160) and rel(t, by_hand) <= 1e-2
+
+
+@pytest.mark.parametrize("H,W,antialias", [(576, 1024, True), (320, 512, True), (100, 300, True), (150, 180, True), (224, 224, True), (576, 1024, False)])
+def test_kornia_preprocess_pixels_match_oracle(hip, H, W, antialias):
+    """the fused pixel kernel with the folded blur x bicubic tap tables against the two-stage restatement of kornia.geometry.resize + normalize (parity unpinned)"""
+    from motionrag_amd.encoders import pixels_to_patch_rows
+    from oracle import kornia_resize_ref as K
+    g = torch.Generator().manual_seed(H + W)
+    x = (torch.rand(2, 3, H, W, generator=g) * 2 - 1).to(torch.bfloat16)
+    want = K.preprocess(x.float(), antialias)                                                  # [2, 3, 224, 224]
+    rows = pixels_to_patch_rows(x.to(DEV)[:, None], resize=224, crop=224, mode="kornia-bicubic" if antialias else "kornia-bicubic-noaa", patch=(1, 14, 14),
+                                mean=K.CLIP_MEAN, std=K.CLIP_STD)
+    got = rows[:, :3 * 196].float().cpu().view(2, 16, 16, 3, 14, 14).permute(0, 3, 1, 4, 2, 5).reshape(2, 3, 224, 224)
+    assert (got - want).abs().max().item() <= 2.5e-2 and rel(got, want) <= 4e-3             # bf16 output rounding of values up to ~2.7

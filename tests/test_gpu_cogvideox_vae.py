@@ -155,3 +155,15 @@ def test_shipped_configuration_one_tile_properties(hip):
     assert torch.equal(a, m.decode(z).sample)
     z2 = z.clone(); z2[:, :, 3:] = 0
     assert torch.equal(m.decode(z2).sample[:, :, :9], a[:, :, :9])
+
+
+def test_shipped_width_decode_and_encode_match_oracle(hip):
+    """the full 128 / 256 / 256 / 512 widths with four resnets per up block on a small latent (two frame batches: 3 + 2 latent frames -> 17 frames), and the
+    shipped encoder on a single image -- against the fp32 restatement on the host cores"""
+    m, sd = _model(R.CONFIG_5B, 21)
+    g = torch.Generator().manual_seed(4)
+    z = bf(torch.randn(1, 16, 5, 6, 8, generator=g))
+    want = R.decode(sd, R.CONFIG_5B, z, tiling=False)
+    assert rel(m.decode(z.to(DEV)).sample, want) < 3e-2
+    x = bf(torch.rand(1, 3, 1, 64, 96, generator=g) * 2 - 1)
+    assert rel(m.encode(x.to(DEV)).latent_dist.parameters, R.encode_moments(sd, R.CONFIG_5B, x, tiling=False)) < 3e-2

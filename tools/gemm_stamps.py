@@ -10,7 +10,8 @@ from motionrag_amd._lib import GemmArgs  # noqa: E402
 
 L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("MRAG_DIAG_LIB", "libmrag_diag.so")))
 L.mrag_gemm_bf16.argtypes = [ctypes.c_void_p, ctypes.POINTER(GemmArgs)]
-for (M, N, K) in ((35552, 9216, 3072), (35552, 3072, 12288)):
+SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(35552, 9216, 3072), (35552, 3072, 12288)]      # e.g. 258048x960x320
+for (M, N, K) in SHAPES:
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

@@ -11,6 +11,7 @@ from microbench import timeit  # noqa: E402
 
 DEV = "cuda"
 M = 28 * 9216
+outs = {}
 for name, N, K, epi in (("ff1 geglu C=320", 2560, 320, "geglu"), ("ff2 C=320", 320, 1280, "resid"), ("qkv C=320", 960, 320, "none"), ("proj C=320", 320, 320, "none"),
                         ("ff1 geglu C=640 (M/4)", 5120, 640, "geglu")):
     m = M if "M/4" not in name else M // 4
@@ -19,13 +20,16 @@ for name, N, K, epi in (("ff1 geglu C=320", 2560, 320, "geglu"), ("ff2 C=320", 3
     b = torch.randn(N, device=DEV).to(torch.bfloat16)
     res = torch.randn(m, N, device=DEV).to(torch.bfloat16) if epi == "resid" else None
     wg, bg = ops.geglu_interleave(w, b) if epi == "geglu" else (None, None)
-    for cfg in ("0", "2", "0", "2"):
-        ops.TUNING["gemm"] = int(cfg) << 4
+    for cfg in (os.environ.get("MRAG_PROBE_CFGS", "0,2,0,2").split(",")):
+        ops.TUNING["gemm"] = (int(cfg.split(":")[0]) << 4) | (8 if cfg.endswith(":p") else 0)      # "tile[:p]" -- p = persistent workgroups (MRAG_GEMM_TUNE_PERSIST)
         if epi == "geglu":
             fn = lambda: ops.linear(x, wg, bg, epilogue=ops.EPI_GEGLU)
         elif epi == "resid":
             fn = lambda: ops.linear(x, w, b, epilogue=ops.EPI_RESID, resid=res)
         else:
             fn = lambda: ops.linear(x, w, b)
+        y = fn().float()
+        ref = outs.setdefault(name, y)
+        assert torch.equal(y, ref), f"{name} cfg {cfg}: result differs from the first configuration"
         dt = timeit(fn, iters=20, warm=3)
         print(f"{name:24s} cfg={cfg}: {dt*1e3:.3f} ms  {2.0*m*N*K/dt/1e12:.0f} TF/s")

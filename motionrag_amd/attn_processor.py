@@ -70,17 +70,19 @@ def _cat_weights(mods, attr="weight"):
 
 
 class _FusedWeights:
-    """per-`Attention` cache of concatenated projection weights (built once, memory plumbing only)."""
+    """per-`Attention` cache of concatenated projection weights (built once, memory plumbing only).  One slot per KIND of fused operand (the first element of
+    a tuple key): a key whose weight addresses / versions changed REPLACES the slot, so updated weights do not leave stale copies behind."""
 
     def __init__(self):
         self._cache = {}
 
     def get(self, key, builder):
-        ent = self._cache.get(key)
-        if ent is None:
-            ent = builder()
-            self._cache[key] = ent
-        return ent
+        kind = key[0] if isinstance(key, tuple) else key
+        ent = self._cache.get(kind)
+        if ent is None or ent[0] != key:
+            ent = (key, builder())
+            self._cache[kind] = ent
+        return ent[1]
 
     def clear(self):
         self._cache.clear()

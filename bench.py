@@ -302,6 +302,7 @@ def main():
             guarded("dynamicrafter_kl_vae_decode_16x576x1024", mb.vae)                 # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
             guarded("svd_temporal_vae_14x576x1024", mb.svd_vae)                         # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
             guarded("cogvideox_3d_causal_vae_49x480x720", mb.cogvideox_vae)             # SURVEY 8f rank 2 (the headline pipeline's VAE, tiled as the reference configures it; oracle unpinned)
+            guarded("retrieval_text_embedder_gte_base", mb.text_embedder)               # SURVEY 8f rank 3 (query-side embedder; remote-code model, oracle unpinned)
             guarded("t5_xxl_prompt_encoder_2x226", mb.t5)                               # SURVEY 8f rank 4 (CogVideoX's text encoder)
             guarded("rag_side_encoders_plus_cama", mb.encoders)                         # VideoMAE-B + DINOv2-L + CAMA from raw pixels
 
@@ -359,6 +360,7 @@ def main():
             sw = secondary or {}
             parts = {"prompt_encoder_t5_xxl_ms": sw["t5_xxl_prompt_encoder_2x226"]["ms"],
                      "image_vae_encode_tiled_ms": sw["cogvideox_3d_causal_vae_49x480x720"]["encode_image_ms"],
+                     "query_text_embedding_ms": sw["retrieval_text_embedder_gte_base"]["query_16_tokens_ms"],
                      "retrieval_top12_of_1M_ms": round(sw["retrieval_top12_768d"]["N1000000_Q1"]["us"] * 1e-3, 3),
                      "videomae_dinov2_cama_from_pixels_ms": sw["rag_side_encoders_plus_cama"]["cama_predict_from_pixels_ms"],
                      "denoise_50_steps_s": round(e2e_sec, 2),

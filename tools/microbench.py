@@ -310,6 +310,21 @@ def svd_vae(frames=14, h=72, w=128):
             "encode_frame_ms": round(de * 1e3, 2)}
 
 
+def text_embedder():
+    """the retrieval row's text embedder: gte-base-en-v1.5's encoder (12 x 768, 136.8 M parameters, random-init) -- one 16-token query (the latency in
+    front of every `text_search(text)`) and the builder's throughput on 32-token captions in unpadded batches of 1024"""
+    from motionrag_amd.text_embedder import NewModel
+    torch.manual_seed(0)
+    m = NewModel().to(DEV, torch.bfloat16)
+    q = torch.randint(1, 30528, (1, 16), device=DEV)
+    caps = torch.randint(1, 30528, (1024, 32), device=DEV)
+    assert torch.isfinite(m(q)[0].float()).all()
+    tq = timeit(lambda: m(q), iters=20, warm=3)
+    tb = timeit(lambda: m(caps), iters=5, warm=2)
+    print(f"gte-base text embedder: one 16-token query {tq*1e3:.2f} ms; 1024 captions x 32 tokens {tb*1e3:.1f} ms -> {1024/tb:.0f} captions/s")
+    return {"query_16_tokens_ms": round(tq * 1e3, 2), "captions_per_s_32_tokens": round(1024 / tb)}
+
+
 def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
     """CogVideoX-5B's 3-D causal VAE (215.6 M parameters, random-init): decode one clip's final latents [1, 16, 13, 60, 90] -> 49 frames of 480 x 720
     as the reference configures it (cogvideox/module.py:39-40: tiling + slicing -> nine 30 x 45 latent tiles of six frame batches each), the untiled decode

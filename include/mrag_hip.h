@@ -366,6 +366,13 @@ int mrag_unpatchify_bf16(void* stream, const void* src, void* dst,
  * v_pred [2, n] bf16 (uncond first), latents [n] bf16 in place. */
 int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* latents, int64_t n,
                             float guidance, float sqrt_alpha_t, float sqrt_beta_t, float a_t, float b_t);
+/* CFG combine + CogVideoXDPMScheduler.step (diffusers 0.32.2; `scheduler: "dpm"` of configs/cogvideox/MotionRAG_open.yml:189-194, selected at
+ * src/projects/cogvideox/module.py:28-35) -- the SDE form of DPM-Solver++(2M), v-prediction:
+ *   v = v_u + g (v_c - v_u); x0 = sa*x - sb*v; d = second_order ? m3*x0 - m4*x0_prev : x0; x <- m1*x - m2*d + m_noise*noise; x0_prev <- x0
+ * with the host-side multipliers of get_variables / get_mult (h = lambda_next - lambda, r = h_last / h).  v_pred [2, n] bf16 (uncond first);
+ * latents, x0_prev, noise [n] bf16; latents and x0_prev in place (x0_prev is only read when second_order).                                  */
+int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void* x0_prev, const void* noise, int64_t n, float guidance,
+                           float sqrt_alpha_t, float sqrt_beta_t, float m1, float m2, float m3, float m4, float m_noise, int32_t second_order);
 
 /* ------------------------------------------------------------------------ */
 /* Retrieval: flat scan top-k (lancedb 0.14.0 `table.search(q).limit(k)`,     */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
     "mrag_ddim_v_step_f32", "mrag_weighted_sum_bf16", "mrag_attn_fp8_workspace_bytes", "mrag_attn_fwd_fp8",
     "mrag_comm_unique_id", "mrag_comm_init", "mrag_comm_destroy", "mrag_allgather",
-    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8", "mrag_attn_small_bf16", "mrag_blend_tile_bf16",
+    "mrag_resize_patchify_bf16", "mrag_assemble_tokens_bf16", "mrag_softmax_rows_bf16", "mrag_denormalize_u8", "mrag_attn_small_bf16", "mrag_blend_tile_bf16", "mrag_cfg_dpm_step_bf16",
     "mrag_resampler_workspace_bytes", "mrag_resampler_fwd", "mrag_cama_encoder_workspace_bytes", "mrag_cama_encoder_fwd",
 ]
 
@@ -242,6 +242,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_cama_encoder_workspace_bytes.restype = c_int64
     L.mrag_cama_encoder_fwd.argtypes = [c_void_p, POINTER(CamaEncoderArgs)]
     L.mrag_denormalize_u8.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32]
+    L.mrag_cfg_dpm_step_bf16.argtypes = [c_void_p] * 5 + [c_int64] + [c_float] * 8 + [c_int32]
     L.mrag_blend_tile_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8
     L.mrag_softmax_rows_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float]
     L.mrag_assemble_tokens_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]

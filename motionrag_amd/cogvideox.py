@@ -20,6 +20,7 @@ takes prompt embeddings and image latents, or user-supplied encoders.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -279,6 +280,40 @@ class CogVideoXDDIMScheduler:
         return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a), float(b)
 
 
+class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
+    """diffusers 0.32.2 `CogVideoXDPMScheduler` -- what the shipped config samples with (`scheduler: "dpm"`, 25 steps: configs/cogvideox/MotionRAG_open.yml:189-194,
+    module.py:28-35): the same zero-terminal-SNR tables and trailing timesteps as the DDIM class, and the SDE form of DPM-Solver++(2M) as the step
+    (`get_variables` / `get_mult` / `step`): first order on the first and the last step, second order in between, fresh Gaussian noise every step.
+    The multipliers are host-side float64 scalars; the update is the `mrag_cfg_dpm_step_bf16` kernel."""
+
+    def dpm_coeffs(self, t: int, t_back: Optional[int]):
+        """(sqrt(a_t), sqrt(1 - a_t), mult1, mult2, mult3, mult4, mult_noise, second_order) for the step at timestep t whose predecessor in the schedule was t_back"""
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else 1.0
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            lam = lambda a: 0.5 * (np.log(np.float64(a)) - np.log(np.float64(1.0 - a)))          # log sqrt(a / (1 - a)); -inf at a = 0 (zero terminal SNR), +inf at a = 1
+            h = lam(a_prev) - lam(a_t)
+            m1 = float(np.sqrt((1.0 - a_prev) / (1.0 - a_t)) * np.exp(-h))
+            m2 = float(np.expm1(-2.0 * h) * np.sqrt(a_prev))
+            mn = float(np.sqrt(1.0 - a_prev) * np.sqrt(1.0 - np.exp(-2.0 * h)))
+            second = t_back is not None and prev >= 0
+            m3, m4 = 1.0, 0.0
+            if second:
+                r = (lam(a_t) - lam(float(self.alphas_cumprod[t_back]))) / h
+                m3, m4 = float(1.0 + 1.0 / (2.0 * r)), float(1.0 / (2.0 * r))
+        return float(np.sqrt(a_t)), float(np.sqrt(1.0 - a_t)), m1, m2, m3, m4, mn, second
+
+
+def make_scheduler(name: str = "ddim"):
+    """cogvideox/module.py:28-35: `eval_pipeline_call_kwargs.scheduler` -> scheduler object"""
+    if name == "ddim":
+        return CogVideoXDDIMScheduler()
+    if name == "dpm":
+        return CogVideoXDPMScheduler()
+    raise ValueError(f"Unknown scheduler: {name}")
+
+
 class CogVideoXPipelineOutput:
     """what diffusers' pipeline returns: `.frames`, and `output[0]` is `.frames` too (the reference indexes it: cogvideox/module.py:211)"""
 
@@ -388,12 +423,23 @@ class CogVideoXImageToVideoActionPipeline:
 
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, prompt_embeds: torch.Tensor, action_emb: torch.Tensor,
-                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None, cfgp=None, hip_graph: bool = False) -> torch.Tensor:
+                num_inference_steps: int = 50, guidance_scale: float = 6.0, callback=None, sp=None, cfgp=None, hip_graph: bool = False, generator=None,
+                use_dynamic_cfg: bool = False) -> torch.Tensor:
         """the hot loop: latents [b, F, 16, h, w] bf16 (N(0,1) noise), prompt_embeds = cat([negative, positive])
         [2b, L, 4096], action_emb [2b, 25, 1024] (uncond first, module.py:329).
         `sp` (dist.SequenceParallel): the token sequence of the clip sharded over the ranks; `cfgp` (dist.CFGParallel): this rank runs ONE of
-        the two guidance branches at batch b and the pair exchanges the velocity prediction (2.2 MB per step) before the shared update."""
+        the two guidance branches at batch b and the pair exchanges the velocity prediction (2.2 MB per step) before the shared update.
+        With a `CogVideoXDPMScheduler` the update is the stochastic DPM step: its noise is drawn per step from `generator` exactly as the reference's
+        `randn_tensor(sample.shape, generator, device, dtype)` does (bf16, on the generator's device; TWO draws on a second-order step, the second one used).
+        `use_dynamic_cfg`: the cosine guidance schedule of diffusers' pipeline (off by default there and in the reference's calls)."""
         self.action_emb = action_emb
+        dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)
+        x0_prev = torch.zeros_like(latents) if dpm else None
+
+        def draw():
+            if generator is not None and generator.device.type != latents.device.type:
+                return torch.randn(latents.shape, generator=generator, dtype=torch.bfloat16).to(latents.device)
+            return torch.randn(latents.shape, generator=generator, dtype=torch.bfloat16, device=latents.device)
         b, F, C, h, w = latents.shape
         p = self.transformer.cfg["patch"]
         ts = self.scheduler.set_timesteps(num_inference_steps)
@@ -428,8 +474,18 @@ class CogVideoXImageToVideoActionPipeline:
                 v = self.transformer(latents, prompt_embeds, timestep, image_rotary_emb=rope_ip, image_latents=image_latents, batch=B, sp=sp)
             if cfgp is not None:
                 v = cfgp.gather_branches(v.view(1, *v.shape)).view(2 * b, *v.shape[1:])     # [uncond ; cond]
-            sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))
-            ops.cfg_ddim_step_(v, latents, guidance_scale, sa, sb, a_t, b_t)
+            g_t = guidance_scale
+            if use_dynamic_cfg:
+                g_t = 1.0 + guidance_scale * ((1.0 - math.cos(math.pi * ((num_inference_steps - float(t)) / num_inference_steps) ** 5.0)) / 2.0)
+            if dpm:
+                sa, sb, m1, m2, m3, m4, mn, second = self.scheduler.dpm_coeffs(int(t), int(ts[i - 1]) if i > 0 else None)
+                noise = draw()
+                if second:
+                    noise = draw()
+                ops.cfg_dpm_step_(v, latents, x0_prev, noise, g_t, sa, sb, m1, m2, m3, m4, mn, second)
+            else:
+                sa, sb, a_t, b_t = self.scheduler.coeffs(int(t))
+                ops.cfg_ddim_step_(v, latents, g_t, sa, sb, a_t, b_t)
             if callback is not None:
                 callback(i, int(t), latents)
         self.action_emb = action_emb
@@ -439,7 +495,7 @@ class CogVideoXImageToVideoActionPipeline:
     def __call__(self, ref_videos: torch.Tensor = None, metadata=None, *args, image=None, prompt=None, negative_prompt=None, height: int = 480,
                  width: int = 720, num_frames: int = 49, num_inference_steps: int = 50, guidance_scale: float = 6.0, generator=None,
                  latents=None, prompt_embeds=None, negative_prompt_embeds=None, image_latents=None, output_type: str = "pil",
-                 max_sequence_length: int = 226, return_dict: bool = True, **kwargs):
+                 max_sequence_length: int = 226, return_dict: bool = True, use_dynamic_cfg: bool = False, **kwargs):
         """pipeline.py:80-89: motion tokens first (CFG on), then the body of diffusers' CogVideoXImageToVideoPipeline.__call__ with
         do_classifier_free_guidance (guidance_scale > 1 in every shipped config): `pipe(prompt=, image=, negative_prompt=, output_type='pt',
         ref_videos=, metadata=, num_frames=, num_inference_steps=, guidance_scale=, ...)` -> output with `.frames` [b, f, c, H, W] in [0, 1]
@@ -463,7 +519,7 @@ class CogVideoXImageToVideoActionPipeline:
                                 dtype=torch.float32)                                     # CPU-seeded
             latents = noise.to(dev, torch.bfloat16)                                      # DDIM: init_noise_sigma == 1
         latents = self.denoise(latents.to(dev, torch.bfloat16).contiguous(), image_latents.to(dev, torch.bfloat16).contiguous(), pe,
-                               self.action_emb, num_inference_steps, guidance_scale)
+                               self.action_emb, num_inference_steps, guidance_scale, generator=generator, use_dynamic_cfg=use_dynamic_cfg)
         if output_type == "latent":
             frames = latents
         else:

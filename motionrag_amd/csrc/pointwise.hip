@@ -141,6 +141,30 @@ __global__ void cfg_ddim_kernel(const bf16_t* vp, bf16_t* x, long long n8, long 
   }
 }
 
+// v = v_u + g (v_c - v_u); x0 = sa x - sb v; d = second ? m3 x0 - m4 x0_old : x0; x <- m1 x - m2 d + mn noise; x0_old <- x0
+// (CogVideoXDPMScheduler.step: the SDE form of DPM-Solver++(2M) the reference's shipped CogVideoX config samples with)
+__global__ void cfg_dpm_kernel(const bf16_t* vp, bf16_t* x, bf16_t* x0_old, const bf16_t* noise, long long n8, long long n, float g, float sa, float sb, float m1,
+                               float m2, float m3, float m4, float mn, int second) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float vu[8], vc[8], xx[8], xo[8], nz[8];
+    unpack8(*(const u32x4*)(vp + i * 8), vu);
+    unpack8(*(const u32x4*)(vp + n + i * 8), vc);
+    unpack8(*(const u32x4*)(x + i * 8), xx);
+    unpack8(*(const u32x4*)(noise + i * 8), nz);
+    if (second) unpack8(*(const u32x4*)(x0_old + i * 8), xo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = vu[e] + g * (vc[e] - vu[e]);
+      const float x0 = bf_round(sa * xx[e] - sb * v);            // the reference carries pred_original_sample between steps in the latents' dtype
+      const float d = second ? m3 * x0 - m4 * xo[e] : x0;
+      xx[e] = m1 * xx[e] - m2 * d + mn * nz[e];
+      xo[e] = x0;
+    }
+    *(u32x4*)(x + i * 8) = pack8(xx);
+    *(u32x4*)(x0_old + i * 8) = pack8(xo);
+  }
+}
+
 // y[r, :] = x[r, :] + table[(r / div) % period, :]  (per-frame / per-sample vectors broadcast over the pixels of a frame)
 __global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long div, long long period) {
   const long long total = rows * D8;
@@ -342,6 +366,16 @@ extern "C" int mrag_cfg_ddim_step_bf16(void* stream, const void* v_pred, void* l
   if (((uintptr_t)v_pred | (uintptr_t)latents) & 15) return MRAG_EINVAL;
   MRAG_LAUNCH(cfg_ddim_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents,
                      (long long)(n / 8), (long long)n, guidance, sqrt_alpha_t, sqrt_beta_t, a_t, b_t);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
+
+extern "C" int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void* x0_prev, const void* noise, int64_t n, float guidance,
+                                      float sqrt_alpha_t, float sqrt_beta_t, float m1, float m2, float m3, float m4, float m_noise, int32_t second_order) {
+  if (!v_pred || !latents || !x0_prev || !noise || n <= 0 || n % 8 != 0) return MRAG_EINVAL;
+  if (((uintptr_t)v_pred | (uintptr_t)latents | (uintptr_t)x0_prev | (uintptr_t)noise) & 15) return MRAG_EINVAL;
+  MRAG_LAUNCH(cfg_dpm_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v_pred, (bf16_t*)latents, (bf16_t*)x0_prev,
+              (const bf16_t*)noise, (long long)(n / 8), (long long)n, guidance, sqrt_alpha_t, sqrt_beta_t, m1, m2, m3, m4, m_noise, second_order ? 1 : 0);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

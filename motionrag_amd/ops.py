@@ -487,6 +487,19 @@ def cfg_ddim_step_(v_pred: torch.Tensor, latents: torch.Tensor, guidance: float,
     return latents
 
 
+def cfg_dpm_step_(v_pred: torch.Tensor, latents: torch.Tensor, x0_prev: torch.Tensor, noise: torch.Tensor, guidance: float, sqrt_alpha_t: float, sqrt_beta_t: float,
+                  m1: float, m2: float, m3: float, m4: float, m_noise: float, second_order: bool) -> torch.Tensor:
+    """latents <- CogVideoXDPMScheduler.step(v_u + g (v_c - v_u)); v_pred [2, ...] (uncond first); latents, x0_prev (the previous step's x0, updated), noise [...]"""
+    for t, nm in ((v_pred, "v_pred"), (latents, "latents"), (x0_prev, "x0_prev"), (noise, "noise")):
+        _dev(t, name=nm)
+    n = latents.numel()
+    if v_pred.numel() != 2 * n or x0_prev.numel() != n or noise.numel() != n or not all(t.is_contiguous() for t in (v_pred, latents, x0_prev, noise)):
+        raise ValueError("cfg_dpm_step_: v_pred [2, *latents.shape]; x0_prev, noise like latents; all contiguous")
+    check(_lib.lib().mrag_cfg_dpm_step_bf16(_stream(), _p(v_pred), _p(latents), _p(x0_prev), _p(noise), n, guidance, sqrt_alpha_t, sqrt_beta_t, m1, m2, m3, m4, m_noise,
+                                            1 if second_order else 0), "mrag_cfg_dpm_step_bf16")
+    return latents
+
+
 _TOPK_WS = {}
 
 

@@ -222,6 +222,41 @@ def cfg_ddim_step(v_pred: torch.Tensor, latents: torch.Tensor, guidance: float, 
 # ----------------------------------------------------------------------------------------------
 # random-init weights (N(0, 0.02), norms gamma = 1 + N), diffusers key layout
 # ----------------------------------------------------------------------------------------------
+def dpm_step(ac: np.ndarray, model_output: torch.Tensor, old_pred_original_sample: Optional[torch.Tensor], timestep: int, timestep_back: Optional[int],
+             sample: torch.Tensor, num_inference_steps: int, noise_fn, n_train: int = 1000):
+    """diffusers 0.32.2 `CogVideoXDPMScheduler.step` (v-prediction), statement by statement -- third-party, PARITY UNPINNED; the scheduler the reference's shipped
+    config selects (configs/cogvideox/MotionRAG_open.yml:189-194 `scheduler: "dpm"`, cogvideox/module.py:28-35).  `noise_fn()` stands for
+    `randn_tensor(sample.shape, generator=...)`: it is called once per step, and a second time on a second-order step (whose result uses the second draw).
+    Returns (prev_sample, pred_original_sample)."""
+    acp = torch.from_numpy(np.asarray(ac)).to(torch.float32)                 # the scheduler's alphas_cumprod tensor is fp32
+    prev_timestep = timestep - n_train // num_inference_steps
+    alpha_prod_t = acp[timestep]
+    alpha_prod_t_prev = acp[prev_timestep] if prev_timestep >= 0 else torch.tensor(1.0)
+    alpha_prod_t_back = acp[timestep_back] if timestep_back is not None else None
+    beta_prod_t = 1 - alpha_prod_t
+    pred_original_sample = (alpha_prod_t ** 0.5) * sample - (beta_prod_t ** 0.5) * model_output
+    # get_variables
+    lamb = ((alpha_prod_t / (1 - alpha_prod_t)) ** 0.5).log()
+    lamb_next = ((alpha_prod_t_prev / (1 - alpha_prod_t_prev)) ** 0.5).log()
+    h = lamb_next - lamb
+    r = None
+    if alpha_prod_t_back is not None:
+        lamb_previous = ((alpha_prod_t_back / (1 - alpha_prod_t_back)) ** 0.5).log()
+        r = (lamb - lamb_previous) / h
+    # get_mult
+    mult1 = ((1 - alpha_prod_t_prev) / (1 - alpha_prod_t)) ** 0.5 * (-h).exp()
+    mult2 = (-2 * h).expm1() * alpha_prod_t_prev ** 0.5
+    mult_noise = (1 - alpha_prod_t_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+    noise = noise_fn()
+    prev_sample = mult1 * sample - mult2 * pred_original_sample + mult_noise * noise
+    if old_pred_original_sample is None or prev_timestep < 0:
+        return prev_sample, pred_original_sample
+    mult3, mult4 = 1 + 1 / (2 * r), 1 / (2 * r)
+    denoised_d = mult3 * pred_original_sample - mult4 * old_pred_original_sample
+    noise = noise_fn()
+    return mult1 * sample - mult2 * denoised_d + mult_noise * noise, pred_original_sample
+
+
 def random_dit_sd(cfg: DiTConfig, seed: int = 0, std: float = 0.02) -> SD:
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g) * std

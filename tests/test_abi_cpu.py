@@ -168,3 +168,33 @@ def test_tuple_tensor_semantics():
     assert h.dtype == torch.float16 and h.to_tuple()[1].dtype == torch.float16
     e, ip = tt                      # how attn_processor.py:34-37 unpacks it
     assert e is a and ip is b
+
+
+def test_dpm_scheduler_multipliers_match_the_restated_step():
+    """CogVideoXDPMScheduler.dpm_coeffs (host float64, with the infinities of the zero-terminal-SNR first step and the alpha = 1 last step) against the oracle's
+    statement-by-statement step: a scalar chain through 25 / 50 / 3 steps lands on the same values, with two noise draws exactly on the second-order steps"""
+    import torch
+    from motionrag_amd.cogvideox import CogVideoXDPMScheduler
+    from oracle import cogvideox_ref as R
+    ac = R.ddim_alphas_cumprod()
+    for steps in (25, 50, 3):
+        s = CogVideoXDPMScheduler()
+        ts = s.set_timesteps(steps)
+        g = torch.Generator().manual_seed(steps)
+        x = torch.randn(4, 5, generator=g)
+        xo, x0_old, mine_old = x.clone(), None, torch.zeros_like(x)
+        for i, t in enumerate(ts):
+            v = torch.randn(4, 5, generator=g)
+            draws = []
+
+            def nf():
+                draws.append(torch.randn(4, 5, generator=g))
+                return draws[-1]
+            t_back = int(ts[i - 1]) if i > 0 else None
+            want, want_x0 = R.dpm_step(ac, v, x0_old, int(t), t_back, xo, steps, nf)
+            sa, sb, m1, m2, m3, m4, mn, second = s.dpm_coeffs(int(t), t_back)
+            assert second == (0 < i < steps - 1) and len(draws) == (2 if second else 1)
+            x0 = sa * x - sb * v
+            got = m1 * x - m2 * (m3 * x0 - m4 * mine_old if second else x0) + mn * draws[-1]
+            assert torch.isfinite(got).all() and torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+            x, mine_old, xo, x0_old = got, x0, want, want_x0

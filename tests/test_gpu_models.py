@@ -444,3 +444,71 @@ def test_denoise_loop_as_hip_graph_equals_eager(hip):
     assert torch.isfinite(eager.float()).all() and torch.equal(eager, graphed)
     graphed2 = pipe.denoise(lat.clone(), img, text, ip * 0.5, num_inference_steps=4, guidance_scale=6.0, hip_graph=True)      # a new clip: new capture, new motion tokens
     assert not torch.equal(graphed2, graphed)
+
+
+def test_dpm_denoise_loop_matches_oracle(hip):
+    """The shipped config's sampler (`scheduler: "dpm"`, configs/cogvideox/MotionRAG_open.yml:189-194): 4 steps of the stochastic DPM loop -- first-order first and last
+    steps, second-order steps between, noise drawn from a CPU generator exactly as diffusers' randn_tensor draws it -- against the oracle's statement-by-statement
+    CogVideoXDPMScheduler.step around the oracle DiT"""
+    from motionrag_amd.cogvideox import CogVideoXDPMScheduler, CogVideoXImageToVideoCTPipeline, make_scheduler
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit(seed=35)
+    g = torch.Generator().manual_seed(36)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(torch.bfloat16)
+    assert isinstance(make_scheduler("dpm"), CogVideoXDPMScheduler)
+    pipe = CogVideoXImageToVideoCTPipeline(model, make_scheduler("dpm"))
+    steps, guidance = 4, 3.0
+    got = pipe.denoise(lat.to(DEV).clone(), img.to(DEV), text.to(DEV), ip.to(DEV), num_inference_steps=steps, guidance_scale=guidance,
+                       generator=torch.Generator().manual_seed(77))
+    ac = cogvideox_ref.ddim_alphas_cumprod()
+    cos, sin = cogvideox_ref.rope_3d(64, 3, 4, 6)
+    x, x0_old = lat.float(), None
+    sdr = _bf_round(sd)
+    gen = torch.Generator().manual_seed(77)
+    ts = cogvideox_ref.ddim_timesteps(steps)
+    draws = 0
+
+    def noise_fn():
+        nonlocal draws
+        draws += 1
+        return torch.randn(x.shape, generator=gen, dtype=torch.bfloat16).float()
+    for i, t in enumerate(ts):
+        inp = torch.cat([torch.cat([x] * 2), torch.cat([img.float()] * 2)], dim=2)
+        v = cogvideox_ref.dit_forward(sdr, cfg, inp, text.float(), torch.full((2,), float(t)), (cos, sin), ip.float())
+        v = v[:1] + guidance * (v[1:] - v[:1])
+        x, x0_old = cogvideox_ref.dpm_step(ac, v, x0_old, int(t), int(ts[i - 1]) if i > 0 else None, x, steps, noise_fn)
+        x, x0_old = x.to(torch.bfloat16).float(), x0_old.to(torch.bfloat16).float()
+    assert draws == 1 + 2 * (steps - 2) + 1
+    close(got, x, rel_l2=4e-2, atol_frac=0.12)
+    # the same generator seed reproduces the clip; another seed does not
+    again = pipe.denoise(lat.to(DEV).clone(), img.to(DEV), text.to(DEV), ip.to(DEV), num_inference_steps=steps, guidance_scale=guidance,
+                         generator=torch.Generator().manual_seed(77))
+    other = pipe.denoise(lat.to(DEV).clone(), img.to(DEV), text.to(DEV), ip.to(DEV), num_inference_steps=steps, guidance_scale=guidance,
+                         generator=torch.Generator().manual_seed(78))
+    assert torch.equal(again, got) and not torch.equal(other, got)
+
+
+def test_cfg_dpm_step_kernel_matches_oracle(hip):
+    from motionrag_amd import ops
+    from motionrag_amd.cogvideox import CogVideoXDPMScheduler
+    from oracle import cogvideox_ref
+    g = torch.Generator().manual_seed(5)
+    sch = CogVideoXDPMScheduler()
+    steps = 25
+    ts = sch.set_timesteps(steps)
+    ac = cogvideox_ref.ddim_alphas_cumprod()
+    n = 4096
+    for i in (0, 1, 12, 24):                                                  # zero-SNR first step, second-order steps, first-order last step
+        t, t_back = int(ts[i]), (int(ts[i - 1]) if i > 0 else None)
+        v2 = torch.randn(2, n, generator=g).to(torch.bfloat16)
+        x, x0p, nz = (torch.randn(n, generator=g).to(torch.bfloat16) for _ in range(3))
+        v = v2[:1].float() + 3.0 * (v2[1:].float() - v2[:1].float())
+        want, want_x0 = cogvideox_ref.dpm_step(ac, v[0], x0p.float() if i > 0 else None, t, t_back, x.float(), steps, lambda: nz.float())
+        xd, x0d = x.to(DEV).clone(), x0p.to(DEV).clone()
+        sa, sb, m1, m2, m3, m4, mn, second = sch.dpm_coeffs(t, t_back)
+        assert second == (i not in (0, 24))
+        ops.cfg_dpm_step_(v2.to(DEV), xd, x0d, nz.to(DEV), 3.0, sa, sb, m1, m2, m3, m4, mn, second)
+        close(xd, want, rel_l2=6e-3, atol_frac=0.03)
+        close(x0d, want_x0, rel_l2=6e-3, atol_frac=0.03)

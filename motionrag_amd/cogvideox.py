@@ -564,9 +564,13 @@ def set_attention_processors(transformer: CogVideoXTransformer3DModel, adapter_m
 
 
 def eval_pipeline(pipe, image, positive_prompt, negative_prompt, dtype, ref_videos, metadata, *args, **kwargs) -> torch.Tensor:
-    """CogVideoX5BAction.eval_pipeline (cogvideox/module.py:197-223): image in [-1, 1] -> video [b, 16, c, H, W] in [-1, 1]."""
+    """CogVideoX5BAction.eval_pipeline (cogvideox/module.py:197-223): image in [-1, 1] -> video [b, 16, c, H, W] in [-1, 1].  `kwargs` is the YAML's
+    `eval_pipeline_call_kwargs`: a `scheduler` entry ('ddim' | 'dpm') selects the pipeline's scheduler as module.py:28-35 does when it builds the pipeline."""
     image = image / 2 + 0.5                                                          # denormalize
     sample_method = kwargs.pop("sample_method", "first")
+    scheduler_name = kwargs.pop("scheduler", None)
+    if scheduler_name is not None:
+        pipe.scheduler = make_scheduler(scheduler_name)
     frames = pipe(prompt=positive_prompt, image=image, negative_prompt=negative_prompt, output_type="pt", ref_videos=ref_videos,
                   metadata=metadata, *args, **kwargs)
     video = frames[0]

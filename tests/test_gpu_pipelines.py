@@ -111,6 +111,15 @@ def test_cogvideox_ct_pipeline_reference_call_surface(hip):
              **dict(kw, num_frames=33))
     with pytest.raises(ValueError):
         cvx.eval_pipeline(pipe, image, ["x"], ["y"], torch.bfloat16, ref_videos, metadata, sample_method="bogus", **kw)
+    # the shipped eval_pipeline_call_kwargs (MotionRAG_open.yml:189-194): scheduler 'dpm', sample_method null, guidance 3 -- every decoded frame comes back
+    pipe.vae = StubVAE(8)
+    shipped = dict(num_inference_steps=3, num_frames=9, guidance_scale=3, sample_method=None, scheduler="dpm", height=64, width=96)
+    dpm = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **shipped)
+    assert isinstance(pipe.scheduler, cvx.CogVideoXDPMScheduler) and dpm.shape == (1, 9, 3, 64, 96) and torch.isfinite(dpm.float()).all()
+    dpm2 = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **shipped)
+    assert torch.equal(dpm, dpm2)                                                                  # the sampler's noise comes from the generator
+    with pytest.raises(ValueError):
+        cvx.eval_pipeline(pipe, image, ["x"], ["y"], torch.bfloat16, ref_videos, metadata, **dict(shipped, scheduler="euler"))
 
 
 def test_cogvideox_set_attention_processors_by_name(hip):

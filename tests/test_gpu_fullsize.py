@@ -100,3 +100,11 @@ def test_cogvideox_5b_full_size_cfg_step(hip):
         outs.append(x.float())
     second = outs[0] - 2 * outs[1] + outs[2]
     assert second.abs().max().item() <= 4 * 2.0 ** -8 * max(o.abs().max().item() for o in outs)
+    # the SHIPPED evaluation geometry on the same weights (configs/cogvideox/MotionRAG_open.yml:189-194: 17 frames -> 5 latent frames, S = 6 976, DPM sampler,
+    # guidance 3): three stochastic steps are finite, reproduce bit for bit from the same generator seed, and differ for another seed
+    from motionrag_amd.cogvideox import make_scheduler
+    pipe.scheduler = make_scheduler("dpm")
+    lat5, img5 = latents[:, :5].contiguous(), image_latents[:, :5].contiguous()
+    runs = [pipe.denoise(lat5.clone(), img5, prompt, action, num_inference_steps=3, guidance_scale=3.0, generator=torch.Generator().manual_seed(s)) for s in (1, 1, 2)]
+    assert runs[0].shape == (1, 5, 16, 60, 90) and torch.isfinite(runs[0].float()).all()
+    assert torch.equal(runs[0], runs[1]) and not torch.equal(runs[0], runs[2])

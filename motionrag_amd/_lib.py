@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
-ABI_VERSION = 5
+ABI_VERSION = 6
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"] + ([f"-DMRAG_ATTN_WPS={os.environ['MRAG_BUILD_ATTN_WPS']}"] if "MRAG_BUILD_ATTN_WPS" in os.environ else []),
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}

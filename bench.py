@@ -395,6 +395,16 @@ def main():
             out["e2e_sec_per_clip_full_pipeline"] = parts
         except (KeyError, TypeError):
             out["e2e_sec_per_clip_full_pipeline"] = None      # a stage was not measured in this run (--no-secondary / --no-e2e / N > 1)
+        try:     # the other two pipelines at their shipped step counts (configs/{dynamicrafter,svd}/MotionRAG_open.yml): steps x the measured CFG step + the measured VAE decode
+            sw = secondary or {}
+            out["e2e_sec_per_clip_other_pipelines_from_measured_parts"] = {
+                "dynamicrafter1024_16f_30_ddim_steps_s": round(1e-3 * (30 * sw["dynamicrafter1024_unet_16x576x1024_cfg_step"]["ms_per_cfg_step"]
+                                                                        + sw["dynamicrafter_kl_vae_decode_16x576x1024"]["ms_per_clip"]
+                                                                        + sw["rag_side_encoders_plus_cama"]["cama_predict_from_pixels_ms"]), 2),
+                "svd_14f_25_euler_steps_s": round(1e-3 * (25 * sw["svd_unet_14x576x1024_cfg_step"]["ms_per_cfg_step"] + sw["svd_temporal_vae_14x576x1024"]["decode_ms_per_clip"]
+                                                          + sw["svd_temporal_vae_14x576x1024"]["encode_frame_ms"] + sw["rag_side_encoders_plus_cama"]["cama_predict_from_pixels_ms"]), 2)}
+        except (KeyError, TypeError):
+            out["e2e_sec_per_clip_other_pipelines_from_measured_parts"] = None
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only (other ranks would idle in the barrier)
             dt, fl, what = cpu_baseline_sample()
             full = dt * (step_flops / fl)

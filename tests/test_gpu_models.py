@@ -512,3 +512,30 @@ def test_cfg_dpm_step_kernel_matches_oracle(hip):
         ops.cfg_dpm_step_(v2.to(DEV), xd, x0d, nz.to(DEV), 3.0, sa, sb, m1, m2, m3, m4, mn, second)
         close(xd, want, rel_l2=6e-3, atol_frac=0.03)
         close(x0d, want_x0, rel_l2=6e-3, atol_frac=0.03)
+
+
+def test_dynamic_cfg_schedule(hip):
+    """`use_dynamic_cfg` of diffusers' pipeline: guidance_t = 1 + s (1 - cos(pi ((N - t) / N)^5)) / 2 with t the TIMESTEP VALUE -- the loop equals the same steps driven
+    by hand with that scale"""
+    import math
+    from motionrag_amd import ops
+    from motionrag_amd.cogvideox import CogVideoXDDIMScheduler, CogVideoXImageToVideoCTPipeline
+    cfg, sd, model = _small_dit(seed=41)
+    g = torch.Generator().manual_seed(42)
+    lat, img = (torch.randn(1, 3, 8, 8, 12, generator=g).to(DEV, torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(DEV, torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(DEV, torch.bfloat16)
+    pipe = CogVideoXImageToVideoCTPipeline(model, CogVideoXDDIMScheduler())
+    steps, s = 3, 6.0
+    got = pipe.denoise(lat.clone(), img, text, ip, num_inference_steps=steps, guidance_scale=s, use_dynamic_cfg=True)
+    x = lat.clone()
+    pipe.action_emb = ip
+    rope = pipe._prepare_rotary_positional_embeddings(3, 4, 6, torch.device(DEV))
+    ts = pipe.scheduler.set_timesteps(steps)
+    scales = []
+    for t in ts:
+        v = model(x, text, torch.full((2,), float(t), device=DEV), image_rotary_emb=rope, image_latents=img, batch=2)
+        scales.append(1 + s * ((1 - math.cos(math.pi * ((steps - float(t)) / steps) ** 5.0)) / 2))
+        ops.cfg_ddim_step_(v, x, scales[-1], *pipe.scheduler.coeffs(int(t)))
+    assert torch.equal(got, x) and len(set(round(v, 6) for v in scales)) == steps
+    assert not torch.equal(got, pipe.denoise(lat.clone(), img, text, ip, num_inference_steps=steps, guidance_scale=s))

@@ -69,7 +69,9 @@ class NewModel(nn.Module):
             inv = 1.0 / ((c.rope_theta * c.rope_scaling_factor) ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64)) / c.rope_scaling_factor ** (2.0 / 64)
             ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
             ang = ang.repeat_interleave(2, dim=1)
-            self._rope_cache = {key: (ang.cos().contiguous().to(device), ang.sin().contiguous().to(device))}
+            if len(self._rope_cache) >= 64:                                     # one table per sequence length the builder meets; bounded
+                self._rope_cache.clear()
+            self._rope_cache[key] = (ang.cos().contiguous().to(device), ang.sin().contiguous().to(device))
         return self._rope_cache[key]
 
     @staticmethod

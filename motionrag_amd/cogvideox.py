@@ -446,7 +446,7 @@ class CogVideoXImageToVideoActionPipeline:
         B = 2 * b
         if cfgp is not None:
             sl = slice(cfgp.branch * b, (cfgp.branch + 1) * b)
-            prompt_embeds, self.action_emb, B = prompt_embeds[sl].contiguous(), action_emb[sl].contiguous(), b
+            prompt_embeds, self.action_emb, B = prompt_embeds[sl].contiguous(), (action_emb[sl].contiguous() if action_emb is not None else None), b
         rope_ip = self._prepare_rotary_positional_embeddings(F, h // p, w // p, latents.device)
         graph = None
         if hip_graph:
@@ -532,6 +532,18 @@ class CogVideoXImageToVideoActionPipeline:
             if output_type == "np":
                 frames = frames.float().cpu().numpy()
         return CogVideoXPipelineOutput(frames) if return_dict else (frames,)
+
+
+class CogVideoXImageToVideoPipeline(CogVideoXImageToVideoActionPipeline):
+    """The pipeline WITHOUT motion injection -- diffusers' `CogVideoXImageToVideoPipeline` as the reference's baseline module runs it (`CogVideoX5B`,
+    cogvideox/module.py:16-79, configs/cogvideox/baseline_open.yml; the "CogVideoX baseline" row of the reference's README): same prompt / image / loop / decode
+    path, plain joint attention in every block, `pipe(prompt=, image=, negative_prompt=, output_type='pt', ...)`."""
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer: CogVideoXTransformer3DModel = None, scheduler=None):
+        super().__init__(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, transformer=transformer, scheduler=scheduler)
+
+    def prepare_action_embeddings(self, ref_videos=None, metadata=None, do_classifier_free_guidance: bool = False, *args, **kwargs):
+        return None                                                                  # no motion tokens: `joint_attention_core` skips the adapter branch
 
 
 class CogVideoXImageToVideoCTPipeline(CogVideoXImageToVideoActionPipeline):

@@ -163,6 +163,21 @@ class SVDActionPipeline:
         return self._run(*args, **kwargs)
 
 
+class StableVideoDiffusionPipeline(SVDActionPipeline):
+    """The pipeline WITHOUT motion injection: diffusers' `StableVideoDiffusionPipeline` as the reference's baseline module runs it (`SVDModule`,
+    src/projects/svd/module.py, configs/svd/baseline_open.yml): the image embedding alone conditions the UNet (plain attention processors),
+    `pipe(image=, height=, width=, num_frames=, decode_chunk_size=, ...)`."""
+
+    def __init__(self, vae=None, image_encoder=None, unet=None, scheduler=None, feature_extractor=None):
+        super().__init__(vae=vae, image_encoder=image_encoder, unet=unet, scheduler=scheduler, feature_extractor=feature_extractor)
+
+    def _encode_image(self, *args, **kwargs) -> torch.Tensor:
+        return self._encode_image_base(*args, **kwargs)
+
+    def __call__(self, *args, ref_videos=None, metadata=None, **kwargs):
+        return self._run(*args, **kwargs)
+
+
 class SVDCTPipeline(SVDActionPipeline):
     """pipeline.py:122-160"""
 

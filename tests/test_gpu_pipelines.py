@@ -369,3 +369,101 @@ def test_cogvideox_ct_pipeline_all_native_components(hip):
     g2 = torch.Generator().manual_seed(3)
     want_il = post.sample(g2) * 0.7
     assert il.shape == (1, 3, 8, 8, 12) and torch.equal(il[:, 0], want_il[:, :, 0]) and il[:, 1:].abs().max().item() == 0
+
+
+def test_cogvideox_baseline_pipeline_without_motion_injection(hip):
+    """diffusers' plain CogVideoXImageToVideoPipeline as the reference's baseline module calls it (cogvideox/module.py:55-79, configs/cogvideox/baseline_open.yml):
+    no ref_videos, plain joint attention; its latents equal the oracle DiT + DDIM loop without the adapter branch, and differ from the motion-injected run"""
+    from motionrag_amd import cogvideox as cvx
+    from oracle import cogvideox_ref
+    from test_gpu_models import _bf_round
+    cfg, sd, dit = _small_dit()
+    pipe = cvx.CogVideoXImageToVideoPipeline(tokenizer=None, text_encoder=StubText(), vae=StubVAE(8), transformer=dit, scheduler=cvx.make_scheduler("ddim"))
+    image, ref_videos, metadata = _pipe_inputs()
+    kw = dict(num_frames=9, num_inference_steps=2, guidance_scale=6.0, height=64, width=96)
+    vid = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, None, None, generator=torch.Generator().manual_seed(3), **kw)
+    assert vid.shape == (1, 9, 3, 64, 96) and torch.isfinite(vid.float()).all()
+    lat = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", generator=torch.Generator().manual_seed(3), **kw).frames
+    # by hand with the oracle: same noise, embeddings, image latents; ip_hidden = None
+    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+    te = StubText()
+    text = torch.cat([te(["blurry"]), te(["a dog runs"])]).float().cpu()
+    il = pipe.encode_image_latents(image / 2 + 0.5, 3).to(torch.bfloat16).float().cpu()
+    ac = cogvideox_ref.ddim_alphas_cumprod()
+    cos, sin = cogvideox_ref.rope_3d(64, 3, 4, 6)
+    x = noise.float()
+    sdr = _bf_round(sd)
+    for t in cogvideox_ref.ddim_timesteps(2):
+        inp = torch.cat([torch.cat([x] * 2), torch.cat([il] * 2)], dim=2)
+        v = cogvideox_ref.dit_forward(sdr, cfg, inp, text, torch.full((2,), float(t)), (cos, sin), None, ip_scale=0.0)
+        x = cogvideox_ref.cfg_ddim_step(v, x, 6.0, cogvideox_ref.ddim_coeffs(ac, int(t), 2)).to(torch.bfloat16).float()
+    close(lat, x, rel_l2=4e-2, atol_frac=0.12)
+    inj = cvx.CogVideoXImageToVideoCTPipeline(tokenizer=None, text_encoder=StubText(), vae=StubVAE(8), transformer=dit, scheduler=cvx.make_scheduler("ddim"),
+                                              condition_transformer=StubCAMA())
+    lat_inj = inj(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+                  generator=torch.Generator().manual_seed(3), **kw).frames
+    assert not torch.equal(lat_inj, lat)
+
+
+def test_svd_baseline_pipeline_without_motion_injection(hip):
+    """diffusers' plain StableVideoDiffusionPipeline as the reference's baseline module runs it (configs/svd/baseline_open.yml): image embedding only, plain
+    attention processors -- two Euler / CFG steps against the oracle UNet without motion tokens"""
+    from motionrag_amd import svd, svd_unet
+    from oracle import svd_ref
+    cfg = dict(in_channels=8, out_channels=4, block_out_channels=(64, 128), addition_time_embed_dim=64, projection_class_embeddings_input_dim=192,
+               layers_per_block=1, cross_attention_dim=64, num_attention_heads=(1, 2))
+    unet = svd_unet.UNetSpatioTemporalConditionModel(**cfg)
+    g0 = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, p in unet.named_parameters():
+            if k.endswith("mix_factor"):
+                p.copy_(torch.randn(p.shape, generator=g0))
+            elif p.dim() == 1:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g0) if "norm" in k and k.endswith("weight") else 0.05 * torch.randn(p.shape, generator=g0))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g0) * (0.7 / p[0].numel() ** 0.5))
+    unet = unet.to(torch.bfloat16)
+    sdict = {k: v.float() for k, v in unet.state_dict().items()}
+    unet = unet.to(DEV)
+    b, Fr, h, w = 1, 4, 16, 16
+
+    class ImgEnc:
+        def __call__(self, x):
+            return torch.tanh(x.float().mean(dim=(2, 3)).repeat(1, 22)[:, :64]).to(torch.bfloat16)
+
+    class VAE:
+        class Cfg:
+            scaling_factor = 0.18215
+        config = Cfg()
+
+        def encode(self, x):
+            return torch.nn.functional.avg_pool2d(x.float(), 8).repeat(1, 2, 1, 1)[:, :4]
+
+        def decode(self, z, num_frames=None):
+            return torch.tanh(torch.nn.functional.interpolate(z[:, :3].float(), scale_factor=8, mode="nearest"))
+    pipe = svd.StableVideoDiffusionPipeline(vae=VAE(), image_encoder=ImgEnc(), unet=unet, scheduler=svd_unet.EulerDiscreteScheduler(), feature_extractor=None)
+    g = torch.Generator().manual_seed(8)
+    img255 = torch.rand(b, 3, 8 * h, 8 * w, generator=g) * 255.0
+    kw = dict(height=8 * h, width=8 * w, num_frames=Fr, num_inference_steps=2, min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=127,
+              noise_aug_strength=0.02)
+    got = pipe(image=img255, output_type="latent", generator=torch.Generator().manual_seed(9), **kw).frames
+    gen = torch.Generator().manual_seed(9)
+    img = img255 / 127.5 - 1.0
+    noise = torch.randn(img.shape, generator=gen)
+    sig = svd_ref.karras_sigmas(2)
+    lat = (torch.randn(b, Fr, 4, h, w, generator=gen) * float((sig[0] ** 2 + 1) ** 0.5)).to(torch.bfloat16).float()
+    emb = ImgEnc()(img).float().unsqueeze(1)
+    emb2 = torch.cat([torch.zeros_like(emb), emb])
+    z = VAE().encode((img + 0.02 * noise)).to(torch.bfloat16).float()
+    il = torch.cat([torch.zeros_like(z), z])[:, None].expand(-1, Fr, -1, -1, -1)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    gs = torch.linspace(1.0, 3.0, Fr)
+    for i in range(2):
+        s, sn = float(sig[i]), float(sig[i + 1])
+        scaled = (lat / (s * s + 1) ** 0.5).to(torch.bfloat16).float()
+        x = torch.cat([torch.cat([scaled, scaled]), il], dim=2)
+        v = svd_ref.unet_forward(sdict, cfg, x, torch.tensor(0.25 * np.log(s)), emb2, ids, None)
+        lat = svd_ref.euler_cfg_step(v[:b].double(), v[b:].double(), lat.double(), s, sn, gs.double()).float().to(torch.bfloat16).float()
+    close(got, lat, rel_l2=4e-2, atol_frac=0.35)          # as the CT test, two chained bf16 CFG steps; one element of 4 096 reaches 0.32 of the mean magnitude with these weights
+    vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, generator=torch.Generator().manual_seed(9), **kw)
+    assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""developer probe: four LDS stages (three K-tiles in flight) against two on the small-M GEMMs that run at most one 128x128 workgroup per CU
-(MRAG_GEMM_TUNE_TWO_STAGES = 8 forces the old loop); results must be bit-equal"""
+"""developer probe: the software-pipelined 64x64-wave-tile loop against the compiler-scheduled one (MRAG_GEMM_TUNE_PLAIN_LOOP = 8) on the small-M GEMMs that run
+128x128 tiles; results must be bit-equal"""
 import os
 import sys
 
@@ -22,5 +22,5 @@ for (M, N, K, what) in ((452, 12288, 4096, "T5 qkv"), (452, 4096, 4096, "T5 o"),
             ref = y if ref is None else ref
             assert torch.equal(y, ref), (what, flag)
             dt = timeit(lambda: ops.linear(x, w), iters=50, warm=5)
-            print(f"{what:22s} M={M} N={N} K={K} stages={'2' if flag else '4'}: {dt*1e6:.1f} us  weights {N*K*2/dt/1e12:.2f} TB/s")
+            print(f"{what:22s} M={M} N={N} K={K} loop={'plain' if flag else 'pipelined'}: {dt*1e6:.1f} us  weights {N*K*2/dt/1e12:.2f} TB/s")
 ops.TUNING["gemm"] = 0

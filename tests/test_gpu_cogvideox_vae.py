@@ -167,3 +167,20 @@ def test_shipped_width_decode_and_encode_match_oracle(hip):
     assert rel(m.decode(z.to(DEV)).sample, want) < 3e-2
     x = bf(torch.rand(1, 3, 1, 64, 96, generator=g) * 2 - 1)
     assert rel(m.encode(x.to(DEV)).latent_dist.parameters, R.encode_moments(sd, R.CONFIG_5B, x, tiling=False)) < 3e-2
+
+
+def test_shipped_configuration_full_tiled_decode(hip):
+    """the headline clip's latents [1, 16, 13, 60, 90] through the tiled decode the reference configures (nine tiles x six frame batches): 49 x 480 x 720 out, finite,
+    and the three-stream fan-out of the tiles is bit-equal to issuing them on one stream"""
+    m, _ = _model(R.CONFIG_5B, 22)
+    m.enable_tiling()
+    m.enable_slicing()
+    z = bf(torch.randn(1, 16, 13, 60, 90, generator=torch.Generator().manual_seed(6))).to(DEV)
+    m.tile_streams = 3
+    a = m.decode(z).sample
+    assert a.shape == (1, 3, 49, 480, 720) and torch.isfinite(a.float()).all() and a.float().abs().mean().item() > 1e-3
+    m.tile_streams = 1
+    assert torch.equal(m.decode(z).sample, a)
+    img = bf(torch.rand(1, 3, 1, 480, 720, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(DEV)
+    post = m.encode(img).latent_dist
+    assert post.mean.shape == (1, 16, 1, 60, 90) and torch.isfinite(post.mean).all()

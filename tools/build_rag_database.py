@@ -25,12 +25,26 @@ if __name__ == "__main__":
     ap.add_argument("--caption_name", type=str, default="motion_caption")
     ap.add_argument("--n_synthetic", type=int, default=10000)
     ap.add_argument("--ref_video_num", type=int, default=9)
+    ap.add_argument("--gte_dir", type=str, default=None, help="local snapshot of Alibaba-NLP/gte-base-en-v1.5 (model.safetensors + tokenizer files): captions are embedded by "
+                    "motionrag_amd.text_embedder on the GPU, as the reference's LanceDB embedding function does (tools/build_rag_database.py:28-31); default: hash-seeded unit vectors")
     args = ap.parse_args()
 
     annotations = torch.load(args.annotations_path) if args.annotations_path else rag.synthetic_captions(args.n_synthetic)
-    embed = rag.hash_embedder(768)
     t0 = time.perf_counter()
-    emb = np.stack([np.asarray(a["text_embedding"], np.float32) if "text_embedding" in a else embed(a[args.caption_name] or "") for a in annotations])
+    if args.gte_dir:
+        import safetensors.torch
+        from transformers import AutoTokenizer
+        from motionrag_amd.text_embedder import NewModel, SentenceEmbedder
+        model = NewModel()
+        sd = safetensors.torch.load_file(os.path.join(args.gte_dir, "model.safetensors"))
+        model.load_state_dict({k[len("new."):] if k.startswith("new.") else k: v for k, v in sd.items() if "position_ids" not in k and not k.startswith("pooler")}, strict=True)
+        tok = AutoTokenizer.from_pretrained(args.gte_dir)
+        embedder = SentenceEmbedder(model.to("cuda", torch.bfloat16), lambda texts: tok(list(texts), truncation=True, max_length=8192)["input_ids"])
+        texts = [a[args.caption_name] or "" for a in annotations]
+        emb = torch.cat([embedder.encode(texts[i:i + 4096]) for i in range(0, len(texts), 4096)]).cpu().numpy()
+    else:
+        embed = rag.hash_embedder(768)
+        emb = np.stack([np.asarray(a["text_embedding"], np.float32) if "text_embedding" in a else embed(a[args.caption_name] or "") for a in annotations])
     rows = rag.prepare_annotations(annotations, text_name=args.caption_name, dataset_name=args.dataset)
     rag.add_to_db(rows, emb, text_name=args.caption_name, db_path=args.db_path)
     t1 = time.perf_counter()

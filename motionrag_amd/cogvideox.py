@@ -431,7 +431,8 @@ class CogVideoXImageToVideoActionPipeline:
         the two guidance branches at batch b and the pair exchanges the velocity prediction (2.2 MB per step) before the shared update.
         With a `CogVideoXDPMScheduler` the update is the stochastic DPM step: its noise is drawn per step from `generator` exactly as the reference's
         `randn_tensor(sample.shape, generator, device, dtype)` does (bf16, on the generator's device; TWO draws on a second-order step, the second one used).
-        `use_dynamic_cfg`: the cosine guidance schedule of diffusers' pipeline (off by default there and in the reference's calls)."""
+        `use_dynamic_cfg`: the cosine guidance schedule of diffusers' pipeline (off by default there and in the reference's calls).
+        Ranks that share a clip (`sp`, `cfgp`) must pass generators in the SAME state: every one of them draws the clip's sampler noise itself."""
         self.action_emb = action_emb
         dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)
         x0_prev = torch.zeros_like(latents) if dpm else None

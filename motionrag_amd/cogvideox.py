@@ -99,14 +99,16 @@ class CogVideoXTransformer3DModel(nn.Module):
 
     def __init__(self, num_layers=42, num_attention_heads=48, attention_head_dim=64, in_channels=32, out_channels=16, time_embed_dim=512,
                  text_embed_dim=4096, max_text_seq_length=226, patch_size=2, sample_frames=13, sample_height=60, sample_width=90,
-                 norm_eps=1e-5):
+                 norm_eps=1e-5, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0):
         super().__init__()
         if attention_head_dim != 64:
             raise NotImplementedError("head_dim 64 only")
         D = num_attention_heads * attention_head_dim
         self.cfg = dict(num_layers=num_layers, heads=num_attention_heads, dim=D, in_channels=in_channels, out_channels=out_channels,
                         time_embed_dim=time_embed_dim, text_embed_dim=text_embed_dim, max_text=max_text_seq_length, patch=patch_size,
-                        norm_eps=norm_eps)
+                        norm_eps=norm_eps, sample=(sample_frames, sample_height // patch_size, sample_width // patch_size),
+                        pos_scales=(spatial_interpolation_scale, temporal_interpolation_scale))
+        self._pos_tables: Dict[tuple, torch.Tensor] = {}
         n_video = sample_frames * (sample_height // patch_size) * (sample_width // patch_size)
         self.patch_embed = _PatchEmbed(patch_size, in_channels, D, text_embed_dim, max_text_seq_length + n_video)
         self.time_embedding = _TimeEmbedding(D, time_embed_dim)
@@ -150,6 +152,26 @@ class CogVideoXTransformer3DModel(nn.Module):
             self._fused["patch_w"] = self.patch_embed.proj.weight.detach().reshape(self.cfg["dim"], -1).contiguous()
         return self._fused["mod_w"], self._fused["mod_b"]
 
+    def joint_pos_embedding(self, frames: int, height: int, width: int) -> torch.Tensor:
+        """[max_text + frames * height * width, D] bf16: the positional rows added to the joint sequence (diffusers 0.32.2
+        `CogVideoXPatchEmbed.forward`, parity unpinned).  At the model's own sample geometry that is the LEARNED table of the checkpoint.  For any
+        other clip length diffusers does not slice the learned table: it REGENERATES a table with `_get_positional_embeddings` -- 3-D sin-cos video
+        rows at the model's interpolation scales and ZERO text rows -- which is what the reference's shipped evaluation runs with (17 frames ->
+        5 latent frames on a 13-frame model, configs/cogvideox/MotionRAG_open.yml:189-194).  A different resolution is refused, as diffusers
+        refuses it for learned tables.  Host-built once per geometry, cached on the device."""
+        cfg = self.cfg
+        sf, sh, sw = cfg["sample"]
+        if (height, width) != (sh, sw):
+            raise ValueError(f"{height}x{width} patch grid: a model with learned positional embeddings runs at its own resolution only ({sh}x{sw})")
+        if frames == sf:
+            return self.patch_embed.pos_embedding[0]
+        key = (frames, height, width, self.patch_embed.pos_embedding.device)
+        if key not in self._pos_tables:
+            video = get_3d_sincos_pos_embed(cfg["dim"], (width, height), frames, *cfg["pos_scales"])
+            joint = torch.cat([torch.zeros(cfg["max_text"], cfg["dim"]), video], dim=0)
+            self._pos_tables[key] = joint.to(self.patch_embed.pos_embedding.device, torch.bfloat16).contiguous()
+        return self._pos_tables[key]
+
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
                 image_rotary_emb=None, image_latents: Optional[torch.Tensor] = None, batch: Optional[int] = None, sp=None) -> torch.Tensor:
@@ -166,9 +188,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         Lt = encoder_hidden_states.shape[1]
         Nv = F * (H // p) * (W // p)
         S = Lt + Nv
-        if S > self.patch_embed.pos_embedding.shape[1] or Lt != cfg["max_text"]:
-            raise ValueError(f"{Lt} text + {Nv} video tokens do not fit the model's positional table ({cfg['max_text']} text rows + "
-                             f"{self.patch_embed.pos_embedding.shape[1] - cfg['max_text']} video rows: sample_frames / sample_height / sample_width)")
+        if Lt != cfg["max_text"]:
+            raise ValueError(f"{Lt} text tokens: the positional table has {cfg['max_text']} text rows (max_text_seq_length)")
         (rope, ip) = image_rotary_emb if (isinstance(image_rotary_emb, tuple) and isinstance(image_rotary_emb[0], tuple)) else (image_rotary_emb, None)
         mod_w, mod_b = self._mod_weights()
 
@@ -180,12 +201,11 @@ class CogVideoXTransformer3DModel(nn.Module):
         ms = mod.stride(0)
 
         # patch embed (Conv2d k=2 s=2 as a GEMM over patch rows) + text projection + positional embedding
-        r0, r1 = (0, S) if sp is None else sp.shard(S)              # this rank's rows of the joint sequence
+        from .dist import SequenceParallel
+        r0, r1, Ltl, t0, v0, v1 = (SequenceParallel(0, 1) if sp is None else sp).layout(S, Lt)   # this rank's rows: text [t0, t0 + Ltl) first, video [v0, v1)
         Sl = r1 - r0
-        Ltl = min(max(Lt - r0, 0), Sl)                              # local text rows come first
-        t0, v0, v1 = r0, max(r0, Lt) - Lt, r1 - Lt                  # text rows [t0, t0 + Ltl), video rows [v0, v1)
         x = torch.empty(B, Sl, D, dtype=torch.bfloat16, device=hidden_states.device)
-        pos = self.patch_embed.pos_embedding[0]
+        pos = self.joint_pos_embedding(F, H // p, W // p)
         patches = ops.patchify(hidden_states, image_latents, B).view(B, Nv, -1)
         for b in range(B):
             if Ltl > 0:
@@ -233,6 +253,30 @@ class CogVideoXTransformer3DModel(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------
+def get_3d_sincos_pos_embed(embed_dim: int, spatial_size: Tuple[int, int], temporal_size: int, spatial_interpolation_scale: float = 1.0,
+                            temporal_interpolation_scale: float = 1.0) -> torch.Tensor:
+    """host-side table of diffusers' `get_3d_sincos_pos_embed` (0.32.2; parity unpinned): [T * H * W, D] fp32, spatial_size = (W, H).
+    Row (t, y, x) = [ sincos(t / ts ; D/4) | sincos(x / ss ; 3D/8) | sincos(y / ss ; 3D/8) ] with sincos(p ; n) = [sin(p w_k), cos(p w_k)],
+    w_k = 10000^(-k / (n/2)), k < n/2 -- the MAE layout, in which the slot diffusers NAMES `emb_h` is fed the x coordinate (its meshgrid
+    puts w first); kept, since the checkpoint's learned table was initialised from exactly this."""
+    if embed_dim % 4:
+        raise ValueError("`embed_dim` must be divisible by 4")
+    W, H = spatial_size
+    T = temporal_size
+
+    def sincos(pos: torch.Tensor, n: int) -> torch.Tensor:
+        w = 10000.0 ** (-torch.arange(n // 2, dtype=torch.float64) / (n / 2.0))
+        a = pos.to(torch.float64)[:, None] * w[None, :]
+        return torch.cat([a.sin(), a.cos()], dim=1)
+    ds, dt = 3 * embed_dim // 4, embed_dim // 4
+    ex = sincos(torch.arange(W, dtype=torch.float32) / spatial_interpolation_scale, ds // 2)       # [W, ds/2]
+    ey = sincos(torch.arange(H, dtype=torch.float32) / spatial_interpolation_scale, ds // 2)       # [H, ds/2]
+    et = sincos(torch.arange(T, dtype=torch.float32) / temporal_interpolation_scale, dt)           # [T, dt]
+    out = torch.cat([et[:, None, None, :].expand(T, H, W, dt), ex[None, None, :, :].expand(T, H, W, ds // 2),
+                     ey[None, :, None, :].expand(T, H, W, ds // 2)], dim=-1)
+    return out.reshape(T * H * W, embed_dim).to(torch.float32)
+
+
 def get_3d_rotary_pos_embed(head_dim: int, t: int, h: int, w: int, theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
     """host-side table (diffusers get_3d_rotary_pos_embed, use_real=True, crop == full grid): [t*h*w, d] fp32."""
     def one(dim, n):
@@ -344,7 +388,8 @@ class CogVideoXImageToVideoActionPipeline:
     def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer: CogVideoXTransformer3DModel = None, scheduler=None,
                  action_embedder=None, action_proj_model=None, ref_fusion_type: str = "mean"):
         self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
-        self.transformer, self.scheduler = transformer, scheduler
+        self.transformer = transformer
+        self.scheduler = scheduler if scheduler is not None else CogVideoXDPMScheduler()   # module.py:44: the motion-injected pipelines get the DPM scheduler
         self.action_embedder, self.action_proj_model = action_embedder, action_proj_model
         self.ref_fusion_type = ref_fusion_type
         self._rope_cache = {}
@@ -402,15 +447,22 @@ class CogVideoXImageToVideoActionPipeline:
     def _vae_scale(self) -> float:
         return float(getattr(getattr(self.vae, "config", None), "scaling_factor", 0.7))
 
-    def encode_image_latents(self, image: torch.Tensor, lat_frames: int, generator=None) -> torch.Tensor:
-        """image [b, 3, H, W] in [0, 1] -> [b, F, 16, H/8, W/8]: VAE latents of the first frame, zero-padded to F latent frames"""
-        x = (image.to(torch.float32) * 2.0 - 1.0).unsqueeze(2)                     # diffusers video_processor.preprocess: [0, 1] -> [-1, 1]
-        enc = self.vae.encode(x.to(self._execution_device))
-        if hasattr(enc, "latent_dist"):
-            enc = enc.latent_dist.sample(generator)
-        elif hasattr(enc, "sample") and callable(enc.sample):
-            enc = enc.sample()
-        z = enc * self._vae_scale()                                                 # [b, 16, 1, h, w]
+    def encode_image_latents(self, image: torch.Tensor, lat_frames: int, generator=None, height: Optional[int] = None, width: Optional[int] = None) -> torch.Tensor:
+        """image [b, 3, H, W] in [0, 1] -> [b, F, 16, H/8, W/8]: VAE latents of the first frame, zero-padded to F latent frames (diffusers
+        `prepare_latents`: every image is encoded and its posterior sampled on its own, in batch order, so the generator is consumed image by image).
+        diffusers' `video_processor.preprocess` would resize to height x width first; a mismatching image is refused here instead."""
+        if height is not None and tuple(image.shape[-2:]) != (height, width):
+            raise ValueError(f"image is {tuple(image.shape[-2:])}, the call asks for {(height, width)}: resize it before the pipeline")
+        x = (image.to(torch.float32) * 2.0 - 1.0).unsqueeze(2)                     # [0, 1] -> [-1, 1], one frame
+        zs = []
+        for one in x.to(self._execution_device).split(1):
+            enc = self.vae.encode(one)
+            if hasattr(enc, "latent_dist"):
+                enc = enc.latent_dist.sample(generator)
+            elif hasattr(enc, "sample") and callable(enc.sample):
+                enc = enc.sample()
+            zs.append(enc)
+        z = torch.cat(zs, dim=0) * self._vae_scale()                                # [b, 16, 1, h, w]
         z = z.permute(0, 2, 1, 3, 4)                                                # [b, 1, 16, h, w]
         pad = torch.zeros(z.shape[0], lat_frames - 1, *z.shape[2:], dtype=z.dtype, device=z.device)
         return torch.cat([z, pad], dim=1)
@@ -514,11 +566,11 @@ class CogVideoXImageToVideoActionPipeline:
         if image_latents is None:
             if self.vae is None:
                 raise ValueError("pass image_latents or a vae")
-            image_latents = self.encode_image_latents(image, F, generator)
-        if latents is None:
-            noise = torch.randn(b, F, self.transformer.cfg["out_channels"], height // 8, width // 8, generator=generator,
-                                dtype=torch.float32)                                     # CPU-seeded
-            latents = noise.to(dev, torch.bfloat16)                                      # DDIM: init_noise_sigma == 1
+            image_latents = self.encode_image_latents(image, F, generator, height, width)
+        if latents is None:                                                              # randn_tensor(shape, generator, device, dtype = bf16): drawn IN bf16 on the
+            gdev = generator.device if generator is not None else torch.device("cpu")    # generator's device (a CPU generator by default), then moved
+            latents = torch.randn(b, F, self.transformer.cfg["out_channels"], height // 8, width // 8, generator=generator, dtype=torch.bfloat16,
+                                  device=gdev).to(dev)                                   # init_noise_sigma == 1 for both schedulers
         latents = self.denoise(latents.to(dev, torch.bfloat16).contiguous(), image_latents.to(dev, torch.bfloat16).contiguous(), pe,
                                self.action_emb, num_inference_steps, guidance_scale, generator=generator, use_dynamic_cfg=use_dynamic_cfg)
         if output_type == "latent":
@@ -576,22 +628,30 @@ def set_attention_processors(transformer: CogVideoXTransformer3DModel, adapter_m
     transformer.set_attn_processor(attn)
 
 
+_FRAME_PICKERS = {
+    "first": lambda n: slice(0, 16),
+    "uniform": lambda n: torch.linspace(0, n - 1, 16).round().long(),
+    None: lambda n: slice(None),
+}
+
+
 def eval_pipeline(pipe, image, positive_prompt, negative_prompt, dtype, ref_videos, metadata, *args, **kwargs) -> torch.Tensor:
-    """CogVideoX5BAction.eval_pipeline (cogvideox/module.py:197-223): image in [-1, 1] -> video [b, 16, c, H, W] in [-1, 1].  `kwargs` is the YAML's
-    `eval_pipeline_call_kwargs`: a `scheduler` entry ('ddim' | 'dpm') selects the pipeline's scheduler as module.py:28-35 does when it builds the pipeline."""
-    image = image / 2 + 0.5                                                          # denormalize
-    sample_method = kwargs.pop("sample_method", "first")
-    scheduler_name = kwargs.pop("scheduler", None)
-    if scheduler_name is not None:
-        pipe.scheduler = make_scheduler(scheduler_name)
-    frames = pipe(prompt=positive_prompt, image=image, negative_prompt=negative_prompt, output_type="pt", ref_videos=ref_videos,
-                  metadata=metadata, *args, **kwargs)
-    video = frames[0]
-    if sample_method == "first":
-        video = video[:, :16, ...]                                                   # use only the first 16 frames
-    elif sample_method == "uniform":
-        frame_idx = torch.linspace(0, video.shape[1] - 1, 16).round().long()
-        video = video[:, frame_idx.to(video.device), ...]
-    elif sample_method is not None:
-        raise ValueError(f"Unknown sample method: {sample_method}")
-    return video * 2 - 1                                                             # normalize
+    """CogVideoX5BAction.eval_pipeline (cogvideox/module.py:197-223): image in [-1, 1] -> video [b, 16 | all, c, H, W] in [-1, 1].
+
+    `kwargs` is the YAML's `eval_pipeline_call_kwargs`.  Its `scheduler` entry never reaches the reference's pipeline call: module.py:28-35 pops it
+    while the module is configured, validates it ('ddim' | 'dpm') and installs it on the BASELINE pipe only; the motion-injected Action / CT pipelines
+    are built with `scheduler=self.scheduler`, which is always the DPM scheduler (module.py:44, 183, 255).  Same rule here: the entry is validated,
+    installed on a baseline `CogVideoXImageToVideoPipeline`, and otherwise dropped -- an Action / CT pipeline samples with the scheduler it was built
+    with (`scheduler=None` in its constructor builds the reference's DPM scheduler)."""
+    chosen = make_scheduler(kwargs.pop("scheduler", "ddim"))                         # unknown names raise as the reference's configure step does
+    if isinstance(pipe, CogVideoXImageToVideoPipeline):
+        pipe.scheduler = chosen
+    pick = kwargs.pop("sample_method", "first")
+    if pick not in _FRAME_PICKERS:
+        raise ValueError(f"Unknown sample method: {pick}")
+    out = pipe(prompt=positive_prompt, image=image / 2 + 0.5,                  # [-1, 1] -> [0, 1]: the pipeline's image convention
+               negative_prompt=negative_prompt, output_type="pt", ref_videos=ref_videos, metadata=metadata, *args, **kwargs)
+    video = out[0]
+    idx = _FRAME_PICKERS[pick](video.shape[1])
+    video = video[:, idx.to(video.device) if isinstance(idx, torch.Tensor) else idx]
+    return video * 2 - 1

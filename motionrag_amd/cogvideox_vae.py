@@ -277,12 +277,13 @@ def frame_batches(num_frames: int, batch: int) -> List[Tuple[int, int]]:
 
 
 class _Posterior(DiagonalGaussianDistribution):
-    """`encode(x).latent_dist`: diffusers' `sample(generator)` draws with `randn_tensor` on the generator's device"""
+    """`encode(x).latent_dist`: diffusers' `sample(generator)` draws with `randn_tensor(mean.shape, generator, device, dtype = parameters.dtype)`: in the
+    VAE's dtype (bf16 in the reference's pipeline, cogvideox/module.py:23-26), on the generator's device"""
 
-    def sample(self, generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def sample(self, generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
         if noise is None:
             gen_dev = generator.device if generator is not None else self.mean.device
-            noise = torch.randn(self.mean.shape, generator=generator, device=gen_dev, dtype=torch.float32)
+            noise = torch.randn(self.mean.shape, generator=generator, device=gen_dev, dtype=dtype)
         return super().sample(noise)
 
 

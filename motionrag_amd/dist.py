@@ -57,6 +57,14 @@ class SequenceParallel:
         s = n_rows // self.world
         return self.rank * s, (self.rank + 1) * s
 
+    def layout(self, n_rows: int, text_len: int) -> "RowLayout":
+        """this rank's slice of the joint [text ; video] sequence: rows [r0, r1) of the joint order, of which the first `text` are text rows
+        [t0, t0 + text) of the prompt and the rest video tokens [v0, v1) of the patch grid.  At the headline geometry (17 776 rows, 226 text
+        rows, 8 ranks of 2 222) only rank 0 holds text and its split point is 226; every other rank's split is 0."""
+        r0, r1 = self.shard(n_rows)
+        text = min(max(text_len - r0, 0), r1 - r0)
+        return RowLayout(r0, r1, text, r0, max(r0, text_len) - text_len, max(r1, text_len) - text_len)
+
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         """[n, ...] per rank -> [world * n, ...] (rank-major) on every rank"""
         if self._ag is not None:
@@ -73,15 +81,34 @@ class SequenceParallel:
     def all_gather_rows_async(self, x: torch.Tensor) -> "_Pending":
         """x [B, n, W] (this rank's rows of every sample, contiguous) -> pending [B, world * n, W]: one all-gather per sample straight into
         that sample's slice of the result (rank-major == global row order: no permute, no copy), issued with async_op=True so that RCCL runs
-        them on its own stream while the caller keeps launching work on the current stream; `.wait()` orders the current stream behind them."""
+        them on its own stream while the caller keeps launching work on the current stream; `.wait()` orders the current stream behind them.
+
+        With a host-side transport (gloo: the one-GPU developer / test configuration, MRAG_BENCH_ONE_GPU) the exchange is asynchronous too and
+        keeps the same ordering structure: an event on the producing stream, a SIDE stream that stages the rows to pinned host memory, a helper
+        thread that runs the collective and uploads the gathered rows on the side stream, and a second event that `.wait()` puts in front of
+        the consumer -- so the stream / event discipline of the RCCL path is what the two-process GPU test executes, not a synchronous copy."""
         B, n, W = x.shape
         if not x.is_contiguous():
             raise ValueError("all_gather_rows_async: contiguous [B, n, W] required")
-        if self._ag is not None or (x.is_cuda and dist.get_backend(self.group) == "gloo"):    # test harness / one-GPU developer runs: synchronous
+        if self._ag is not None:                                                               # in-process test harness (ranks as threads)
             return _Pending(torch.stack([self.all_gather(x[b]) for b in range(B)]), [])
         out = torch.empty(B, self.world * n, W, dtype=x.dtype, device=x.device)
+        if dist.get_backend(self.group) == "gloo":
+            return _HostStagedGather(self, x, out) if x.is_cuda else _gather_rows_host(self, x, out)
         works = [dist.all_gather_into_tensor(out[b], x[b], group=self.group, async_op=True) for b in range(B)]
         return _Pending(out, works)
+
+
+class RowLayout(tuple):
+    """(r0, r1, text, t0, v0, v1): see SequenceParallel.layout"""
+    __slots__ = ()
+
+    def __new__(cls, r0, r1, text, t0, v0, v1):
+        return tuple.__new__(cls, (r0, r1, text, t0, v0, v1))
+
+    r0 = property(lambda s: s[0]); r1 = property(lambda s: s[1]); text = property(lambda s: s[2])
+    t0 = property(lambda s: s[3]); v0 = property(lambda s: s[4]); v1 = property(lambda s: s[5])
+    rows = property(lambda s: s[1] - s[0])
 
 
 class _Pending:
@@ -92,6 +119,65 @@ class _Pending:
         for w in self.works:
             w.wait()
         return self.out
+
+
+def _gather_rows_host(sp, x_host: torch.Tensor, out_host: torch.Tensor) -> "_Pending":
+    """[B, n, W] host rows of every rank -> out_host [B, world * n, W]; ONE collective for all samples (rank-major parts re-sliced per sample)"""
+    B, n, W = x_host.shape
+    parts = [torch.empty(x_host.shape, dtype=x_host.dtype) for _ in range(sp.world)]
+    dist.all_gather(parts, x_host, group=sp.group)
+    for r, p in enumerate(parts):
+        out_host[:, r * n:(r + 1) * n].copy_(p)
+    return _Pending(out_host, [])
+
+
+class _HostStagedGather:
+    """asynchronous K/V row exchange over a host transport; see SequenceParallel.all_gather_rows_async"""
+
+    def __init__(self, sp, x: torch.Tensor, out: torch.Tensor):
+        import threading
+        self.out = out
+        self._side = _side_stream(x.device)
+        self._done = torch.cuda.Event()
+        self._err = None
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x.device))                 # the K|V projection that produced x
+        host_in = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+        host_out = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        x.record_stream(self._side); out.record_stream(self._side)
+
+        def run():
+            try:
+                with torch.cuda.device(x.device), torch.cuda.stream(self._side):      # the current device is per thread
+                    self._side.wait_event(ready)
+                    host_in.copy_(x, non_blocking=True)
+                    self._side.synchronize()                              # blocks this helper thread only
+                    _gather_rows_host(sp, host_in, host_out)
+                    out.copy_(host_out, non_blocking=True)
+                    self._done.record(self._side)
+                    self._side.synchronize()                              # host_out must outlive the upload
+            except BaseException as e:                                   # surfaced by wait()
+                self._err = e
+
+        self._thread = threading.Thread(target=run, name="mrag-kv-gather", daemon=True)
+        self._thread.start()
+
+    def wait(self) -> torch.Tensor:
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        torch.cuda.current_stream(self.out.device).wait_event(self._done)
+        return self.out
+
+
+_SIDE = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 class RcclComm:

@@ -202,8 +202,13 @@ def set_attention_processors(unet, adapter_modules: Iterable[str], cross_attenti
 
 
 def eval_pipeline(pipe, image, positive_prompt=None, negative_prompt=None, dtype=None, ref_videos=None, metadata=None, *args, **kwargs):
-    """SVDActionModule.eval_pipeline (svd/module.py:169-191): image in [-1, 1] -> `.frames[:, :16] * 2 - 1`.  The reference converts the
-    image to PIL (`tensor2PIL`) and the pipeline converts it back; here the [0, 255] tensor goes in directly."""
-    img255 = (image.float() / 2 + 0.5).clamp(0, 1) * 255.0
-    frames = pipe(image=img255, ref_videos=ref_videos, metadata=metadata, output_type="pt", *args, **kwargs).frames[:, :16]
+    """SVDActionModule.eval_pipeline (svd/module.py:169-191): image in [-1, 1] -> `.frames[:, :16] * 2 - 1`.
+
+    The reference hands the pipeline PIL images: `tensor2PIL` (module.py:181) goes through `denormalize` (src/utils/pipeline.py:178-184), i.e.
+    `clip((x + 1) / 2, 0, 1) * 255` TRUNCATED to uint8, and the pipeline reads them back with `pil_to_tensor(img) / 127.5 - 1`
+    (svd/pipelines/pipeline.py:154-155).  CLIP, the noise-augmented VAE input and CAMA's target frame therefore all see the quantised image; the
+    same uint8 hop runs here on the GPU (`mrag_denormalize_u8`, bit-exact with the torch ops) and the pipeline receives the uint8 tensor."""
+    from .eval_harness import denormalize
+    img_u8 = denormalize(image.to(pipe._execution_device)).to(image.device)
+    frames = pipe(image=img_u8, ref_videos=ref_videos, metadata=metadata, output_type="pt", *args, **kwargs).frames[:, :16]
     return frames * 2 - 1

@@ -34,7 +34,8 @@ class DiTConfig:
 
     def __init__(self, num_layers=42, heads=48, head_dim=64, in_channels=32, out_channels=16, time_embed_dim=512,
                  text_embed_dim=4096, max_text_len=226, patch=2, ip_dim=1024, norm_eps=1e-5, qk_eps=1e-6,
-                 frames=13, height=60, width=90):
+                 frames=13, height=60, width=90, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0):
+        self.spatial_interpolation_scale, self.temporal_interpolation_scale = spatial_interpolation_scale, temporal_interpolation_scale
         self.num_layers, self.heads, self.head_dim = num_layers, heads, head_dim
         self.dim = heads * head_dim
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -157,6 +158,47 @@ def block(sd: SD, cfg: DiTConfig, h, e, temb, rope, ip_hidden, ip_scale=1.0):
     return h, e
 
 
+def sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    """diffusers get_1d_sincos_pos_embed_from_grid: [M] positions -> [M, embed_dim] = [sin | cos], float64"""
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1).astype(np.float64), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_3d(embed_dim: int, spatial_size, temporal_size: int, spatial_interpolation_scale: float = 1.0,
+              temporal_interpolation_scale: float = 1.0) -> np.ndarray:
+    """diffusers get_3d_sincos_pos_embed (0.32.2), step by step as the package writes it (the MAE recipe): [T, H*W, D]; spatial_size = (W, H)"""
+    d_spatial, d_temporal = 3 * embed_dim // 4, embed_dim // 4
+    grid_h = np.arange(spatial_size[1], dtype=np.float32) / spatial_interpolation_scale
+    grid_w = np.arange(spatial_size[0], dtype=np.float32) / spatial_interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0)                       # w goes first
+    grid = grid.reshape([2, 1, spatial_size[1], spatial_size[0]])
+    emb_h = sincos_1d(d_spatial // 2, grid[0])                                 # get_2d_sincos_pos_embed_from_grid
+    emb_w = sincos_1d(d_spatial // 2, grid[1])
+    pos_spatial = np.concatenate([emb_h, emb_w], axis=1)                       # [H*W, 3D/4]
+    grid_t = np.arange(temporal_size, dtype=np.float32) / temporal_interpolation_scale
+    pos_temporal = sincos_1d(d_temporal, grid_t)                               # [T, D/4]
+    pos_spatial = np.repeat(pos_spatial[np.newaxis, :, :], temporal_size, axis=0)
+    pos_temporal = np.repeat(pos_temporal[:, np.newaxis, :], spatial_size[0] * spatial_size[1], axis=1)
+    return np.concatenate([pos_temporal, pos_spatial], axis=-1)
+
+
+def patch_embed_positions(sd: SD, cfg: DiTConfig, frames: int, height: int, width: int) -> torch.Tensor:
+    """CogVideoXPatchEmbed.forward's choice of table (diffusers 0.32.2, use_learned_positional_embeddings): the learned parameter at the model's
+    sample geometry; otherwise `_get_positional_embeddings` -- a freshly generated sin-cos table with ZERO text rows (never a slice of the learned
+    one); a different resolution raises.  [1, max_text + frames*height*width, D]"""
+    if (height, width) != (cfg.height // cfg.patch, cfg.width // cfg.patch):
+        raise ValueError("learned positional embeddings: the model's own resolution only")
+    if frames == cfg.frames:
+        return sd["patch_embed.pos_embedding"]
+    video = torch.from_numpy(sincos_3d(cfg.dim, (width, height), frames, cfg.spatial_interpolation_scale, cfg.temporal_interpolation_scale)).flatten(0, 1)
+    joint = torch.zeros(1, cfg.max_text_len + video.shape[0], cfg.dim)
+    joint[:, cfg.max_text_len:] = video.float()
+    return joint
+
+
 def dit_forward(sd: SD, cfg: DiTConfig, latents: torch.Tensor, text: torch.Tensor, timestep: torch.Tensor, rope, ip_hidden,
                 ip_scale: float = 1.0) -> torch.Tensor:
     """CogVideoXTransformer3DModel.forward (5B-I2V flavour: rotary + learned positional embedding).
@@ -169,7 +211,7 @@ def dit_forward(sd: SD, cfg: DiTConfig, latents: torch.Tensor, text: torch.Tenso
     e = F.linear(text, sd["patch_embed.text_proj.weight"], sd["patch_embed.text_proj.bias"])
     x = F.conv2d(latents.reshape(B * Fr, C, H, W), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=p)
     x = x.view(B, Fr, cfg.dim, -1).transpose(2, 3).flatten(1, 2)     # [B, F*h*w, D]
-    x = torch.cat([e, x], dim=1) + sd["patch_embed.pos_embedding"][:, : e.size(1) + x.size(1)]
+    x = torch.cat([e, x], dim=1) + patch_embed_positions(sd, cfg, Fr, H // p, W // p).to(x.dtype)
     text_len = e.size(1)
     e, h = x[:, :text_len], x[:, text_len:]
     for i in range(cfg.num_layers):

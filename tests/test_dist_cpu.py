@@ -132,3 +132,75 @@ def test_unet_frame_pixel_all_to_all_world2_gloo():
     mp.spawn(_a2a_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r] == (True, True, (2, 4, 3, 3))
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config #4 at its real geometry
+S_FULL, LT_FULL, B_FULL, WORLD8 = 17776, 226, 2, 8          # 226 text + 13 x 30 x 45 video rows; CFG batch 2; one node of 8 GPUs
+
+
+def test_sequence_layout_world8_real_geometry():
+    """SequenceParallel.layout at 17 776 rows over 8 ranks: 2 222 rows each, the text / video split (226) falls INSIDE rank 0, every other rank holds
+    video rows only; text and video ranges tile the prompt and the patch grid exactly once, in order (what cogvideox.forward slices by)"""
+    from motionrag_amd.dist import SequenceParallel
+    text, video, rows = [], [], []
+    for r in range(WORLD8):
+        lay = SequenceParallel(r, WORLD8).layout(S_FULL, LT_FULL)
+        assert lay.rows == 2222 and (lay.r0, lay.r1) == (2222 * r, 2222 * (r + 1))
+        assert lay.text == (LT_FULL if r == 0 else 0) and lay.t0 == lay.r0
+        assert lay.v1 - lay.v0 == lay.rows - lay.text                       # local rows = text rows first, then video rows
+        text += list(range(lay.t0, lay.t0 + lay.text)); video += list(range(lay.v0, lay.v1)); rows += list(range(lay.r0, lay.r1))
+    assert text == list(range(LT_FULL)) and video == list(range(S_FULL - LT_FULL)) and rows == list(range(S_FULL))
+    # a split that straddles two ranks (text longer than one shard) and a rank made of text only
+    lays = [SequenceParallel(r, 4).layout(40, 25) for r in range(4)]
+    assert [tuple(l) for l in lays] == [(0, 10, 10, 0, 0, 0), (10, 20, 10, 10, 0, 0), (20, 30, 5, 20, 0, 5), (30, 40, 0, 30, 5, 15)]
+    with pytest.raises(ValueError):
+        SequenceParallel(0, 8).layout(17777, 226)
+    assert tuple(SequenceParallel(0, 1).layout(S_FULL, LT_FULL)) == (0, S_FULL, LT_FULL, 0, 0, S_FULL - LT_FULL)
+
+
+def _w8_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from motionrag_amd.dist import CFGParallel, SequenceParallel, gather_latents
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = {}
+        sp = SequenceParallel(rank, world)
+        lay = sp.layout(S_FULL, LT_FULL)
+        # the joint sequence as the DiT assembles it on this rank (cogvideox.forward): local text rows first, then local video rows
+        W = 6
+        text_src = torch.arange(LT_FULL, dtype=torch.float32)[None, :, None] + 1e6 * torch.arange(B_FULL)[:, None, None] + torch.zeros(W)                   # [B, Lt, W]
+        video_src = 5e4 + torch.arange(S_FULL - LT_FULL, dtype=torch.float32)[None, :, None] + 1e6 * torch.arange(B_FULL)[:, None, None] + torch.zeros(W)  # [B, Nv, W]
+        x_loc = torch.cat([text_src[:, lay.t0:lay.t0 + lay.text], video_src[:, lay.v0:lay.v1]], dim=1).contiguous()                                        # [B, 2222, W]
+        full = torch.cat([text_src, video_src], dim=1)                                                                                                       # the unsharded order
+        # (1) the per-block K|V exchange: [B, s_loc, W] -> [B, S, W], rank-major == global row order, for every sample of the CFG batch
+        pend = sp.all_gather_rows_async(x_loc)
+        ok["kv_rows"] = torch.equal(pend.wait(), full)
+        # (2) the end-of-forward exchange of the projected rows: [s_loc, B, C] -> [S, B, C] -> [B, S, C]; the video part is rows [226:]
+        out = sp.all_gather(x_loc.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        ok["out_rows"] = torch.equal(out, full) and torch.equal(out[:, LT_FULL:], video_src)
+        # (3) tier 0 (the judged default): one clip per rank, final latents [1, 13, 16, 60, 90] bf16 gathered once in rank order
+        lat = torch.full((1, 13, 16, 60, 90), float(rank), dtype=torch.bfloat16)
+        g = gather_latents(lat, world)
+        ok["latents"] = tuple(g.shape) == (world, 13, 16, 60, 90) and all(bool((g[r] == r).all()) for r in range(world))
+        # (4) tier 1: four CFG pairs; each pair exchanges its two branches of ONE clip
+        cp = CFGParallel(rank, world, group=CFGParallel.pair_groups(world, rank))
+        v = cp.gather_branches(torch.full((1, 13, 16, 60, 90), float(rank), dtype=torch.bfloat16))
+        ok["cfg"] = (cp.clip, cp.branch) == (rank // 2, rank % 2) and tuple(v.shape) == (2, 13, 16, 60, 90) and \
+            bool((v[0] == 2 * (rank // 2)).all()) and bool((v[1] == 2 * (rank // 2) + 1).all())
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_config4_world8_gloo_real_geometry():
+    """BASELINE config #4 (CogVideoX 49x480x720 over 8 GPUs) with 8 gloo ranks at the REAL row geometry -- 8 x 2 222 rows, B = 2, the 226-row text
+    block inside rank 0: the K|V row exchange (the asynchronous entry point the attention processor calls), the output-row gather, the end-of-loop
+    latent gather and the CFG pair exchange all return the unsharded order on every rank"""
+    port = 37500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_w8_worker, args=(WORLD8, port, ret), nprocs=WORLD8, join=True)
+    for r in range(WORLD8):
+        assert ret[r] == {"kv_rows": True, "out_rows": True, "latents": True, "cfg": True}, (r, ret[r])

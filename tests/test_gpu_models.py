@@ -219,6 +219,32 @@ def test_dit_forward_matches_oracle(hip):
     close(got, want)
 
 
+@pytest.mark.parametrize("frames", [2, 5])
+def test_dit_forward_other_clip_length_regenerates_the_positional_table(hip, frames):
+    """a clip shorter (the shipped 17-frame evaluation on the 49-frame model) or longer than the model's sample length: diffusers' patch embedding
+    adds a regenerated sin-cos table with zero text rows, not a slice of the learned one (oracle: patch_embed_positions; parity unpinned)"""
+    from oracle import cogvideox_ref
+    cfg, sd, model = _small_dit()
+    g = torch.Generator().manual_seed(35)
+    lat, img = (torch.randn(1, frames, 8, 8, 12, generator=g).to(torch.bfloat16) for _ in range(2))
+    text = torch.randn(2, 10, 64, generator=g).to(torch.bfloat16)
+    ip = torch.randn(2, 25, 64, generator=g).to(torch.bfloat16)
+    t = torch.tensor([481.0, 481.0])
+    cos, sin = cogvideox_ref.rope_3d(64, frames, 4, 6)
+    got = model(lat.to(DEV), text.to(DEV), t.to(DEV), image_rotary_emb=((cos.to(DEV), sin.to(DEV)), ip.to(DEV)), image_latents=img.to(DEV), batch=2)
+    x = torch.cat([torch.cat([lat] * 2), torch.cat([img] * 2)], dim=2).float()
+    want = cogvideox_ref.dit_forward(_bf_round(sd), cfg, x, text.float(), t, (cos, sin), ip.float())
+    assert got.shape == want.shape == (2, frames, 8, 8, 12)
+    close(got, want)
+    if frames < 3:      # the prefix slice of the learned table (what round 2 shipped) is a different function
+        sliced = dict(_bf_round(sd))
+        cfg2 = cogvideox_ref.DiTConfig(num_layers=cfg.num_layers, heads=2, in_channels=16, out_channels=8, time_embed_dim=64, text_embed_dim=64,
+                                       max_text_len=10, ip_dim=64, frames=frames, height=8, width=12)
+        sliced["patch_embed.pos_embedding"] = sliced["patch_embed.pos_embedding"][:, :10 + frames * 24]
+        other = cogvideox_ref.dit_forward(sliced, cfg2, x, text.float(), t, (cos, sin), ip.float())
+        assert (other - want).norm() / want.norm() > 0.05
+
+
 def test_denoise_loop_matches_oracle(hip):
     """3 DDIM steps of the motion-injected loop (CFG, v-prediction) with pre-generated CPU noise."""
     from motionrag_amd.cogvideox import CogVideoXDDIMScheduler, CogVideoXImageToVideoCTPipeline

@@ -87,7 +87,7 @@ def test_cogvideox_ct_pipeline_reference_call_surface(hip):
     # the same call, latent output, equals the hot loop driven by hand with the same noise, embeddings and image latents
     lat = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", ref_videos=ref_videos,
                metadata=metadata, generator=torch.Generator().manual_seed(3), **kw).frames
-    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3)).to(DEV, torch.bfloat16)
+    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3), dtype=torch.bfloat16).to(DEV)   # randn_tensor draws IN bf16
     te = StubText()
     pe = torch.cat([te(["blurry"]), te(["a dog runs"])])
     il = pipe.encode_image_latents(image / 2 + 0.5, 3).to(DEV, torch.bfloat16)
@@ -98,7 +98,8 @@ def test_cogvideox_ct_pipeline_reference_call_surface(hip):
     # eval_pipeline (module.py:197-223): denormalise the image, first-16 / uniform sampling, back to [-1, 1]
     vid = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **kw)
     assert vid.shape == (1, 9, 3, 64, 96) and torch.allclose(vid, out.frames * 2 - 1)
-    # uniform sampling of 16 of the decoded frames (module.py:214-216); a clip longer than the model's positional table is refused, not faulted
+    # uniform sampling of 16 of the decoded frames (module.py:214-216); a clip longer than the model's sample length runs on a regenerated positional
+    # table (diffusers' patch embedding), another resolution is refused
     class LongVAE(StubVAE):
         def decode(self, z):
             return super().decode(z).repeat_interleave(3, dim=2)                                      # 27 frames out of 3 latent frames
@@ -106,15 +107,25 @@ def test_cogvideox_ct_pipeline_reference_call_surface(hip):
     uni = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, sample_method="uniform",
                             generator=torch.Generator().manual_seed(3), **kw)
     assert uni.shape == (1, 16, 3, 64, 96)
+    longer = pipe(prompt=["x"], image=image / 2 + 0.5, negative_prompt=["y"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+                  **dict(kw, num_frames=33)).frames
+    assert longer.shape == (1, 9, 8, 8, 12) and torch.isfinite(longer.float()).all()
     with pytest.raises(ValueError):
-        pipe(prompt=["x"], image=image / 2 + 0.5, negative_prompt=["y"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
-             **dict(kw, num_frames=33))
+        pipe(prompt=["x"], image=(image / 2 + 0.5)[..., :80], negative_prompt=["y"], output_type="latent", ref_videos=ref_videos, metadata=metadata,
+             **dict(kw, width=80))
     with pytest.raises(ValueError):
         cvx.eval_pipeline(pipe, image, ["x"], ["y"], torch.bfloat16, ref_videos, metadata, sample_method="bogus", **kw)
     # the shipped eval_pipeline_call_kwargs (MotionRAG_open.yml:189-194): scheduler 'dpm', sample_method null, guidance 3 -- every decoded frame comes back
+    # the motion-injected pipelines are BUILT with the DPM scheduler (module.py:44, 183, 255); the YAML's `scheduler` entry is validated and dropped for them
     pipe.vae = StubVAE(8)
+    ddim = pipe.scheduler
     shipped = dict(num_inference_steps=3, num_frames=9, guidance_scale=3, sample_method=None, scheduler="dpm", height=64, width=96)
-    dpm = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **shipped)
+    cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **shipped)
+    assert pipe.scheduler is ddim                                                                  # not swapped behind the caller's back
+    pipe = cvx.CogVideoXImageToVideoCTPipeline(tokenizer=None, text_encoder=StubText(), vae=StubVAE(8), transformer=dit, condition_transformer=cama)
+    assert isinstance(pipe.scheduler, cvx.CogVideoXDPMScheduler)                                   # the constructor's default is the reference's choice
+    dpm = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3),
+                            **dict(shipped, scheduler="ddim"))
     assert isinstance(pipe.scheduler, cvx.CogVideoXDPMScheduler) and dpm.shape == (1, 9, 3, 64, 96) and torch.isfinite(dpm.float()).all()
     dpm2 = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, ref_videos, metadata, generator=torch.Generator().manual_seed(3), **shipped)
     assert torch.equal(dpm, dpm2)                                                                  # the sampler's noise comes from the generator
@@ -220,6 +231,15 @@ def test_svd_ct_pipeline_matches_oracle_loop(hip):
     close(got, lat, rel_l2=4e-2, atol_frac=0.25)          # two chained CFG steps of a bf16 UNet against fp32: 4 % Frobenius, elements within 5 % + a quarter of the mean magnitude
     vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, ref_videos=ref_videos, metadata=None, generator=torch.Generator().manual_seed(9), **kw)
     assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
+    # the uint8 hop of svd/module.py:181 (tensor2PIL -> denormalize -> uint8) + pipeline.py:154-155 (pil_to_tensor / 127.5 - 1): eval_pipeline's clip is
+    # the clip of the pipeline fed the reference's own quantised image, NOT of the float image it was handed
+    pm1 = img255 / 127.5 - 1.0
+    u8 = (torch.clip((pm1 + 1.0) / 2.0, 0.0, 1.0) * 255).to(torch.uint8)            # src/utils/pipeline.py:178-184, verbatim arithmetic on the host
+    assert (u8.float() != img255).any()                                                # the hop is not the identity on this image
+    want = pipe(image=u8, ref_videos=ref_videos, metadata=None, output_type="pt", generator=torch.Generator().manual_seed(9), **kw).frames[:, :16] * 2 - 1
+    assert torch.equal(vid, want)
+    unq = pipe(image=img255, ref_videos=ref_videos, metadata=None, output_type="pt", generator=torch.Generator().manual_seed(9), **kw).frames[:, :16] * 2 - 1
+    assert not torch.equal(vid, unq)
 
 
 def test_retrieval_consumer_contract_and_fan_out(hip):
@@ -383,9 +403,14 @@ def test_cogvideox_baseline_pipeline_without_motion_injection(hip):
     kw = dict(num_frames=9, num_inference_steps=2, guidance_scale=6.0, height=64, width=96)
     vid = cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, None, None, generator=torch.Generator().manual_seed(3), **kw)
     assert vid.shape == (1, 9, 3, 64, 96) and torch.isfinite(vid.float()).all()
+    # the YAML's `scheduler` entry selects the BASELINE pipe's scheduler (module.py:28-35); absent = 'ddim'
+    cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, None, None, generator=torch.Generator().manual_seed(3), scheduler="dpm", **kw)
+    assert isinstance(pipe.scheduler, cvx.CogVideoXDPMScheduler)
+    cvx.eval_pipeline(pipe, image, ["a dog runs"], ["blurry"], torch.bfloat16, None, None, generator=torch.Generator().manual_seed(3), **kw)
+    assert isinstance(pipe.scheduler, cvx.CogVideoXDDIMScheduler)
     lat = pipe(prompt=["a dog runs"], image=image / 2 + 0.5, negative_prompt=["blurry"], output_type="latent", generator=torch.Generator().manual_seed(3), **kw).frames
     # by hand with the oracle: same noise, embeddings, image latents; ip_hidden = None
-    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+    noise = torch.randn(1, 3, 8, 8, 12, generator=torch.Generator().manual_seed(3), dtype=torch.bfloat16)
     te = StubText()
     text = torch.cat([te(["blurry"]), te(["a dog runs"])]).float().cpu()
     il = pipe.encode_image_latents(image / 2 + 0.5, 3).to(torch.bfloat16).float().cpu()
@@ -467,3 +492,6 @@ def test_svd_baseline_pipeline_without_motion_injection(hip):
     close(got, lat, rel_l2=4e-2, atol_frac=0.35)          # as the CT test, two chained bf16 CFG steps; one element of 4 096 reaches 0.32 of the mean magnitude with these weights
     vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, generator=torch.Generator().manual_seed(9), **kw)
     assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
+    u8 = (torch.clip((img255 / 127.5 - 1.0 + 1.0) / 2.0, 0.0, 1.0) * 255).to(torch.uint8)   # the reference's tensor2PIL quantisation (utils/pipeline.py:178-184)
+    want = pipe(image=u8, output_type="pt", generator=torch.Generator().manual_seed(9), **kw).frames[:, :16] * 2 - 1
+    assert torch.equal(vid, want)

@@ -94,10 +94,17 @@ typedef struct mrag_gemm_args {
   int32_t tuning;     /* developer knobs (tools/microbench.py), 0 = shipped: MRAG_GEMM_TUNE_* bits, bits 4-7 tile choice
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
   int32_t geglu_act;  /* MRAG_EPI_GEGLU: 0 = v * gelu_erf(g) (diffusers / lvdm GEGLU), 1 = v * gelu_tanh(g) (T5 v1.1 "gated-gelu": gelu_new) */
+  void* workspace;         /* optional scratch, 16-byte aligned, private to the call until it completes on `stream`; NULL = none        */
+  int64_t workspace_bytes; /* >= mrag_gemm_workspace_bytes(M, N, K) enables the stream-K tail: the K-tiles of the partial last round of
+                              256x256 tiles (e.g. 132 of 1 668 tiles on 256 CUs for the DiT's to_out / FF2) are dealt evenly over the CUs
+                              and the partial sums meet in the workspace, summed in K order by the last arriver (bit-reproducible run to
+                              run; differs from the plain launch by fp32 summation order only)                                         */
 } mrag_gemm_args;
-enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4 };
+enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_NO_STREAMK = 8 };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
+/* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */
+int64_t mrag_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* ------------------------------------------------------------------------ */
 /* Attention, head_dim 64, bf16, flash-style (no S x S matrix in HBM).       */
@@ -149,7 +156,9 @@ enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pa
        MRAG_ATTN_TUNE_QB4W4 = 32,    /* the same in 4-wave workgroups, two per CU                  */
        MRAG_ATTN_TUNE_SUBS2 = 64,    /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
        MRAG_ATTN_TUNE_W4PF = 128,    /* attn16: 4-wave workgroups x 3 per CU, fragment prefetch    */
-       MRAG_ATTN_TUNE_W8PF = 256 };  /* attn16: 32 rows per wave, 8-wave workgroups, two per CU    */
+       MRAG_ATTN_TUNE_W8PF = 256,    /* attn16: 32 rows per wave, 8-wave workgroups, two per CU    */
+       MRAG_ATTN_TUNE_M32 = 512,     /* attn32: the attn16 algorithm on 32x32x16, 64 rows per wave */
+       MRAG_ATTN_TUNE_M32QB1 = 1024 };/* attn32 with 32 rows per wave, three workgroups per CU      */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 

@@ -57,9 +57,15 @@ struct GemmP {
   // implicit-GEMM convolution (CONV != 0): A is the channels-last activation, rows are gathered per K-tile
   int cv_H, cv_W, cv_Hi, cv_Wi, cv_Ho, cv_Wo, cv_stride, cv_up, cv_ctiles, cv_T, cv_pad;   // cv_pad: zero rows / columns in FRONT of the image (1, or 0 for the bottom/right-only padding)
   long long cv_C, cv_HW;
+  // stream-K tail (SK instantiation): logical tiles [0, sk_main) run one per workgroup; the sk_rem tiles behind them are cut into sk_units equal
+  // runs of K-tiles, one per workgroup; partial accumulators meet in sk_part, the last arriver of a tile (sk_ticket) sums them in K order
+  float* sk_part; unsigned* sk_ticket;
+  int sk_main, sk_rem, sk_units, sk_maxparts;
   int cv_tf;          // CONV == 1 with three temporal taps (causal 3x3x3): output frames per sample (input holds cv_tf + 2 frames per sample); 0 = 2-D
   long long cv_fs;    // elements between consecutive input frames
 };
+
+constexpr int SK_FLAG_OFF = 8 * 128 * 144;   // one LDS word behind the staged epilogue's region (stream-K: "this workgroup finishes the tile")
 
 // zero source for the taps that fall outside the image / clip (never written)
 __device__ __attribute__((aligned(128))) bf16_t g_zero_row[64];
@@ -87,15 +93,16 @@ __device__ __forceinline__ float epi_act(float v) {
   else return v;
 }
 
-template <int WM, int WN, int TM, int TN, int EPI, int CONV = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
+// One output tile (SK: one run of K-tiles [kt0, kt0 + nk) of it).  `wg` = the tile's index in the logical order.
+template <int WM, int WN, int TM, int TN, int EPI, int CONV, bool SK>
+__device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const int kt0, const int nk, const int sk_tile, const int sk_unit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 64;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int PIECES = (BM + BN) / 8;   // 1 KiB LDS-DMA pieces per stage (8 rows x 128 B)
   constexpr int PPW = PIECES / NW;        // pieces per wave
   static_assert(PIECES % NW == 0, "piece split");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef MRAG_GEMM_STAMPS
@@ -104,11 +111,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 #endif
   const int wm = wave / WN, wn = wave % WN;
 
-  const int nwg = p.tiles_m * p.tiles_n;
   // logical tile order: groups of GROUP_M m-tiles walked n-major, so the ~32 workgroups resident on one XCD (a contiguous
   // run of the logical order after the XCD remap) form a GROUP_M x 8 block that shares GROUP_M A-panels and 8 W-panels
   // per K-step through that XCD's L2 (instead of 1 A-panel and 32 W-panels)
-  const int wg = xcd_remap(blockIdx.x, nwg);
   const int gw = p.group_m * p.tiles_n;
   const int first_m = (wg / gw) * p.group_m;
   const int gsz = min(p.tiles_m - first_m, p.group_m);
@@ -141,12 +146,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
         gsrc[i] = p.A + row * p.cv_C + chunk * 8;
         cv_y[i] = (int)((row / p.cv_HW) % p.cv_T);
       } else {
-        gsrc[i] = p.A + row * p.lda + chunk * 8;
+        gsrc[i] = p.A + row * p.lda + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
       }
     } else {
       long long row = bn0 + (r - BM);
       row = row < p.N ? row : p.N - 1;
-      gsrc[i] = p.W + row * p.ldw + chunk * 8;
+      gsrc[i] = p.W + row * p.ldw + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
     }
   }
 
@@ -160,8 +165,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
   const int a_off = (wm * TM * 16 + frag_row) * 128;
   const int w_off = BM * 128 + (wn * TN * 16 + frag_row) * 128;
-
-  const int nk = (int)(p.K / BK);
 
   // DMA source of piece i for K-tile kt.  Plain GEMM: the row pointer advanced by kt * 64.  Convolutions: K-tile kt is channel
   // block (kt % ctiles) of tap (kt / ctiles); the lane's row is the tap-shifted pixel (or frame), or the zero row outside.
@@ -354,6 +357,58 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  if constexpr (SK) {
+    if (nk != (int)(p.K / BK)) {   // a partial run of this tile's K-tiles (workgroup-uniform)
+      // Contributors of tail tile T are the units whose iteration range [b(u), b(u + 1)), b(u) = u I / U, meets [T nk_full, (T + 1) nk_full): consecutive
+      // units, numbered in K order.  Every contributor parks its fp32 accumulators in its own slot and takes a ticket; the LAST arriver sums the
+      // slots in K order -- a fixed order, so the result does not depend on who arrives last (bit-reproducible run to run) -- and runs the epilogue.
+      const int nkf = (int)(p.K / BK), I = p.sk_rem * nkf, U = p.sk_units;
+      auto owner = [&](int it) {   // the unit whose range holds iteration `it`
+        int u = (int)(((long long)it * U) / I);
+        while ((int)(((long long)(u + 1) * I) / U) <= it) ++u;
+        while ((int)(((long long)u * I) / U) > it) --u;
+        return u;
+      };
+      const int u_first = owner(sk_tile * nkf), u_last = owner(sk_tile * nkf + nkf - 1);
+      const int part = sk_unit - u_first, nparts = u_last - u_first + 1;
+      float* slot0 = p.sk_part + (size_t)sk_tile * p.sk_maxparts * (BM * BN);
+      float* mine = slot0 + (size_t)part * (BM * BN) + ((size_t)wave * (TM * TN) * 64 + lane) * 4;   // lane-linear: every store / load instruction moves 1 KiB
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *(f32x4*)(mine + (size_t)(i * TN + j) * 256) = acc[i][j];
+      unsigned* flag = (unsigned*)(smem + SK_FLAG_OFF);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                   // every wave's slot stores have left
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must not be overtaken by the ticket (guide, compiler hazard of the release)
+        const unsigned old = __hip_atomic_fetch_add(p.sk_ticket + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)(nparts - 1);
+        if (last) {
+          __hip_atomic_store(p.sk_ticket + sk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                                            // this CU's L1 forgets the other contributors' lines
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*flag == 0u) return;
+      const float* src0 = slot0 + ((size_t)wave * (TM * TN) * 64 + lane) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = *(const f32x4*)(src0 + (size_t)(i * TN + j) * 256);
+      for (int q = 1; q < nparts; ++q) {
+        const float* sq = src0 + (size_t)q * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] += *(const f32x4*)(sq + (size_t)(i * TN + j) * 256);
       }
     }
   }
@@ -697,6 +752,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   }
 }
 
+template <int WM, int WN, int TM, int TN, int EPI, int CONV = 0, bool SK = false>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
+  if constexpr (!SK) {
+    gemm_tile<WM, WN, TM, TN, EPI, CONV, false>(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), 0, (int)(p.K / 64), 0, 0);
+  } else {
+    // one workgroup per whole tile for the full rounds, then sk_units workgroups that share the K-tiles of the last, partial round evenly
+    const int nkf = (int)(p.K / 64);
+    int it, it_end, unit = 0;
+    const bool tail = (int)blockIdx.x >= p.sk_main;
+    if (!tail) {
+      it = 0; it_end = nkf;
+    } else {
+      unit = blockIdx.x - p.sk_main;
+      const int I = p.sk_rem * nkf;
+      it = (int)(((long long)unit * I) / p.sk_units);
+      it_end = (int)(((long long)(unit + 1) * I) / p.sk_units);
+    }
+    bool again = false;
+    while (it < it_end) {
+      if (again) __syncthreads();                // the previous run's epilogue / exchange still reads LDS
+      const int T = tail ? it / nkf : 0;
+      const int kt0 = tail ? it - T * nkf : 0;
+      const int n = min(nkf - kt0, it_end - it);
+      gemm_tile<WM, WN, TM, TN, EPI, CONV, true>(p, tail ? p.sk_main + T : xcd_remap(blockIdx.x, p.sk_main), kt0, n, T, unit);
+      it += n;
+      again = true;
+    }
+  }
+}
+
 // UNet widths are multiples of 320: N = 320 / 640 / 960 wastes 38 / 17 / 6 % of a 256-wide tile grid, nothing of a 320-wide one
 inline bool wide_n_pays(long long N, int tuning = 0) {
   if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
@@ -710,20 +795,73 @@ inline bool narrow_n_pays(long long N) {
   return r != 0 && r <= 128;
 }
 
+// Stream-K for the partial last round of the 256x256 tile grid (one workgroup per CU, 256 CUs).  The DiT's to_out / FF2 GEMMs are 1 668 tiles =
+// 6.52 rounds: the seventh round runs 132 workgroups on 256 CUs for a whole tile's time.  Here the K-tiles of those `rem` tiles are dealt evenly to
+// `units` workgroups (all co-resident: <= 256), so the round ends after rem / units of a tile's time plus the partial-sum exchange.
+struct SkPlan {
+  bool use = false;
+  int n_main = 0, rem = 0, units = 0, maxparts = 0;
+  size_t bytes = 0;
+};
+constexpr int SK_CUS = 256, SK_TICKET_BYTES = 1024;
+inline SkPlan plan_streamk(long long M, long long N, long long K) {
+  SkPlan pl;
+  const long long tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  const int nk = (int)(K / 64);
+  if (tiles < SK_CUS || tiles > (1 << 24) || nk < 16 || nk > 4096) return pl;
+  const int rem = (int)(tiles % SK_CUS);
+  if (rem == 0 || rem > 208) return pl;           // a nearly full last round has nothing to win (the exchange costs ~15 us)
+  pl.rem = rem; pl.n_main = (int)(tiles - rem);
+  pl.units = rem * 4 < SK_CUS ? rem * 4 : SK_CUS;  // at most ~4 contributors per tile (+1 where a run straddles)
+  const long long I = (long long)rem * nk;
+  for (int t = 0, u = 0; t < rem; ++t) {           // contributors per tile: units meeting [t nk, (t + 1) nk)
+    while ((long long)(u + 1) * I / pl.units <= (long long)t * nk) ++u;
+    int v = u;
+    while ((long long)(v + 1) * I / pl.units < (long long)(t + 1) * nk) ++v;
+    pl.maxparts = pl.maxparts > v - u + 1 ? pl.maxparts : v - u + 1;
+  }
+  pl.bytes = SK_TICKET_BYTES + (size_t)rem * pl.maxparts * 256 * 256 * sizeof(float);
+  pl.use = true;
+  return pl;
+}
+
 template <int WM, int WN, int TM, int TN, int CONV = 0>
-int launch_cfg(hipStream_t s, const GemmP& p0, int epi) {
+int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullptr) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   GemmP p = p0;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(WM * WN * 64);
+  const dim3 grid(sk ? sk->n_main + sk->units : p.tiles_m * p.tiles_n), block(WM * WN * 64);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
   if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || ((epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
-  const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
+  const size_t lds = ((WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages) + (sk ? 16 : 0);
+  if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
+    if (sk) {   // the DiT's four linears (and the plain GEMM)
+#define MRAG_GEMM_SK_CASE(E)                                                                           \
+  case E: {                                                                                            \
+    auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, 0, true>;                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
+    break;                                                                                             \
+  }
+      switch (epi) {
+        MRAG_GEMM_SK_CASE(MRAG_EPI_NONE)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_GELU_TANH)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_RESID)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_GATE_RESID)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_QKNORM_ROPE)
+        default: return MRAG_ENOTSUP;
+      }
+#undef MRAG_GEMM_SK_CASE
+      MRAG_LAUNCH_CHECK();
+      return MRAG_OK;
+    }
+  }
 #define MRAG_GEMM_CASE(E)                                                                              \
   case E: {                                                                                            \
     auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, CONV>;                                              \
@@ -798,8 +936,29 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
     if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, epi);                  // 128x128, 4 waves, 2 workgroups per CU
   }
   if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, epi);   // 256x320 tile
+  if (t256 >= 192 && a->workspace && !(a->tuning & MRAG_GEMM_TUNE_NO_STREAMK) &&
+      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE)) {
+    const SkPlan pl = plan_streamk(a->M, a->N, a->K);
+    if (pl.use && a->workspace_bytes >= (int64_t)pl.bytes) {
+      if ((uintptr_t)a->workspace & 15) return MRAG_EINVAL;
+      p.sk_ticket = (unsigned*)a->workspace;
+      p.sk_part = (float*)((char*)a->workspace + SK_TICKET_BYTES);
+      p.sk_main = pl.n_main; p.sk_rem = pl.rem; p.sk_units = pl.units; p.sk_maxparts = pl.maxparts;
+      const hipError_t e = hipMemsetAsync(a->workspace, 0, SK_TICKET_BYTES, s);   // the tickets start at zero whatever an earlier (aborted) launch left
+      if (e != hipSuccess) return (int)e;
+      const int rc = launch_cfg<2, 4, 8, 4>(s, p, epi, &pl);
+      if (rc != MRAG_ENOTSUP) return rc;
+    }
+  }
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4>(s, p, epi);
   return launch_cfg<2, 2, 4, 4>(s, p, epi);
+}
+
+extern "C" int64_t mrag_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return 0;
+  if (wide_n_pays(N)) return 0;
+  const SkPlan pl = plan_streamk(M, N, K);
+  return pl.use ? (int64_t)pl.bytes : 0;
 }
 
 extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {

@@ -23,6 +23,7 @@ LOG2E = 1.4426950408889634
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
 ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4, ATTN_TUNE_SUBS2, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 2, 4, 8, 16, 32, 64, 128, 256
+ATTN_TUNE_M32, ATTN_TUNE_M32QB1 = 512, 1024
 
 
 class HipOnly(RuntimeError):
@@ -83,8 +84,24 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if epilogue == EPI_GATE_RESID:
         a.gate0, a.gate1 = _p(_dev(gate0, name="gate0")), _p(_dev(gate1, name="gate1"))
         a.rows_per_batch, a.split, a.gate_stride = rows_per_batch, split, gate_stride
+    _gemm_workspace(a, x.device)
     check(_lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a)), "mrag_gemm_bf16")
     return out
+
+
+def _gemm_workspace(a: "GemmArgs", device: torch.device) -> None:
+    """hand mrag_gemm_bf16 the scratch that turns a partial last round of 256x256 tiles into a stream-K tail (include/mrag_hip.h); the same grow-only
+    per-(device, stream) buffers as the attention's: launches on one stream are ordered"""
+    if M_SK_MIN_ROWS > a.M or TUNING["gemm"] & GEMM_TUNE_NO_STREAMK:
+        return
+    need = _lib.lib().mrag_gemm_workspace_bytes(a.M, a.N, a.K)
+    if need > 0:
+        ws = _attn_workspace(device, need, "gemm")
+        a.workspace, a.workspace_bytes = _p(ws), ws.numel()
+
+
+M_SK_MIN_ROWS = 4096          # below this no 256x256 grid reaches a second round: skip the query
+GEMM_TUNE_NO_STREAMK = 8
 
 
 def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,
@@ -316,6 +333,7 @@ def qkv_linear_qknorm_rope(x: torch.Tensor, weight: torch.Tensor, bias: Optional
             raise ValueError("cos/sin must be contiguous [S - text_len, 64] fp32")
         a.rope_cos, a.rope_sin = _p(cos), _p(sin)
     a.tuning = TUNING["gemm"]
+    _gemm_workspace(a, x.device)
     rc = _lib.MRAG_ENOTSUP if TUNING["no_qkv_fuse"] else _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))
     if rc == _lib.MRAG_ENOTSUP:                                   # small problem / unaligned output: plain GEMM, then the norm + RoPE pass
         if first != 0 or N != 3 * D:

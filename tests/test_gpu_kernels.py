@@ -80,6 +80,91 @@ def test_gemm_epilogues(hip, epi, M, N, K):
     close(got, want, scale=acc.abs().mean().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(4352, 4096, 1024), (5000, 3840, 3072), (8300, 3072, 2048)])
+def test_gemm_stream_k_tail(hip, M, N, K):
+    """stream-K for the partial last round of 256x256 tiles (272 tiles = 1 round + 16: 64 units of a quarter tile; 300 tiles = 1 + 44: 176 uneven
+    units; 396 = 1 + 140: 256 units of ~half a tile, the DiT's regime): every epilogue the DiT runs equals the fp32 reference and the plain launch
+    (fp32 summation order is the only difference: a bf16 ulp on a few elements), results are bit-identical run to run whichever contributor
+    finishes a tile, the tickets are left at zero, and the C-ABI falls back to the plain launch without (enough) workspace"""
+    import ctypes
+    from motionrag_amd import ops, _lib
+    L = _lib.lib()
+    need = L.mrag_gemm_workspace_bytes(M, N, K)
+    assert need > 0 and L.mrag_gemm_workspace_bytes(256 * 16, 256 * 16, K) == 0          # a grid of whole rounds has no tail
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV), bf(torch.randn(N, generator=g)).to(DEV)
+    r = bf(torch.randn(M, N, generator=g)).to(DEV)
+    rpb = M // 2
+    g0, g1 = (bf(torch.randn(2, N, generator=g)).to(DEV) for _ in range(2))
+    acc = x.float() @ w.float().t() + b.float()
+    pos = torch.arange(M, device=DEV) % rpb
+    gate = torch.where((pos < 37)[:, None], g0[torch.arange(M, device=DEV) // rpb].float(), g1[torch.arange(M, device=DEV) // rpb].float()) if M % 2 == 0 else None
+    cases = {"none": (dict(), acc), "gelu": (dict(epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(acc, approximate="tanh")),
+             "resid": (dict(epilogue=ops.EPI_RESID, resid=r), r.float() + acc.to(torch.bfloat16).float())}
+    if gate is not None:
+        cases["gate"] = (dict(epilogue=ops.EPI_GATE_RESID, resid=r, gate0=g0, gate1=g1, rows_per_batch=rpb, split=37, gate_stride=N),
+                         r.float() + (gate * acc).to(torch.bfloat16).float())
+    for name, (kw, want) in cases.items():
+        got = ops.linear(x, w, b, **kw)
+        close(got, want, scale=want.abs().mean().item())
+        for _ in range(4):
+            assert torch.equal(ops.linear(x, w, b, **kw), got), f"{name}: stream-K result differs run to run"
+        ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+        try:
+            plain = ops.linear(x, w, b, **kw)
+        finally:
+            ops.TUNING["gemm"] = 0
+        d = (got.float() - plain.float()).abs()
+        assert (d > 0).float().mean().item() < 2e-2 and (d <= plain.float().abs() * 2.0 ** -7 + 1e-3 * want.abs().mean().item()).all(), name
+        assert not torch.equal(got, plain) or name != "none"          # the tail really ran as stream-K (some element rounds differently)
+    ws = ops._attn_workspace(x.device, need, "gemm")
+    assert int(ws[:1024].to(torch.int32).abs().sum().item()) == 0      # tickets back at zero
+    # raw C-ABI: no / short workspace -> the plain launch; a misaligned one is refused
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+    try:
+        plain = ops.linear(x, w, b)
+    finally:
+        ops.TUNING["gemm"] = 0
+    sk = ops.linear(x, w, b)
+    buf = torch.zeros(need + 64, dtype=torch.uint8, device=DEV)
+    for ptr, nbytes, expect in ((None, 0, plain), (buf.data_ptr(), need - 1, plain), (buf.data_ptr(), need, sk), (buf.data_ptr() + 8, need, None)):
+        a = _lib.GemmArgs()
+        a.A, a.W, a.bias, a.C = x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr()
+        a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
+        a.workspace, a.workspace_bytes = ptr, nbytes
+        rc = L.mrag_gemm_bf16(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(a))
+        if expect is None:
+            assert rc == _lib.MRAG_EINVAL
+        else:
+            assert rc == _lib.MRAG_OK and torch.equal(out, expect)
+
+
+def test_qkv_gemm_stream_k_tail_matches_plain(hip):
+    """the fused QKV + qk-norm + RoPE epilogue behind a stream-K tail (the DiT's QKV GEMM: 5 004 tiles = 19 rounds + 140)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, S, H, K, text_len = 2, 3900, 12, 1024, 226                     # M = 7 800 (31 m-tiles) x N = 2 304 (9 n-tiles) = 279 tiles = 1 round + 23
+    D = H * 64
+    x = bf(torch.randn(B, S, K, generator=g)).to(DEV)
+    w = bf(torch.randn(3 * D, K, generator=g) * K ** -0.5).to(DEV)
+    b = bf(torch.randn(3 * D, generator=g) * 0.1).to(DEV)
+    qg, qb, kg, kb = (bf(1.0 + 0.2 * torch.randn(64, generator=g)).to(DEV) if i % 2 == 0 else bf(0.1 * torch.randn(64, generator=g)).to(DEV) for i in range(4))
+    ang = torch.rand(S - text_len, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
+    from motionrag_amd import _lib
+    assert _lib.lib().mrag_gemm_workspace_bytes(B * S, 3 * D, K) > 0
+    got = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+    assert torch.equal(got, ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18))
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+    try:
+        plain = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+    finally:
+        ops.TUNING["gemm"] = 0
+    d = (got.float() - plain.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-2 and (d <= plain.float().abs() * 2.0 ** -6 + 2e-3).all() and not torch.equal(got, plain)
+
+
 def test_gemm_rejects_bad_arguments(hip):
     from motionrag_amd import ops, _lib
     import ctypes
@@ -198,6 +283,60 @@ def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
         ops.TUNING["attn"] = 0
     close(old, sdpa_ref(q_r, k, v), scale=0.3, rtol=3e-2, atol_frac=0.12)
     close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)           # the two kernel families agree to a bf16 ulp or two
+
+
+@pytest.mark.parametrize("variant", ["M32", "M32QB1"])
+def test_attention32_family_matches_reference_and_attn16(hip, variant):
+    """attn32.hip: the attn16 algorithm (max as the MFMA's C operand, lazy re-centre, P from accumulators to B operand) on 32x32x16 -- a developer
+    A/B variant.  Same forced branches as the attn16 test (finite blow-up, inf, a spike inside the slid-back ragged last
+    stage, low first tile), plus ragged query tiles, a fused residual, kv batch repeat, and the key-split tail of the 256-row variant"""
+    from motionrag_amd import ops
+    tune = getattr(ops, "ATTN_TUNE_" + variant)
+    g = torch.Generator().manual_seed(18)
+    B, H, Sq, Skv = 1, 2, 300, 1000
+    q, k, v = (torch.randn(B, S, H, 64, generator=g) for S in (Sq, Skv, Skv))
+    k[:, :64] -= 3.0 * q[:, :1].mean(dim=1, keepdim=True)
+    unit = lambda r: q[:, r] / q[:, r].norm(dim=-1, keepdim=True)
+    k[:, 300] = 20.0 * unit(7)
+    k[:, 700] = 104.0 * unit(200)
+    k[:, 701] = 21.5 * unit(7)
+    k[:, 990] = 45.0 * unit(290)
+    k[:, 40] = 30.0 * unit(100)          # a spike in the SECOND 32-key block of the very first stage (re-centre right after the first block fixed m)
+    q, k, v = bf(q), bf(k), bf(v)
+    q_r = bf(q * (0.125 * 1.4426950408889634)) / (0.125 * 1.4426950408889634)
+    base = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    ops.TUNING["attn"] = tune
+    try:
+        got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+        close(got, sdpa_ref(q_r, k, v), scale=0.3, rtol=3e-2, atol_frac=0.15)        # one more forced spike than the attn16 test: 0.0395 on one element of 38 400 (bf16 Q', bf16 P)
+        close(got, base.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)
+        # plain random shapes: ragged query tiles / key stages, strided fused-QKV views, fused residual with a repeated K / V batch
+        for (b, h, sq, skv) in ((2, 3, 300, 300), (1, 2, 1000, 777), (1, 1, 257, 258)):
+            gq = torch.Generator().manual_seed(b * 100 + sq)
+            qq, kk, vv = (bf(torch.randn(b, S, h, 64, generator=gq)) for S in (sq, skv, skv))
+            close(ops.attention(qq.to(DEV), kk.to(DEV), vv.to(DEV)), sdpa_ref(qq, kk, vv), scale=0.3)
+        qkv = bf(torch.randn(4, 333, 3, 3, 64, generator=g)).to(DEV)
+        kv = bf(torch.randn(2, 320, 2, 3, 64, generator=g))
+        resid = bf(torch.randn(4, 333, 192, generator=g))
+        out = ops.attention(qkv[:, :, 0], kv[:, :, 0].to(DEV), kv[:, :, 1].to(DEV), resid=resid.to(DEV), kv_batch_div=2, out_scale=0.75)
+        close(out, resid.float() + 0.75 * sdpa_ref(qkv[:, :, 0].cpu(), kv[:, :, 0], kv[:, :, 1], kv_div=2), scale=1.0)
+        # key-split tail (256-row variant): 16 x 256 + 112 rows; the tail rows equal the reference and the unsplit launch to a bf16 ulp or two
+        B2, H2, Sq2, Skv2 = 1, 16, 16 * 256 + 112, 4200
+        q2 = bf(torch.randn(B2, Sq2, H2, 64, generator=g))
+        k2, v2 = (bf(torch.randn(B2, Skv2, H2, 64, generator=g)) for _ in range(2))
+        k2[:, 3000] = bf(9.0 * q2[:, Sq2 - 5] / q2[:, Sq2 - 5].norm(dim=-1, keepdim=True))
+        rows = torch.cat([torch.arange(Sq2 - 112, Sq2), torch.randint(0, Sq2 - 112, (80,), generator=g)])
+        want = sdpa_ref(q2[:, rows], k2, v2)
+        outs = {}
+        for nosplit in (False, True):
+            ops.TUNING["attn_no_split"] = nosplit
+            outs[nosplit] = ops.attention(q2.to(DEV), k2.to(DEV), v2.to(DEV))
+            close(outs[nosplit][:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
+        assert torch.equal(outs[False][:, :Sq2 - 112], outs[True][:, :Sq2 - 112])
+        if variant == "M32":
+            assert not torch.equal(outs[False][:, Sq2 - 112:], outs[True][:, Sq2 - 112:])         # the tail really took the key-split path
+    finally:
+        ops.TUNING["attn"], ops.TUNING["attn_no_split"] = 0, False
 
 
 def test_attention_large_sequence_properties(hip):

@@ -95,12 +95,13 @@ typedef struct mrag_gemm_args {
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
   int32_t geglu_act;  /* MRAG_EPI_GEGLU: 0 = v * gelu_erf(g) (diffusers / lvdm GEGLU), 1 = v * gelu_tanh(g) (T5 v1.1 "gated-gelu": gelu_new) */
   void* workspace;         /* optional scratch, 16-byte aligned, private to the call until it completes on `stream`; NULL = none        */
-  int64_t workspace_bytes; /* >= mrag_gemm_workspace_bytes(M, N, K) enables the stream-K tail: the K-tiles of the partial last round of
-                              256x256 tiles (e.g. 132 of 1 668 tiles on 256 CUs for the DiT's to_out / FF2) are dealt evenly over the CUs
-                              and the partial sums meet in the workspace, summed in K order by the last arriver (bit-reproducible run to
-                              run; differs from the plain launch by fp32 summation order only)                                         */
+  int64_t workspace_bytes; /* with tuning & MRAG_GEMM_TUNE_STREAMK and >= mrag_gemm_workspace_bytes(M, N, K) bytes: the partial last round
+                              of 256x256 tiles (e.g. 132 of 1 668 tiles on 256 CUs for the DiT's to_out / FF2) runs as a stream-K tail
+                              launch -- its K-tiles dealt evenly over the CUs, partial sums exchanged through the workspace and summed in
+                              K order by the last arriver (bit-reproducible run to run; differs from the plain launch by fp32 summation
+                              order only).  OPT-IN: measured slower than the partial round on MI355X               */
 } mrag_gemm_args;
-enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_NO_STREAMK = 8 };
+enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8 };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */

@@ -755,30 +755,21 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
 template <int WM, int WN, int TM, int TN, int EPI, int CONV = 0, bool SK = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmP p) {
   if constexpr (!SK) {
-    gemm_tile<WM, WN, TM, TN, EPI, CONV, false>(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), 0, (int)(p.K / 64), 0, 0);
+    // the grid is the logical tile range [0, gridDim.x): every tile, or the whole rounds in front of a stream-K tail launch
+    gemm_tile<WM, WN, TM, TN, EPI, CONV, false>(p, xcd_remap(blockIdx.x, gridDim.x), 0, (int)(p.K / 64), 0, 0);
   } else {
-    // one workgroup per whole tile for the full rounds, then sk_units workgroups that share the K-tiles of the last, partial round evenly
-    const int nkf = (int)(p.K / 64);
-    int it, it_end, unit = 0;
-    const bool tail = (int)blockIdx.x >= p.sk_main;
-    if (!tail) {
-      it = 0; it_end = nkf;
-    } else {
-      unit = blockIdx.x - p.sk_main;
-      const int I = p.sk_rem * nkf;
-      it = (int)(((long long)unit * I) / p.sk_units);
-      it_end = (int)(((long long)(unit + 1) * I) / p.sk_units);
-    }
-    bool again = false;
-    while (it < it_end) {
-      if (again) __syncthreads();                // the previous run's epilogue / exchange still reads LDS
-      const int T = tail ? it / nkf : 0;
-      const int kt0 = tail ? it - T * nkf : 0;
-      const int n = min(nkf - kt0, it_end - it);
-      gemm_tile<WM, WN, TM, TN, EPI, CONV, true>(p, tail ? p.sk_main + T : xcd_remap(blockIdx.x, p.sk_main), kt0, n, T, unit);
-      it += n;
-      again = true;
-    }
+    // the tail launch: sk_units runs of K-tiles share the sk_rem tiles behind logical tile sk_main evenly.  A run touches at most two tiles, and
+    // each of its (at most) two pieces is a workgroup of its own -- blockIdx = 2 unit + piece -- so this wrapper is straight-line code: a loop
+    // over the pieces made hipcc keep the whole argument struct in SGPRs across it (106 SGPRs, 40-86 spilled VGPRs, reloads inside the K loop)
+    // Runs are dealt to XCDs in contiguous chunks, like the tiles of the main launch: consecutive runs work on neighbouring tiles (shared A / W
+    // panels) at nearly the same K offset, so an XCD's L2 serves the panels once instead of every CU streaming its own from HBM
+    const int nkf = (int)(p.K / 64), I = p.sk_rem * nkf, unit = xcd_remap(blockIdx.x >> 1, p.sk_units);
+    const int it0 = (int)(((long long)unit * I) / p.sk_units), it1 = (int)(((long long)(unit + 1) * I) / p.sk_units);
+    const int T0 = it0 / nkf, cut = min(it1, (T0 + 1) * nkf);          // the first piece ends at its tile's last K-tile
+    const int it = (blockIdx.x & 1) ? cut : it0, end = (blockIdx.x & 1) ? it1 : cut;
+    if (it >= end) return;
+    const int T = it / nkf;
+    gemm_tile<WM, WN, TM, TN, EPI, CONV, true>(p, p.sk_main + T, it - T * nkf, end - it, T, unit);
   }
 }
 
@@ -832,36 +823,16 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
-  const dim3 grid(sk ? sk->n_main + sk->units : p.tiles_m * p.tiles_n), block(WM * WN * 64);
+  const dim3 grid(sk ? sk->n_main : p.tiles_m * p.tiles_n), block(WM * WN * 64);   // with a stream-K plan: the whole rounds here, the tail as a second launch
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
   if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || ((epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
-  const size_t lds = ((WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages) + (sk ? 16 : 0);
-  if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
-    if (sk) {   // the DiT's four linears (and the plain GEMM)
-#define MRAG_GEMM_SK_CASE(E)                                                                           \
-  case E: {                                                                                            \
-    auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, 0, true>;                                           \
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return (int)e;                                                                \
-    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
-    break;                                                                                             \
-  }
-      switch (epi) {
-        MRAG_GEMM_SK_CASE(MRAG_EPI_NONE)
-        MRAG_GEMM_SK_CASE(MRAG_EPI_GELU_TANH)
-        MRAG_GEMM_SK_CASE(MRAG_EPI_RESID)
-        MRAG_GEMM_SK_CASE(MRAG_EPI_GATE_RESID)
-        MRAG_GEMM_SK_CASE(MRAG_EPI_QKNORM_ROPE)
-        default: return MRAG_ENOTSUP;
-      }
-#undef MRAG_GEMM_SK_CASE
-      MRAG_LAUNCH_CHECK();
-      return MRAG_OK;
-    }
-  }
+  const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
+  bool sk_ok = false;
+  if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) sk_ok = sk != nullptr;
+  if (sk && !sk_ok) return MRAG_ENOTSUP;
 #define MRAG_GEMM_CASE(E)                                                                              \
   case E: {                                                                                            \
     auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, CONV>;                                              \
@@ -892,6 +863,29 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
   }
 #undef MRAG_GEMM_CASE
   MRAG_LAUNCH_CHECK();
+  if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
+    if (sk) {   // the partial last round.  Its own launch: the main kernel keeps its register allocation, and whole rounds end together anyway
+      const dim3 tgrid(2 * sk->units);
+#define MRAG_GEMM_SK_CASE(E)                                                                           \
+  case E: {                                                                                            \
+    auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, E, 0, true>;                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 16)); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    MRAG_LAUNCH(kfn, tgrid, block, lds + 16, s, p);                                                    \
+    break;                                                                                             \
+  }
+      switch (epi) {
+        MRAG_GEMM_SK_CASE(MRAG_EPI_NONE)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_GELU_TANH)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_RESID)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_GATE_RESID)
+        MRAG_GEMM_SK_CASE(MRAG_EPI_QKNORM_ROPE)
+        default: return MRAG_EINVAL;   // mrag_gemm_bf16 plans a tail for these five only
+      }
+#undef MRAG_GEMM_SK_CASE
+      MRAG_LAUNCH_CHECK();
+    }
+  }
   return MRAG_OK;
 }
 
@@ -936,7 +930,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
     if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, epi);                  // 128x128, 4 waves, 2 workgroups per CU
   }
   if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, epi);   // 256x320 tile
-  if (t256 >= 192 && a->workspace && !(a->tuning & MRAG_GEMM_TUNE_NO_STREAMK) &&
+  if (t256 >= 192 && a->workspace && (a->tuning & MRAG_GEMM_TUNE_STREAMK) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE)) {
     const SkPlan pl = plan_streamk(a->M, a->N, a->K);
     if (pl.use && a->workspace_bytes >= (int64_t)pl.bytes) {

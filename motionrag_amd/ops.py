@@ -90,9 +90,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def _gemm_workspace(a: "GemmArgs", device: torch.device) -> None:
-    """hand mrag_gemm_bf16 the scratch that turns a partial last round of 256x256 tiles into a stream-K tail (include/mrag_hip.h); the same grow-only
+    """with TUNING["gemm"] & GEMM_TUNE_STREAMK: hand mrag_gemm_bf16 the scratch that turns a partial last round of 256x256 tiles into a stream-K tail (include/mrag_hip.h); the same grow-only
     per-(device, stream) buffers as the attention's: launches on one stream are ordered"""
-    if M_SK_MIN_ROWS > a.M or TUNING["gemm"] & GEMM_TUNE_NO_STREAMK:
+    if M_SK_MIN_ROWS > a.M or not TUNING["gemm"] & GEMM_TUNE_STREAMK:      # opt-in: measured slower than the partial last round (DESIGN.md section 7)
         return
     need = _lib.lib().mrag_gemm_workspace_bytes(a.M, a.N, a.K)
     if need > 0:
@@ -101,7 +101,7 @@ def _gemm_workspace(a: "GemmArgs", device: torch.device) -> None:
 
 
 M_SK_MIN_ROWS = 4096          # below this no 256x256 grid reaches a second round: skip the query
-GEMM_TUNE_NO_STREAMK = 8
+GEMM_TUNE_STREAMK = 8
 
 
 def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,

@@ -85,7 +85,8 @@ def test_gemm_stream_k_tail(hip, M, N, K):
     """stream-K for the partial last round of 256x256 tiles (272 tiles = 1 round + 16: 64 units of a quarter tile; 300 tiles = 1 + 44: 176 uneven
     units; 396 = 1 + 140: 256 units of ~half a tile, the DiT's regime): every epilogue the DiT runs equals the fp32 reference and the plain launch
     (fp32 summation order is the only difference: a bf16 ulp on a few elements), results are bit-identical run to run whichever contributor
-    finishes a tile, the tickets are left at zero, and the C-ABI falls back to the plain launch without (enough) workspace"""
+    finishes a tile, the tickets are left at zero, and the C-ABI falls back to the plain launch without (enough) workspace.  Stream-K is an OPT-IN
+    developer path (MRAG_GEMM_TUNE_STREAMK): built for VERDICT r2 item 2b, measured slower than the partial last round it replaces"""
     import ctypes
     from motionrag_amd import ops, _lib
     L = _lib.lib()
@@ -99,45 +100,48 @@ def test_gemm_stream_k_tail(hip, M, N, K):
     acc = x.float() @ w.float().t() + b.float()
     pos = torch.arange(M, device=DEV) % rpb
     gate = torch.where((pos < 37)[:, None], g0[torch.arange(M, device=DEV) // rpb].float(), g1[torch.arange(M, device=DEV) // rpb].float()) if M % 2 == 0 else None
-    cases = {"none": (dict(), acc), "gelu": (dict(epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(acc, approximate="tanh")),
-             "resid": (dict(epilogue=ops.EPI_RESID, resid=r), r.float() + acc.to(torch.bfloat16).float())}
+    # (keyword arguments, reference, magnitude of the bf16-rounded product in front of the residual add: ITS ulp bounds a rounding flip)
+    cases = {"none": (dict(), acc, acc.abs()), "gelu": (dict(epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(acc, approximate="tanh"), acc.abs()),
+             "resid": (dict(epilogue=ops.EPI_RESID, resid=r), r.float() + acc.to(torch.bfloat16).float(), acc.abs())}
     if gate is not None:
         cases["gate"] = (dict(epilogue=ops.EPI_GATE_RESID, resid=r, gate0=g0, gate1=g1, rows_per_batch=rpb, split=37, gate_stride=N),
-                         r.float() + (gate * acc).to(torch.bfloat16).float())
-    for name, (kw, want) in cases.items():
-        got = ops.linear(x, w, b, **kw)
-        close(got, want, scale=want.abs().mean().item())
-        for _ in range(4):
-            assert torch.equal(ops.linear(x, w, b, **kw), got), f"{name}: stream-K result differs run to run"
-        ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+                         r.float() + (gate * acc).to(torch.bfloat16).float(), (gate * acc).abs())
+    for name, (kw, want, mag) in cases.items():
+        plain = ops.linear(x, w, b, **kw)
+        ops.TUNING["gemm"] = ops.GEMM_TUNE_STREAMK          # opt-in developer path (measured slower than the partial last round: DESIGN.md section 7)
         try:
-            plain = ops.linear(x, w, b, **kw)
+            got = ops.linear(x, w, b, **kw)
+            close(got, want, scale=want.abs().mean().item())
+            for _ in range(4):
+                assert torch.equal(ops.linear(x, w, b, **kw), got), f"{name}: stream-K result differs run to run"
         finally:
             ops.TUNING["gemm"] = 0
         d = (got.float() - plain.float()).abs()
-        assert (d > 0).float().mean().item() < 2e-2 and (d <= plain.float().abs() * 2.0 ** -7 + 1e-3 * want.abs().mean().item()).all(), name
+        assert (d > 0).float().mean().item() < 2e-2 and (d <= (plain.float().abs() + mag) * 2.0 ** -7 + 1e-3 * want.abs().mean().item()).all(), name
         assert not torch.equal(got, plain) or name != "none"          # the tail really ran as stream-K (some element rounds differently)
     ws = ops._attn_workspace(x.device, need, "gemm")
     assert int(ws[:1024].to(torch.int32).abs().sum().item()) == 0      # tickets back at zero
     # raw C-ABI: no / short workspace -> the plain launch; a misaligned one is refused
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+    plain = ops.linear(x, w, b)
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_STREAMK
     try:
-        plain = ops.linear(x, w, b)
+        sk = ops.linear(x, w, b)
     finally:
         ops.TUNING["gemm"] = 0
-    sk = ops.linear(x, w, b)
     buf = torch.zeros(need + 64, dtype=torch.uint8, device=DEV)
     for ptr, nbytes, expect in ((None, 0, plain), (buf.data_ptr(), need - 1, plain), (buf.data_ptr(), need, sk), (buf.data_ptr() + 8, need, None)):
         a = _lib.GemmArgs()
         a.A, a.W, a.bias, a.C = x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr()
         a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
-        a.workspace, a.workspace_bytes = ptr, nbytes
+        a.workspace, a.workspace_bytes, a.tuning = ptr, nbytes, ops.GEMM_TUNE_STREAMK
         rc = L.mrag_gemm_bf16(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(a))
         if expect is None:
             assert rc == _lib.MRAG_EINVAL
         else:
             assert rc == _lib.MRAG_OK and torch.equal(out, expect)
+    a.workspace, a.workspace_bytes, a.tuning = buf.data_ptr(), need, 0                       # workspace without the opt-in bit: the plain launch
+    assert L.mrag_gemm_bf16(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(a)) == _lib.MRAG_OK and torch.equal(out, plain)
 
 
 def test_qkv_gemm_stream_k_tail_matches_plain(hip):
@@ -154,15 +158,16 @@ def test_qkv_gemm_stream_k_tail_matches_plain(hip):
     cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
     from motionrag_amd import _lib
     assert _lib.lib().mrag_gemm_workspace_bytes(B * S, 3 * D, K) > 0
-    got = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
-    assert torch.equal(got, ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18))
-    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_STREAMK
+    plain = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_STREAMK
     try:
-        plain = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+        got = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18)
+        assert torch.equal(got, ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text_len, eps=1e-6, q_premul=0.18))
     finally:
         ops.TUNING["gemm"] = 0
+    # a rounding flip of the bf16 projection moves a normalised, rotated feature by up to ~ulp(proj) * rstd * gamma: bound it loosely, count it tightly
     d = (got.float() - plain.float()).abs()
-    assert (d > 0).float().mean().item() < 2e-2 and (d <= plain.float().abs() * 2.0 ** -6 + 2e-3).all() and not torch.equal(got, plain)
+    assert (d > 0).float().mean().item() < 2e-2 and d.max().item() < 0.12 and not torch.equal(got, plain)
 
 
 def test_gemm_rejects_bad_arguments(hip):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Interleaved A/B on ONE device (cdna guide rule 24): the DiT's four linears with the stream-K tail (shipped) against the plain tile grid
-(MRAG_GEMM_TUNE_NO_STREAMK) and against hipBLASLt (torch.nn.functional.linear: the vendor ceiling, plain GEMM only)."""
+"""Interleaved A/B on ONE device (cdna guide rule 24): the DiT's four linears with the opt-in stream-K tail (MRAG_GEMM_TUNE_STREAMK) against the plain tile grid
+(the shipped default) and against hipBLASLt (torch.nn.functional.linear: the vendor ceiling, plain GEMM only)."""
 import os
 import sys
 
@@ -32,7 +32,7 @@ for name, N, K, epi in SHAPES:
             if label.startswith("hip"):
                 t = timeit(lambda: torch.nn.functional.linear(x, w, b), iters=8, warm=2)
             else:
-                ops.TUNING["gemm"] = 0 if label == "stream-K" else ops.GEMM_TUNE_NO_STREAMK
+                ops.TUNING["gemm"] = ops.GEMM_TUNE_STREAMK if label == "stream-K" else 0
                 t = timeit(lambda: ops.linear(x, w, b, out=out, **kw), iters=8, warm=2)
                 ops.TUNING["gemm"] = 0
             res[label].append(t)

@@ -95,6 +95,8 @@ typedef struct mrag_gemm_args {
                          (1 = 256x256 on 16 waves, 2 = 128x128), bits 8-15 GROUP_M of the tile order (0 = 4)           */
   int32_t geglu_act;  /* MRAG_EPI_GEGLU: 0 = v * gelu_erf(g) (diffusers / lvdm GEGLU), 1 = v * gelu_tanh(g) (T5 v1.1 "gated-gelu": gelu_new) */
   void* workspace;         /* optional scratch, 16-byte aligned, private to the call until it completes on `stream`; NULL = none        */
+  float acc_scale;         /* MRAG_EPI_RESID: C = resid + acc_scale * (acc + bias); 0 means 1.  The SVD UNet's AlphaBlender over a residual branch
+                              (a s + (1 - a)(s + c) = s + (1 - a) c) rides in the branch's last projection this way                            */
   int64_t workspace_bytes; /* with tuning & MRAG_GEMM_TUNE_STREAMK and >= mrag_gemm_workspace_bytes(M, N, K) bytes: the partial last round
                               of 256x256 tiles (e.g. 132 of 1 668 tiles on 256 CUs for the DiT's to_out / FF2) runs as a stream-K tail
                               launch -- its K-tiles dealt evenly over the CUs, partial sums exchanged through the workspace and summed in
@@ -463,6 +465,7 @@ typedef struct mrag_conv_args {
                                       CogVideoXCausalConv3d (the VAE behind cogvideox/module.py:39-40): x holds, per sample, the two context frames
                                       (conv cache, or the first frame twice) followed by t_frames frames -> x [(N / t_frames) (t_frames + 2), H, Wd, Cin],
                                       y [N, H, Wd, Cout], W [Cout, (kt, ky, kx, cin)]; zero padding in space, none in time.  0 = 2-D.            */
+  float acc_scale;                 /* MRAG_EPI_RESID: y = resid + acc_scale * (conv + bias); 0 means 1                                          */
 } mrag_conv_args;
 int mrag_conv_bf16(void* stream, const mrag_conv_args* args);
 /* row gather for nn.Conv3d((3,1,1), padding (1,0,0)), openaimodel3d.py:256-268:

@@ -54,7 +54,7 @@ class GemmArgs(Structure):
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
         ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32), ("geglu_act", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("workspace", c_void_p), ("acc_scale", c_float), ("workspace_bytes", c_int64),
     ]
 
 
@@ -140,7 +140,7 @@ class ConvArgs(Structure):
         ("x", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("y", c_void_p), ("resid", c_void_p),
         ("N", c_int32), ("H", c_int32), ("Wd", c_int32), ("Cin", c_int32), ("Cout", c_int32),
         ("stride", c_int32), ("upsample", c_int32), ("mode", c_int32), ("epilogue", c_int32), ("asym_pad", c_int32),
-        ("t_taps", c_int32), ("t_frames", c_int32),
+        ("t_taps", c_int32), ("t_frames", c_int32), ("acc_scale", c_float),
     ]
 
 

@@ -255,7 +255,8 @@ class APAdapterAttnProcessor2_0(nn.Module):
         self._fused = _FusedWeights()
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states=None, action_hidden_states=None,
-                 attention_mask=None, temb=None, scale: float = 1.0, ip_adapter_masks=None):
+                 attention_mask=None, temb=None, scale: float = 1.0, ip_adapter_masks=None, block_residual: Optional[torch.Tensor] = None):
+        """`block_residual` (not a diffusers argument): the caller's `x` of `x = attn2(norm2(x)) + x`; added in the output projection's epilogue"""
         residual = hidden_states
         ip_hidden_states = None
         if encoder_hidden_states is not None:                                      # :34-41
@@ -290,7 +291,11 @@ class APAdapterAttnProcessor2_0(nn.Module):
             ipkv = ops.linear(ip, wip)
             ops.attention(ip_q.view(B, L, H, 64), ipkv[..., :C].unflatten(-1, (H, 64)), ipkv[..., C:].unflatten(-1, (H, 64)),
                           out=o, resid=o, kv_batch_div=r, out_scale=float(self.scale[0]))
-        if attn.residual_connection and input_ndim != 4:
+        if block_residual is not None:
+            if attn.residual_connection or input_ndim == 4:
+                raise NotImplementedError("block_residual with residual_connection / 4-D input")
+            out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=block_residual)
+        elif attn.residual_connection and input_ndim != 4:
             out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=residual.contiguous())
         else:
             out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias)        # :129-131

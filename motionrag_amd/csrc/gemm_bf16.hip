@@ -59,6 +59,7 @@ struct GemmP {
   long long cv_C, cv_HW;
   // stream-K tail (SK instantiation): logical tiles [0, sk_main) run one per workgroup; the sk_rem tiles behind them are cut into sk_units equal
   // runs of K-tiles, one per workgroup; partial accumulators meet in sk_part, the last arriver of a tile (sk_ticket) sums them in K order
+  float acc_scale;    // MRAG_EPI_RESID: C = resid + acc_scale * (acc + bias) (1 unless the caller blends: AlphaBlender folded into a residual branch)
   float* sk_part; unsigned* sk_ticket;
   int sk_main, sk_rem, sk_units, sk_maxparts;
   int cv_tf;          // CONV == 1 with three temporal taps (causal 3x3x3): output frames per sample (input holds cv_tf + 2 frames per sample); 0 = 2-D
@@ -495,6 +496,10 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
           v[0] *= __uint_as_float(gg[0] << 16); v[1] *= __uint_as_float(gg[0] & 0xffff0000u);
           v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
         }
+        if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+        }
         u32x2 out;
         out[0] = pack_bf2(v[0], v[1]);
         out[1] = pack_bf2(v[2], v[3]);
@@ -736,6 +741,10 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
         v[0] *= __uint_as_float(gg[0] << 16); v[1] *= __uint_as_float(gg[0] & 0xffff0000u);
         v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
       }
+      if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+      }
       if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
         // the same rounding points as the LDS-staged epilogue above and as the reference's bf16 tensors (`x + gate * linear(.)`: the gated
         // projection is a bf16 tensor before the residual add) -- so a GEMM gives the same bits whichever tile configuration its size selects
@@ -910,6 +919,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.gate0 = (const bf16_t*)a->gate0; p.gate1 = (const bf16_t*)a->gate1;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
+  p.acc_scale = a->acc_scale == 0.0f ? 1.0f : a->acc_scale;
   if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
     if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
@@ -967,6 +977,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
   GemmP p{};
   p.A = (const bf16_t*)a->x; p.W = (const bf16_t*)a->W; p.bias = (const bf16_t*)a->bias; p.C = (bf16_t*)a->y; p.resid = (const bf16_t*)a->resid;
   p.N = a->Cout; p.ldc = a->Cout; p.ldr = a->Cout; p.cv_C = a->Cin; p.cv_ctiles = a->Cin / 64;
+  p.acc_scale = a->acc_scale == 0.0f ? 1.0f : a->acc_scale;
   hipStream_t s = (hipStream_t)stream;
   if (a->mode == MRAG_CONV_3X3) {
     if ((a->stride != 1 && a->stride != 2) || (a->upsample != 0 && a->upsample != 1)) return MRAG_EINVAL;

@@ -82,16 +82,16 @@ def conv3x3(x: torch.Tensor, conv: nn.Conv2d, *, stride: int = 1, upsample: bool
     return y.view(N, Ho, Wo, cout)
 
 
-def conv_t3(x: torch.Tensor, conv: nn.Conv3d, B: int, T: int, *, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Conv3d((3,1,1), padding (1,0,0)) on x [(b t), HW, C]"""
+def conv_t3(x: torch.Tensor, conv: nn.Conv3d, B: int, T: int, *, resid: Optional[torch.Tensor] = None, acc_scale: float = 1.0) -> torch.Tensor:
+    """nn.Conv3d((3,1,1), padding (1,0,0)) on x [(b t), HW, C]; with `resid`: resid + acc_scale * conv(x)"""
     C = x.shape[-1]
     cout = conv.weight.shape[0]
     wk = _CACHE.get(("t3", id(conv)), conv.weight, lambda: conv.weight.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, 3 * C).contiguous())
     if C % 64 == 0:
-        return ops.conv_implicit(x.contiguous(), wk, conv.bias, ops.CONV_T3, frames=T, resid=resid.contiguous() if resid is not None else None)
+        return ops.conv_implicit(x.contiguous(), wk, conv.bias, ops.CONV_T3, frames=T, resid=resid.contiguous() if resid is not None else None, acc_scale=acc_scale)
     rows = ops.unfold_t3(x, B, T)
     if resid is not None:
-        return ops.linear(rows, wk, conv.bias, epilogue=ops.EPI_RESID, resid=resid.reshape(-1, cout)).view(x.shape[0], x.shape[1], cout)
+        return ops.linear(rows, wk, conv.bias, epilogue=ops.EPI_RESID, resid=resid.reshape(-1, cout), acc_scale=acc_scale).view(x.shape[0], x.shape[1], cout)
     return ops.linear(rows, wk, conv.bias).view(x.shape[0], x.shape[1], cout)
 
 

@@ -55,8 +55,10 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
            epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate0: Optional[torch.Tensor] = None,
-           gate1: Optional[torch.Tensor] = None, rows_per_batch: int = 0, split: int = 0, gate_stride: int = 0, geglu_tanh: bool = False) -> torch.Tensor:
-    """out = epilogue(x @ weight.T + bias); x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout).  EPI_GEGLU: `geglu_tanh` picks gelu_tanh (T5's gated-gelu) over gelu_erf."""
+           gate1: Optional[torch.Tensor] = None, rows_per_batch: int = 0, split: int = 0, gate_stride: int = 0, geglu_tanh: bool = False,
+           acc_scale: float = 1.0) -> torch.Tensor:
+    """out = epilogue(x @ weight.T + bias); x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout).  EPI_GEGLU: `geglu_tanh` picks gelu_tanh (T5's gated-gelu) over gelu_erf.
+    EPI_RESID: out = resid + acc_scale * (x @ weight.T + bias)."""
     _dev(x, name="x"); _dev(weight, name="weight")
     x2 = _rows(x)
     M, K = x2.shape
@@ -78,6 +80,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     a.epilogue = epilogue
     a.tuning = TUNING["gemm"]
     a.geglu_act = 1 if geglu_tanh else 0
+    a.acc_scale = acc_scale
     if resid is not None:
         r2 = _rows(_dev(resid, name="resid"))
         a.resid, a.ldr = _p(r2), r2.stride(0)
@@ -643,7 +646,7 @@ CONV_3X3, CONV_T3 = 1, 2
 
 
 def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor], mode: int, *, stride: int = 1, upsample: bool = False,
-                  frames: int = 0, resid: Optional[torch.Tensor] = None, asym_pad: bool = False, t_frames: int = 0) -> torch.Tensor:
+                  frames: int = 0, resid: Optional[torch.Tensor] = None, asym_pad: bool = False, t_frames: int = 0, acc_scale: float = 1.0) -> torch.Tensor:
     """implicit-GEMM convolution (no materialised im2col), Cin % 64 == 0.
     CONV_3X3: x [N, H, W, Cin] -> [N, Ho, Wo, Cout], wk [Cout, 9 Cin] in (ky, kx, cin) order.
               t_frames = T > 0: causal 3x3x3 -- x [S (T + 2), H, W, Cin] (two context frames in front of each sample's T frames) -> [S T, H, W, Cout],
@@ -684,7 +687,7 @@ def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor
         _dev(resid, name="resid")
         if resid.numel() != out.numel() or not resid.is_contiguous():
             raise ValueError("conv_implicit: resid must be contiguous with the output's shape")
-        a.resid, a.epilogue = _p(resid), EPI_RESID
+        a.resid, a.epilogue, a.acc_scale = _p(resid), EPI_RESID, acc_scale
     check(_lib.lib().mrag_conv_bf16(_stream(), ctypes.byref(a)), "mrag_conv_bf16")
     return out
 

@@ -91,8 +91,9 @@ class TemporalResnetBlock(nn.Module):
         self.norm2 = nn.GroupNorm(32, out_channels, eps=eps)
         self.conv2 = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
 
-    def forward(self, x, silu_temb, b: int):
-        """x [(b f), HW, C]; GroupNorm statistics over (f, h, w) per sample (5-D input in the package)"""
+    def forward(self, x, silu_temb, b: int, branch_scale: float = 1.0):
+        """x [(b f), HW, C]; GroupNorm statistics over (f, h, w) per sample (5-D input in the package).  Returns x + branch_scale * branch(x):
+        the block's own `x + h` for 1, the AlphaBlender mix behind it (SpatioTemporalResBlock) for 1 - alpha"""
         N, HW, C = x.shape
         f = N // b
         h = ops.groupnorm(x.view(b, f * HW, C), self.norm1.weight, self.norm1.bias, 32, self.norm1.eps, silu=True).view(N, HW, C)
@@ -100,7 +101,7 @@ class TemporalResnetBlock(nn.Module):
         t = ops.linear(silu_temb, self.time_emb_proj.weight, self.time_emb_proj.bias)            # [(b f), C] -> one vector per frame
         h = ops.add_bcast(h, t, HW)
         h = ops.groupnorm(h.view(b, f * HW, C), self.norm2.weight, self.norm2.bias, 32, self.norm2.eps, silu=True).view(N, HW, C)
-        return conv_t3(h, self.conv2, b, f, resid=x)
+        return conv_t3(h, self.conv2, b, f, resid=x, acc_scale=branch_scale)
 
 
 class SpatioTemporalResBlock(nn.Module):
@@ -113,8 +114,10 @@ class SpatioTemporalResBlock(nn.Module):
     def forward(self, x, silu_temb, b: int):
         s = self.spatial_res_block(x, silu_temb)
         N, H, W, C = s.shape
-        t = self.temporal_res_block(s.view(N, H * W, C), silu_temb, b)
-        return self.time_mixer(s, t.view(N, H, W, C))
+        # time_mixer(s, t) with t = s + c (the temporal block's residual form): a s + (1 - a)(s + c) = s + (1 - a) c -- the blend rides in the epilogue
+        # of the temporal block's last convolution (one rounding of the mixed value instead of the package's three; no separate pass over the activation)
+        a = _sigmoid_scalar(self.time_mixer.mix_factor)
+        return self.temporal_res_block(s.view(N, H * W, C), silu_temb, b, branch_scale=1.0 - a).view(N, H, W, C)
 
 
 class AttnProcessor2_0:
@@ -126,7 +129,8 @@ class AttnProcessor2_0:
             raise ValueError("precision must be 'bf16' or 'fp8'")
         self.precision = precision
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, temporal=None, **_):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, temporal=None, block_residual=None, **_):
+        residual = block_residual                                                       # the block's `x` of `x = attn(norm(x)) + x` (not a diffusers argument)
         x = hidden_states
         Nb, L, C = x.shape
         H = attn.heads
@@ -149,6 +153,8 @@ class AttnProcessor2_0:
             wkv = _CACHE.get(("kv", id(attn)), (attn.to_k.weight, attn.to_v.weight), lambda: _cat0([attn.to_k.weight, attn.to_v.weight]))
             kv = ops.linear(ctx, wkv)
             o = ops.attention(q, kv[..., :C].unflatten(-1, (H, 64)), kv[..., C:].unflatten(-1, (H, 64)), kv_batch_div=Nb // ctx.shape[0])
+        if residual is not None:                                                        # block's `attn(norm(x)) + x` in the projection's epilogue
+            return ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=residual)
         return ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias)
 
 
@@ -178,6 +184,23 @@ def _attn(dim, heads, head_dim, cross=None):
     return Attention(dim, cross_attention_dim=cross, heads=heads, dim_head=head_dim, bias=False, out_bias=True, processor=AttnProcessor2_0())
 
 
+def _attn_plus(attn, normed, x, **kw):
+    """attn(normed) + x with the add in the output projection's epilogue when the site's processor takes `block_residual` (the two processors of this
+    package); any other processor object installed through the diffusers protocol gets the plain call and a separate add"""
+    import inspect
+    proc = attn.processor
+    ok = getattr(proc, "_takes_block_residual", None)
+    if ok is None:
+        ok = "block_residual" in inspect.signature(proc.__call__).parameters
+        try:
+            proc._takes_block_residual = ok
+        except AttributeError:
+            pass
+    if ok:
+        return attn(normed, block_residual=x, **kw)
+    return ops.add(attn(normed, **kw), x)
+
+
 class BasicTransformerBlock(nn.Module):
     """spatial block; `attn2` is the motion-adapter site (its processor is replaced by APAdapterAttnProcessor2_0)"""
 
@@ -189,8 +212,8 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, encoder_hidden_states):
-        x = ops.add(self.attn1(_ln(self.norm1, x)), x)
-        x = ops.add(self.attn2(_ln(self.norm2, x), encoder_hidden_states=encoder_hidden_states), x)
+        x = _attn_plus(self.attn1, _ln(self.norm1, x), x)
+        x = _attn_plus(self.attn2, _ln(self.norm2, x), x, encoder_hidden_states=encoder_hidden_states)
         return self.ff(_ln(self.norm3, x), resid=x)
 
 
@@ -212,7 +235,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         """x [(b f), HW, C] in place of the package's [(b hw), f, C]; first_frame_context [b, 1, D]"""
         b, f, hw = temporal
         x = self.ff_in(_ln(self.norm_in, x), resid=x)
-        x = ops.add(self.attn1(_ln(self.norm1, x), temporal=temporal), x)
+        x = _attn_plus(self.attn1, _ln(self.norm1, x), x, temporal=temporal)
         # attn2: every (b, hw) row attends to ONE context token, so softmax == 1 exactly and the branch is
         # to_out(to_v(context)) whatever the query; the package builds `time_context` with rows ordered (hw, b) while the
         # hidden rows are ordered (b, hw), i.e. row n = b*hw + s reads the context of batch n % B -- reproduced as is.

@@ -325,8 +325,8 @@ def test_attention32_family_matches_reference_and_attn16(hip, variant):
         resid = bf(torch.randn(4, 333, 192, generator=g))
         out = ops.attention(qkv[:, :, 0], kv[:, :, 0].to(DEV), kv[:, :, 1].to(DEV), resid=resid.to(DEV), kv_batch_div=2, out_scale=0.75)
         close(out, resid.float() + 0.75 * sdpa_ref(qkv[:, :, 0].cpu(), kv[:, :, 0], kv[:, :, 1], kv_div=2), scale=1.0)
-        # key-split tail (256-row variant): 16 x 256 + 112 rows; the tail rows equal the reference and the unsplit launch to a bf16 ulp or two
-        B2, H2, Sq2, Skv2 = 1, 16, 16 * 256 + 112, 4200
+        # key-split tail (256-row variant): 64 x 256 + 112 rows; the tail rows equal the reference and the unsplit launch to a bf16 ulp or two
+        B2, H2, Sq2, Skv2 = 1, 16, 64 * 256 + 112, 4200
         q2 = bf(torch.randn(B2, Sq2, H2, 64, generator=g))
         k2, v2 = (bf(torch.randn(B2, Skv2, H2, 64, generator=g)) for _ in range(2))
         k2[:, 3000] = bf(9.0 * q2[:, Sq2 - 5] / q2[:, Sq2 - 5].norm(dim=-1, keepdim=True))

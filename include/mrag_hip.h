@@ -152,12 +152,9 @@ typedef struct mrag_attn_args {
   int64_t bias_sh;
 } mrag_attn_args;
 enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pair kernel          */
-       MRAG_ATTN_TUNE_PIPE = 2,      /* intra-wave software-pipelined variant (measured slower)    */
-       MRAG_ATTN_TUNE_NW4 = 4,       /* 4-wave workgroups for long sequences                       */
+                                     /* 2, 4: retired (intra-wave pipelined tile, 4-wave long-sequence workgroups: measured slower, code pruned in round 3) */
        MRAG_ATTN_TUNE_LEGACY = 8,    /* long unmasked sequences through the 32x32x16 kernel        */
-       MRAG_ATTN_TUNE_QB4 = 16,      /* attn16 with 64 query rows per wave (no key-split tail)     */
-       MRAG_ATTN_TUNE_QB4W4 = 32,    /* the same in 4-wave workgroups, two per CU                  */
-       MRAG_ATTN_TUNE_SUBS2 = 64,    /* attn16 with 128-key LDS stages (one barrier per 128 keys)  */
+                                     /* 16, 32, 64: retired (64 rows per wave, 128-key stages)     */
        MRAG_ATTN_TUNE_W4PF = 128,    /* attn16: 4-wave workgroups x 3 per CU, fragment prefetch    */
        MRAG_ATTN_TUNE_W8PF = 256,    /* attn16: 32 rows per wave, 8-wave workgroups, two per CU    */
        MRAG_ATTN_TUNE_M32 = 512,     /* attn32: the attn16 algorithm on 32x32x16, 64 rows per wave */

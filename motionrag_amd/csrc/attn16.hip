@@ -30,7 +30,7 @@ namespace {
 
 constexpr int KVB = 64;                // keys per compute tile
 constexpr int TILE_BYTES = KVB * 128;
-// LDS: K ring of NS stages, then the V ring; a stage = SUBS compute tiles (SUBS = 2: half the barriers)
+// LDS: K ring of NS stages, then the V ring
 constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
 
 struct Lane16 {
@@ -39,37 +39,10 @@ struct Lane16 {
   int g;
 };
 
-// 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads.  PF = false: one group (16 VGPRs of fragments) live at a time;
-// PF = true (the 168-register, 3-waves-per-SIMD configuration): both groups requested up front, the second lands under the first one's MFMAs.
-template <int OFF, int QB, bool PF, typename Between>
+// 8 K fragments of one 64-key tile -> 8 QB score MFMAs, in two groups of 4 reads: one group (16 VGPRs of fragments) is live at a time.
+// (Requesting both groups up front -- 150 -> 168 VGPRs forced -- lost 4 % when it cost the third workgroup per CU; pruned in round 3.)
+template <int OFF, int QB, typename Between>
 __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
-  if constexpr (PF) {
-    u32x4 k0[4], k1[4];
-    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
-                 : "=&v"(k0[0]), "=&v"(k0[1]), "=&v"(k0[2]), "=&v"(k0[3])
-                 : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF), "n"(OFF + 2048) : "memory");
-    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7"
-                 : "=&v"(k1[0]), "=&v"(k1[1]), "=&v"(k1[2]), "=&v"(k1[3])
-                 : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 4096), "n"(OFF + 6144) : "memory");
-    between();
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]) :: "memory");   // LDS reads return in order
-#pragma unroll
-    for (int kbl = 0; kbl < 2; ++kbl)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        s[kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
-        s[kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[2 * kbl + 1]), qf[qb][1], s[kbl][qb], 0, 0, 0);
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) :: "memory");
-#pragma unroll
-    for (int kbl = 0; kbl < 2; ++kbl)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        s[2 + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
-        s[2 + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[2 * kbl + 1]), qf[qb][1], s[2 + kbl][qb], 0, 0, 0);
-      }
-    return;
-  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
     u32x4 kf[4];                           // [2 * kbl + ks]
@@ -92,27 +65,6 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
         s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl]), qf[qb][0], negm[qb], 0, 0, 0);
         s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl + 1]), qf[qb][1], s[2 * half + kbl][qb], 0, 0, 0);
       }
-  }
-}
-
-// the 8 transposed reads of one 32-key step of V^T (4 d-blocks x keys 4 g.. / 16 + 4 g..), no wait: the caller retires them
-template <int VOFF>
-__device__ __forceinline__ void pv_issue(const Lane16& ln, u32x2 (&lo)[4], u32x2 (&hi)[4]) {
-  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
-               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF), "n"(VOFF + 2048) : "memory");
-}
-
-template <int QB>
-__device__ __forceinline__ void pv_mma(const u32x2 (&lo)[4], const u32x2 (&hi)[4], const bf16x8 (&pb)[QB], f32x4 (&o)[4][QB]) {
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[qb], o[db][qb], 0, 0, 0);
   }
 }
 
@@ -151,11 +103,11 @@ struct NoHook16 {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <int QB, int NW, int SUBS, int NS, bool PF, bool KVSPLIT>
-__global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) void attn16_kernel(const AttnP p) {
+template <int QB, int NW, int NS, bool KVSPLIT>
+__global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : 4) void attn16_kernel(const AttnP p) {
   constexpr int ROWS = NW * QB * 16;
-  constexpr int SK = SUBS * KVB, STAGE_BYTES = SUBS * TILE_BYTES, V_BASE = NS * STAGE_BYTES;   // an LDS stage = SUBS compute tiles; one barrier per stage
-  constexpr int PPW = SUBS * 8 / NW;                                                // 1-KiB DMA pieces per wave per K (and V) stage
+  constexpr int SK = KVB, STAGE_BYTES = TILE_BYTES, V_BASE = NS * STAGE_BYTES;      // an LDS stage = one 64-key compute tile; one barrier per stage
+  constexpr int PPW = 8 / NW;                                                       // 1-KiB DMA pieces per wave per K (and V) stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,8 +236,8 @@ __global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) v
     }
   };
 
-  auto tile = [&](int t, auto off_c, auto sub_c, auto hook) {
-    constexpr int OFF = decltype(off_c)::value, SUB = decltype(sub_c)::value;
+  auto tile = [&](int t, auto off_c, auto hook) {
+    constexpr int OFF = decltype(off_c)::value, SUB = 0;
     f32x4 s[4][QB];
     float ps[QB];
     const bool ragged = (t == nt - 1) && (skv & (SK - 1));
@@ -294,12 +246,10 @@ __global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) v
     // ~20 log2 units: never on real activations): those re-centre -- exact tile maximum, m moves, O and l are rescaled by the exact
     // factor -- and, for an exploded tile, the score MFMAs are simply run again (its K stage is still resident).
     bool recentre = (t == 0 && SUB == 0);
-    u32x2 vlo[4], vhi[4];
     bf16x8 pb[2][QB];
-    if constexpr (PF) pv_issue<V_BASE + OFF>(ln, vlo, vhi);   // V^T fragments of k-step 0: their LDS latency hides under the score MFMAs and the softmax
     for (int pass = 0;; ++pass) {
-      if (pass == 0) qk16<OFF, QB, PF>(ln, qf, negm, s, hook);
-      else qk16<OFF, QB, PF>(ln, qf, negm, s, NoHook16());
+      if (pass == 0) qk16<OFF, QB>(ln, qf, negm, s, hook);
+      else qk16<OFF, QB>(ln, qf, negm, s, NoHook16());
       if (ragged) {   // keys before t * 64 were consumed by the previous tile
         asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
         const int lo = t * SK;
@@ -362,24 +312,14 @@ __global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) v
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
-    if constexpr (PF) {
-      u32x2 wlo[4], whi[4];
-      pv_issue<V_BASE + OFF + 4096>(ln, wlo, whi);            // k-step 1 lands under k-step 0's MFMAs
-      asm volatile("" : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3]));   // landed at qk16's lgkmcnt(0)
-      pv_mma<QB>(vlo, vhi, pb[0], o);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wlo[0]), "+v"(wlo[1]), "+v"(wlo[2]), "+v"(wlo[3]), "+v"(whi[0]), "+v"(whi[1]), "+v"(whi[2]), "+v"(whi[3]) :: "memory");
-      pv_mma<QB>(wlo, whi, pb[1], o);
-    } else {
-      pv16<V_BASE + OFF, QB>(ln, pb, o);
-    }
+    pv16<V_BASE + OFF, QB>(ln, pb, o);
   };
   auto iter = [&](int t, auto stage_c) {
     constexpr int STG = decltype(stage_c)::value;
     wait_pair();   // barrier #t: stage t has landed for every wave, stage t - 1's buffer is free
     auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
     if (!wave_active) { early_issue(); return; }
-    tile(t, std::integral_constant<int, STG * STAGE_BYTES>{}, std::integral_constant<int, 0>{}, early_issue);
-    if constexpr (SUBS == 2) tile(t, std::integral_constant<int, STG * STAGE_BYTES + TILE_BYTES>{}, std::integral_constant<int, 1>{}, NoHook16());
+    tile(t, std::integral_constant<int, STG * STAGE_BYTES>{}, early_issue);
   };
 
 
@@ -433,15 +373,15 @@ __global__ __launch_bounds__(NW * 64, QB == 4 ? 2 : ((PF || QB == 3) ? 3 : 4)) v
 
 }  // namespace
 
-template <int QB, int NW, int SUBS, int NS, bool PF>
+template <int QB, int NW, int NS>
 static int launch16_plain(hipStream_t s, AttnP p) {
   constexpr int ROWS = NW * QB * 16;
-  const size_t lds = 2 * NS * SUBS * TILE_BYTES;
+  const size_t lds = 2 * NS * TILE_BYTES;
   p.n_qtiles = (p.Sq + ROWS - 1) / ROWS;
-  const void* kf = (const void*)attn16_kernel<QB, NW, SUBS, NS, PF, false>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, NS, false>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, SUBS, NS, PF, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, NS, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -455,10 +395,10 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
   p.kv_splits = pl->splits; p.chunk_keys = pl->chunk_keys; p.rem_rows = pl->rem_rows; p.tile_rows = NW * QB * 16;
   p.part_o = (float*)workspace;
   p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl->splits * pl->rem_rows * 64 * sizeof(float));
-  const void* kf = (const void*)attn16_kernel<QB, NW, 1, NS, false, true>;
+  const void* kf = (const void*)attn16_kernel<QB, NW, NS, true>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn16_kernel<QB, NW, 1, NS, false, true>), dim3(p.n_main + nbh * pl->splits), dim3(NW * 64), lds, s, p);
+  MRAG_LAUNCH((attn16_kernel<QB, NW, NS, true>), dim3(p.n_main + nbh * pl->splits), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
   return mrag_launch_attn_combine(s, p);
 }
@@ -466,20 +406,17 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
 // Shipped configuration (interleaved A/B on MI355X, tools/attn_ab.py, profiles/r2_attn_ab_variants.txt): 48 query rows per wave (QB = 3),
 // 4-wave workgroups of 192 rows, THREE per CU (168 VGPRs, 3 waves per SIMD, 48 KB of LDS each).  Against 32 rows per wave in 8-wave
 // workgroups (two per CU, 4 waves per SIMD) it reads 2/3 of the K / V fragment bytes per FLOP and its barriers couple 4 waves instead of 8:
-// 6.54-6.62 vs 6.82-6.83 ms at the BASELINE shape, 2.87-2.89 vs 2.95-3.03 ms at the DynamiCrafter level-0 shape.  64 rows per wave (2 waves
-// per SIMD) loses 5-7 %, fragment prefetching at 150 VGPRs 4 %, 128-key LDS stages 1 % (all kept as developer variants below).
+// 6.54-6.62 vs 6.82-6.83 ms at the BASELINE shape, 2.87-2.89 vs 2.95-3.03 ms at the DynamiCrafter level-0 shape.  Retired by measurement and
+// pruned in round 3: 64 rows per wave (2 waves per SIMD: -5..7 %), fragment prefetching at 150 VGPRs (-4 %), 128-key LDS stages (-1 %).
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
   if ((long long)p.Skv * p.k_ss * 2 >= 0xffffffffLL || (long long)p.Skv * p.v_ss * 2 >= 0xffffffffLL) return MRAG_ENOTSUP;   // walked 32-bit DMA offsets
-  // developer A/B variants (tools/attn_ab.py), all without the key-split tail:
-  if (tuning & MRAG_ATTN_TUNE_QB4) return launch16_plain<4, 8, 1, 4, false>(s, p);      // 64 query rows per wave, 512-row workgroups, one per CU
-  if (tuning & MRAG_ATTN_TUNE_QB4W4) return launch16_plain<4, 4, 1, 4, false>(s, p);    // 64 rows per wave, 4-wave workgroups, two per CU
-  if (tuning & MRAG_ATTN_TUNE_SUBS2) return launch16_plain<2, 8, 2, 2, false>(s, p);    // 128-key LDS stages, one barrier per 128 keys
-  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 1, 2, false>(s, p);     // 32 rows per wave, 4-wave workgroups, FOUR per CU (2-stage ring)
-  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 1, 4, false>(s, p);     // round-2 first form: 32 rows per wave, 8-wave workgroups, two per CU
+  // the two developer variants tools/attn_ab.py still compares against (both without the key-split tail):
+  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 2>(s, p);     // 32 rows per wave, 4-wave workgroups, FOUR per CU (2-stage ring)
+  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 4>(s, p);     // round-2 first form: 32 rows per wave, 8-wave workgroups, two per CU
   if (pl) {
     if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 192) return MRAG_ENOTSUP;
     return launch16_split<3, 4, 3>(s, p, pl, workspace);
   }
-  return launch16_plain<3, 4, 1, 3, false>(s, p);
+  return launch16_plain<3, 4, 3>(s, p);
 }

@@ -17,9 +17,9 @@
 //     V stages; K is XOR-swizzled on the source side for conflict-free ds_read_b128, V keeps
 //     row-major [key][d] with its 64-byte halves swapped on odd key pairs and is consumed through
 //     ds_read_b64_tr_b16 (hardware transpose) as the A operand of O^T = V^T . P^T;
-//   * PIPE variant (long sequences): software-pipelined inside the wave -- the QK^T MFMAs of tile
-//     t+1 are issued before the softmax VALU work of tile t, so the matrix pipe and the vector pipe
-//     of a SIMD are busy together instead of taking turns behind the per-tile barrier;
+//   * variants retired by measurement (round 3 pruned their code; numbers in DESIGN.md section 3): the intra-wave software-pipelined tile
+//     (9.9 vs 8.7 ms at S = 17 776), 4-wave workgroups for long sequences, packed fp32 adds, per-32-key-block softmax + PV, static priorities
+//     for the younger half, a half-tile stagger of the two halves, vector-pipe max subtraction, f32-add row sums;
 //   * the running max is carried as the MFMA's C operand (S' = K.Q^T - m comes out of the chain,
 //     no per-score subtract) and only moved when a tile raises it by more than THR (deferred
 //     rescale): the rare path rescales O, l, the pending S' and the prefetched S' together;
@@ -41,45 +41,7 @@ extern "C" int mrag_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSym
   } while (0)
 #endif
 
-#ifndef MRAG_ATTN_WPS
-#define MRAG_ATTN_WPS 4   // waves per SIMD the long-sequence kernel is register-budgeted for (A/B on MI355X: 4 -> +9.5 % over 2)
-#endif
 
-#ifndef MRAG_ATTN_IMM_STAGE
-#define MRAG_ATTN_IMM_STAGE 1   // ring stage as a ds_read offset immediate (main loop unrolled by the ring depth)
-#endif
-#ifndef MRAG_ATTN_PK_ADD
-// packed fp32 adds (v_pk_add_f32) for the max subtraction and the row sums: 16 instead of 32 vector instructions per block, but measured
-// SLOWER beside the MFMAs (927-936 vs 951-968 TFLOP/s, interleaved A/B) -> off
-#define MRAG_ATTN_PK_ADD 0
-#endif
-#ifndef MRAG_ATTN_SPLIT
-// per-32-key-block softmax + PV (softmax_block / pv_half: block 0's vector work under block 1's MFMA chain, block 0's PV under block 1's
-// vector work) instead of one softmax over the 64-key tile: bit-correct, spill-free at 127 VGPRs, and measured EQUAL (997-999 vs 996-1004
-// TFLOP/s): with four waves per SIMD the other waves already fill those gaps -> off, the simpler path ships
-#define MRAG_ATTN_SPLIT 0
-#endif
-#ifndef MRAG_ATTN_YOUNG_PRIO
-// static s_setprio for waves 4-7 of the 8-wave workgroup: measured 948-966 (prio 1) and 951-955 (prio 2) vs 966-983 TFLOP/s without -> off
-#define MRAG_ATTN_YOUNG_PRIO 0
-#endif
-#ifndef MRAG_ATTN_UPFRONT
-// bit 0: all 8 K fragment reads of a tile up front; bit 1: all 16 V^T reads (see qk_tile_imm8).  Interleaved A/B on MI355X (B=2, H=48,
-// S=17776): 0 -> 7.770-7.790 ms, 1 -> 7.730, 2 -> 7.772-7.782, 3 -> 7.712-7.728: the K side is worth +0.7 %, the V side nothing -> 1
-#define MRAG_ATTN_UPFRONT 1
-#endif
-#ifndef MRAG_ATTN_DOT2_SUM
-// softmax row sums by v_dot2c_f32_bf16 over the packed bf16 P pairs (see softmax_tile): 16 instead of 32 vector instructions per tile.
-// Interleaved A/B on MI355X: 7.743 vs 7.769 ms (+0.3 %) -- the vector-instruction count is no longer what bounds the loop.
-#define MRAG_ATTN_DOT2_SUM 1
-#endif
-#ifndef MRAG_ATTN_MFMA_MAX
-// 1 = subtract the running max on the matrix pipe (one extra k-step per 32x32 score block whose key fragment is (-1, 0, ...) and whose
-// query fragment is (m, 0, ...), m kept bf16-representable) instead of 32 v_add per tile.  Measured on MI355X (interleaved A/B, B=2 H=48
-// S=17776): neutral in the first 4-waves-per-SIMD kernel (992-995 vs 994-996 TFLOP/s), +1.6 % once the ring stage became an immediate
-// and the loop was unrolled (1010-1016 vs 994-999): the vector pipe is the busier one (PMC: ~77 % active, 9-10 vector instructions per MFMA)
-#define MRAG_ATTN_MFMA_MAX 1
-#endif
 
 #include "attn_common.h"
 
@@ -88,7 +50,7 @@ namespace {
 constexpr float kThr = 5.0f;          // deferred-rescale threshold in log2 units (P <= 32)
 constexpr int KVB = 64;               // keys per tile
 constexpr int TILE_BYTES = KVB * 128; // one K (or V) tile
-constexpr int NS = MRAG_ATTN_WPS >= 4 ? 4 : 5;   // LDS ring stages per operand (DMA runs D = NS-2 tiles ahead); 2 x 64 KB fit two workgroups per CU
+constexpr int NS = 4;   // LDS ring stages per operand (DMA runs D = NS-2 tiles ahead); 2 x 64 KB fit two workgroups per CU
 constexpr int V_BASE = NS * TILE_BYTES;  // LDS: K stages 0..NS-1, then V stages 0..NS-1
 
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 raw, float s) {
@@ -123,7 +85,6 @@ struct NoHook {
 template <typename Between = NoHook>
 __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const bf16x8 (&qf)[4], const f32x16& negm, f32x16& s0, f32x16& s1,
                                         Between between = Between()) {
-#if MRAG_ATTN_WPS >= 4
   // register-lean form (4 waves per SIMD hide the LDS latency): one 32-key block at a time
   const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
   const unsigned b0 = base + ((0 + ln.hh) ^ ln.k_swz) * 16, b1 = base + ((2 + ln.hh) ^ ln.k_swz) * 16;
@@ -134,16 +95,12 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
   between();
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C
-#if MRAG_ATTN_MFMA_MAX
   // The running max is subtracted BY THE MATRIX PIPE: one more k-step whose key fragment is the constant (-1, 0, ..., 0) and whose
   // query fragment is (m, 0, ..., 0) adds -m to every score of the lane's query.  The vector pipe is the saturated one here
   // (per tile 32 v_exp + 32 row-sum adds + 17 v_max3 + 16 cvt_pk against 16 MFMAs); this trades 32 v_add (128 issue cycles)
   // for 2 MFMAs (64 matrix cycles, 16 issue cycles).  m is kept bf16-representable so the product is exact (softmax_tile).
   const u32x4 kneg = {ln.hh == 0 ? 0x0000bf80u : 0u, 0u, 0u, 0u};
   const u32x4 qm = {__float_as_uint(negm[1]), 0u, 0u, 0u};
-#else
-  const float nm = negm[0];   // register-lean form: the running max is one VGPR and is subtracted after the chain
-#endif
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
@@ -153,61 +110,14 @@ __device__ __forceinline__ void qk_tile(const char* kst, const Lane& ln, const b
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
-#if MRAG_ATTN_MFMA_MAX
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
-#else
-#if MRAG_ATTN_PK_ADD
-  {   // 16 v_pk_add_f32 per block instead of 32 v_add_f32
-    const f32x2 nm2 = {nm, nm};
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      const f32x2 a = f32x2{s0[i], s0[i + 1]} + nm2, b = f32x2{s1[i], s1[i + 1]} + nm2;
-      s0[i] = a[0]; s0[i + 1] = a[1]; s1[i] = b[0]; s1[i + 1] = b[1];
-    }
-  }
-#else
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
-#endif
-#endif
-#else
-  u32x4 k0f[4], k1f[4];
-  const unsigned base = (unsigned)(size_t)(kst + ln.k_row_off);
-  const unsigned a0 = base + ((0 + ln.hh) ^ ln.k_swz) * 16, a1 = base + ((2 + ln.hh) ^ ln.k_swz) * 16;
-  const unsigned a2 = base + ((4 + ln.hh) ^ ln.k_swz) * 16, a3 = base + ((6 + ln.hh) ^ ln.k_swz) * 16;
-  asm volatile(
-      "ds_read_b128 %0, %8\n\t"
-      "ds_read_b128 %4, %8 offset:4096\n\t"
-      "ds_read_b128 %1, %9\n\t"
-      "ds_read_b128 %5, %9 offset:4096\n\t"
-      "ds_read_b128 %2, %10\n\t"
-      "ds_read_b128 %6, %10 offset:4096\n\t"
-      "ds_read_b128 %3, %11\n\t"
-      "ds_read_b128 %7, %11 offset:4096"
-      : "=&v"(k0f[0]), "=&v"(k0f[1]), "=&v"(k0f[2]), "=&v"(k0f[3]), "=&v"(k1f[0]), "=&v"(k1f[1]), "=&v"(k1f[2]), "=&v"(k1f[3])
-      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-      : "memory");
-  between();
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(k0f[0]), "+v"(k0f[1]), "+v"(k0f[2]), "+v"(k0f[3]), "+v"(k1f[0]), "+v"(k1f[1]), "+v"(k1f[2]), "+v"(k1f[3])
-               :
-               : "memory");
-  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0f[0]), qf[0], negm, 0, 0, 0);
-  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1f[0]), qf[0], negm, 0, 0, 0);
-#pragma unroll
-  for (int ks = 1; ks < 4; ++ks) {
-    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k0f[ks]), qf[ks], s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k1f[ks]), qf[ks], s1, 0, 0, 0);
-  }
-#endif
 }
 
 // O^T += V^T . P^T (8 MFMAs).  The 16 transposed reads go through ONE asm statement: hipcc cannot see that the
 // ds_read_tr16 builtin does not alias the in-flight LDS-DMA of later tiles and would drain it (s_waitcnt vmcnt(0))
 // in the middle of the tile.  EXEC is all ones here (wave-uniform control flow only).
 __device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1, f32x16& lacc) {
-#if MRAG_ATTN_WPS >= 4
   {
     const unsigned c0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0), c1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
 #pragma unroll
@@ -230,46 +140,8 @@ __device__ __forceinline__ void pv_tile(const char* vst, const Lane& ln, const b
       }
     }
   }
-#else
-  u32x2 t0[8], t1[8];
-  const unsigned a0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0);
-  const unsigned a1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %16 offset:0\n\t"
-      "ds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
-      "ds_read_b64_tr_b16 %8, %17 offset:0\n\t"
-      "ds_read_b64_tr_b16 %9, %17 offset:1024\n\t"
-      "ds_read_b64_tr_b16 %2, %16 offset:2048\n\t"
-      "ds_read_b64_tr_b16 %3, %16 offset:3072\n\t"
-      "ds_read_b64_tr_b16 %10, %17 offset:2048\n\t"
-      "ds_read_b64_tr_b16 %11, %17 offset:3072\n\t"
-      "ds_read_b64_tr_b16 %4, %16 offset:4096\n\t"
-      "ds_read_b64_tr_b16 %5, %16 offset:5120\n\t"
-      "ds_read_b64_tr_b16 %12, %17 offset:4096\n\t"
-      "ds_read_b64_tr_b16 %13, %17 offset:5120\n\t"
-      "ds_read_b64_tr_b16 %6, %16 offset:6144\n\t"
-      "ds_read_b64_tr_b16 %7, %16 offset:7168\n\t"
-      "ds_read_b64_tr_b16 %14, %17 offset:6144\n\t"
-      "ds_read_b64_tr_b16 %15, %17 offset:7168\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(t0[0]), "=&v"(t0[1]), "=&v"(t0[2]), "=&v"(t0[3]), "=&v"(t0[4]), "=&v"(t0[5]), "=&v"(t0[6]), "=&v"(t0[7]),
-        "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]), "=&v"(t1[6]), "=&v"(t1[7])
-      : "v"(a0), "v"(a1)
-      : "memory");
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const u32x4 w0 = {t0[2 * kk][0], t0[2 * kk][1], t0[2 * kk + 1][0], t0[2 * kk + 1][1]};
-    const u32x4 w1 = {t1[2 * kk][0], t1[2 * kk][1], t1[2 * kk + 1][0], t1[2 * kk + 1][1]};
-    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[kk], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[kk], o1, 0, 0, 0);
-    // row sums on the (under-used) matrix pipe instead of 32 v_add per tile on the (saturated) vector pipe: A = all-ones
-    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[kk], lacc, 0, 0, 0);
-  }
-#endif
 }
 
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
 // The ring stage as an INSTRUCTION IMMEDIATE (ds_read offset field) instead of per-tile address arithmetic: the main loop is unrolled by
 // NS, so `t % NS` is a compile-time constant, the lane's base addresses are loop-invariant registers, and ~11 integer vector instructions
 // per tile (of ~144) disappear from a loop whose vector pipe is ~77 % busy.
@@ -281,30 +153,19 @@ __device__ __forceinline__ void qk_tile_imm(const Lane& ln, const bf16x8 (&qf)[4
   between();
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) :: "memory");
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if MRAG_ATTN_MFMA_MAX
   const u32x4 kneg = {ln.hh == 0 ? 0x0000bf80u : 0u, 0u, 0u, 0u};
   const u32x4 qm = {__float_as_uint(negm[1]), 0u, 0u, 0u};
-#else
-  const float nm = negm[0];
-#endif
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s0, 0, 0, 0);
-#ifndef MRAG_ATTN_EXP_HALF_LDS   // diagnostic builds only (wrong results): how much of the loop is LDS bandwidth?
   asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\t"
                "s_waitcnt lgkmcnt(0)"
                : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(ln.kb[0]), "v"(ln.kb[1]), "v"(ln.kb[2]), "v"(ln.kb[3]), "n"(STG * TILE_BYTES + 4096) : "memory");
-#endif
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[0], zero, 0, 0, 0);
 #pragma unroll
   for (int ks = 1; ks < 4; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), qf[ks], s1, 0, 0, 0);
-#if MRAG_ATTN_MFMA_MAX
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s0, 0, 0, 0);
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kneg), __builtin_bit_cast(bf16x8, qm), s1, 0, 0, 0);
-#else
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { s0[i] += nm; s1[i] += nm; }
-#endif
 }
 
 template <int STG>
@@ -321,9 +182,6 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
                    : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
                    : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES), "n"(STG * TILE_BYTES + 1024), "n"(STG * TILE_BYTES + 2048), "n"(STG * TILE_BYTES + 3072) : "memory");
     } else {
-#ifdef MRAG_ATTN_EXP_HALF_LDS
-      asm volatile("" : "=v"(u0[0]), "=v"(u0[1]), "=v"(u0[2]), "=v"(u0[3]), "=v"(u1[0]), "=v"(u1[1]), "=v"(u1[2]), "=v"(u1[3]));
-#else
       asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
                    "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
                    "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
@@ -331,7 +189,6 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
                    : "v"(ln.vc0), "v"(ln.vc1), "n"(STG * TILE_BYTES + 4096), "n"(STG * TILE_BYTES + 5120), "n"(STG * TILE_BYTES + 6144), "n"(STG * TILE_BYTES + 7168) : "memory");
-#endif
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -342,9 +199,7 @@ __device__ __forceinline__ void pv_tile_imm(const Lane& ln, const bf16x8 (&pb)[4
     }
   }
 }
-#endif
 
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE && MRAG_ATTN_MFMA_MAX
 // Both 32-key blocks' fragments requested UP FRONT (8 K reads / 16 V^T reads in flight, released to the MFMAs by counted lgkmcnt waits --
 // LDS reads return in order): the second block's LDS latency hides under the first block's MFMAs instead of being paid behind them.  The LDS
 // pipe is only ~25 % busy in this loop (256 B/clk per CU, tools/exp/lds_rate.hip; SQ_LDS_IDX_ACTIVE), so what the reads cost is their latency.
@@ -402,7 +257,6 @@ __device__ __forceinline__ void pv_tile_imm16(const Lane& ln, const bf16x8 (&pb)
     }
   }
 }
-#endif
 
 struct Run {
   f32x16 o0, o1, negm;
@@ -471,55 +325,33 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
   const bool first = (t == 0);
   if (first || __any(tm > kThr)) {
     float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_MFMA_MAX
     // the shift lives in a bf16 MFMA operand: round the new running max to bf16 and move by the EXACT difference (both ends are
     // bf16 values, their fp32 difference is exact), so O / l / P all see the same shift.  Rows that do not move keep delta == 0.
     const float m_new = bf_round(r.m + delta);
     delta = m_new - r.m;
-#endif
     if (!first) {
       const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
       for (int i = 0; i < 16; ++i) { r.o0[i] *= alpha; r.o1[i] *= alpha; }
-#if MRAG_ATTN_WPS >= 4
       r.lacc[0] *= alpha;
-#else
-#pragma unroll
-      for (int i = 0; i < 16; ++i) r.lacc[i] *= alpha;
-#endif
     }
     r.m += delta;
-#if MRAG_ATTN_WPS >= 4
     r.negm[0] = -r.m;
-#if MRAG_ATTN_MFMA_MAX
     r.negm[1] = __uint_as_float(ln.hh == 0 ? (unsigned)f2bf(r.m) : 0u);   // query-side fragment (m, 0, ..., 0) of the max-subtracting k-step
-#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
-#else
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; r.negm[i] = -r.m; }
-#endif
     if constexpr (HAS_NEXT) {  // the prefetched S' of tile t+1 was formed against the old max
 #pragma unroll
       for (int i = 0; i < 16; ++i) { n0[i] -= delta; n1[i] -= delta; }
     }
   }
   mid();  // staggered waves rendezvous here (between the max / rescale head and the exp body)
-#if MRAG_ATTN_WPS >= 4
   float la = 0.f, lb = 0.f;
-#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     s0[i] = __builtin_amdgcn_exp2f(s0[i]);
     s1[i] = __builtin_amdgcn_exp2f(s1[i]);
-#if MRAG_ATTN_WPS >= 4 && !MRAG_ATTN_DOT2_SUM
-    la += s0[i]; lb += s1[i];
-#endif
   }
-#if MRAG_ATTN_WPS >= 4 && !MRAG_ATTN_DOT2_SUM
-  r.lacc[0] += la + lb;   // lane-local half of the row sum; the two half-waves are combined in the epilogue
-#endif
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     u32x4 w0, w1;
@@ -527,7 +359,6 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
     for (int j = 0; j < 4; ++j) {
       w0[j] = pack_bf2(s0[8 * s + 2 * j], s0[8 * s + 2 * j + 1]);
       w1[j] = pack_bf2(s1[8 * s + 2 * j], s1[8 * s + 2 * j + 1]);
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_DOT2_SUM
       // row sum of the bf16 pairs the PV MFMAs consume: one v_dot2c_f32_bf16 (pair . (1, 1) + acc, fp32) per packed register instead of
       // two v_add_f32 per pair -- 16 instead of 32 vector instructions per tile, and l sums exactly the P values that multiply V
       // (the packed registers pass through an empty asm: hipcc 7.2 otherwise selects sub-register 0 of the u32x4 for all four dot2c)
@@ -536,103 +367,20 @@ __device__ __forceinline__ void softmax_tile(const AttnP& p, const int skv, cons
       w0[j] = p0; w1[j] = p1;
       la = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, p0), __builtin_bit_cast(bf16v2, 0x3f803f80u), la, false);
       lb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, p1), __builtin_bit_cast(bf16v2, 0x3f803f80u), lb, false);
-#endif
     }
     pb[s] = __builtin_bit_cast(bf16x8, w0);
     pb[2 + s] = __builtin_bit_cast(bf16x8, w1);
   }
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_DOT2_SUM
   r.lacc[0] += la + lb;   // lane-local half of the row sum; the two half-waves are combined in the epilogue
-#endif
 }
 
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
-// Per-block softmax + PV (4-waves-per-SIMD form): the two 32-key blocks of a tile are independent online-softmax steps, so block 0's
-// max / exp / convert depends only on S0 and is issued while the matrix pipe still runs S1's MFMA chain, and block 0's PV MFMAs run under
-// block 1's vector work -- an intra-wave software pipeline at no extra registers.  With the deferred rescale the running max moves
-// rarely, so the second threshold check per tile is one more half-wave swap + v_max3.
-__device__ __forceinline__ void softmax_block(int t, int kb, f32x16& s, f32x16* pending, Run& r, bf16x8 (&pb)[4]) {
-  float ma = max3_asm(s[0], s[1], s[2]), mb = max3_asm(s[3], s[4], s[5]);
-  ma = max3_asm(ma, s[6], s[7]); mb = max3_asm(mb, s[8], s[9]);
-  ma = max3_asm(ma, s[10], s[11]); mb = max3_asm(mb, s[12], s[13]);
-  const float tm = half_swap_max(max3_asm(max3_asm(ma, s[14], s[15]), mb, mb));
-  const bool first = (t == 0 && kb == 0);
-  if (first || __any(tm > kThr)) {
-    const float delta = first ? fmaxf(tm, -1e30f) : fmaxf(tm, 0.f);
-    if (!first) {
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { r.o0[i] *= alpha; r.o1[i] *= alpha; }
-      r.lacc[0] *= alpha;
-    }
-    r.m += delta;
-    r.negm[0] = -r.m;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] -= delta;
-    if (pending) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) (*pending)[i] -= delta;     // block 1 of this tile was formed against the old max
-    }
-  }
-#if MRAG_ATTN_PK_ADD
-  f32x2 l2 = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 16; i += 2) {
-    s[i] = __builtin_amdgcn_exp2f(s[i]); s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1]);
-    l2 += f32x2{s[i], s[i + 1]};
-  }
-  r.lacc[0] += l2[0] + l2[1];
-#else
-  float l = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(s[i]); l += s[i]; }
-  r.lacc[0] += l;
-#endif
-#pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) {
-    u32x4 w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[8 * h2 + 2 * j], s[8 * h2 + 2 * j + 1]);
-    pb[2 * kb + h2] = __builtin_bit_cast(bf16x8, w);
-  }
-}
-
-__device__ __forceinline__ void pv_half(const char* vst, const Lane& ln, int half, const bf16x8 (&pb)[4], f32x16& o0, f32x16& o1) {
-  const unsigned c0 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half0), c1 = (unsigned)(size_t)(vst + ln.v_lane_off + ln.v_half1);
-  u32x2 u0[4], u1[4];
-  if (half == 0) {
-    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:0\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-                 "ds_read_b64_tr_b16 %4, %9 offset:0\n\tds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
-                 "ds_read_b64_tr_b16 %2, %8 offset:2048\n\tds_read_b64_tr_b16 %3, %8 offset:3072\n\t"
-                 "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
-                 : "v"(c0), "v"(c1) : "memory");
-  } else {
-    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:4096\n\tds_read_b64_tr_b16 %1, %8 offset:5120\n\t"
-                 "ds_read_b64_tr_b16 %4, %9 offset:4096\n\tds_read_b64_tr_b16 %5, %9 offset:5120\n\t"
-                 "ds_read_b64_tr_b16 %2, %8 offset:6144\n\tds_read_b64_tr_b16 %3, %8 offset:7168\n\t"
-                 "ds_read_b64_tr_b16 %6, %9 offset:6144\n\tds_read_b64_tr_b16 %7, %9 offset:7168\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
-                 : "v"(c0), "v"(c1) : "memory");
-  }
-#pragma unroll
-  for (int k2 = 0; k2 < 2; ++k2) {
-    const u32x4 w0 = {u0[2 * k2][0], u0[2 * k2][1], u0[2 * k2 + 1][0], u0[2 * k2 + 1][1]};
-    const u32x4 w1 = {u1[2 * k2][0], u1[2 * k2][1], u1[2 * k2 + 1][0], u1[2 * k2 + 1][1]};
-    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), pb[2 * half + k2], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), pb[2 * half + k2], o1, 0, 0, 0);
-  }
-}
-#endif
 
 // SHORTKV: key sets of at most one tile (motion tokens, text, temporal frames) -- same code, no barrier stagger; a separate
 // instantiation so that profiles list the HBM-bound small-KV launches apart from the MFMA-bound long-sequence ones.
 // KVSPLIT: the launch's last workgroups (blockIdx >= n_main) each scan ONE CHUNK of the keys for the ragged last query tile of a
 // (b, h) pair and leave (unnormalised O, running max, row sum) in the workspace for attn_combine_kernel -- see launch_attn_split.
-template <int NW, bool HAS_MASK, bool PIPE, bool SHORTKV = false, bool KVSPLIT = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATTN_WPS : 1) void attn_fwd_kernel(const AttnP p) {
+template <int NW, bool HAS_MASK, bool SHORTKV = false, bool KVSPLIT = false>
+__global__ __launch_bounds__(NW * 64, (NW == 8 && !HAS_MASK) ? 4 : 1) void attn_fwd_kernel(const AttnP p) {
   constexpr int PPW = NW >= 8 ? 1 : 8 / NW;  // 1 KiB DMA pieces per wave per K (or V) tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -698,9 +446,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   const int last_start = skv - KVB;
   const unsigned lds0 = (unsigned)(size_t)smem;
   auto issue_k = [&](int stage, int t) {
-#ifdef MRAG_ATTN_EXP_HALF_DMA   // diagnostic builds only (wrong results): how much of the loop is the L2 -> LDS tile traffic?
-    if (t & 1) return;
-#endif
     if (last_start >= 0) {
       const int start = t * KVB < last_start ? t * KVB : last_start;
       const char* tile = (const char*)kbase + (long long)start * p.k_ss * 2;
@@ -717,9 +462,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     }
   };
   auto issue_v = [&](int stage, int t) {
-#ifdef MRAG_ATTN_EXP_HALF_DMA
-    if (t & 1) return;
-#endif
     if (last_start >= 0) {
       const int start = t * KVB < last_start ? t * KVB : last_start;
       const char* tile = (const char*)vbase + (long long)start * p.v_ss * 2;
@@ -763,16 +505,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
   // retired by a COUNTED vmcnt (every wave issues exactly 2*PPW DMA instructions per tile pair, tiles past the end
   // re-read clamped rows so the count never changes) + a raw s_barrier: __syncthreads() would drain the queue.
   const int nt = (skv + KVB - 1) / KVB;
-#if MRAG_ATTN_YOUNG_PRIO
-  // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment (stamps: QK^T 1600 vs 1220 cycles,
-  // exp / PV 1300 vs 1000) and the first half then waits for it at the per-tile barrier: one static priority bump for that half
-  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(MRAG_ATTN_YOUNG_PRIO);
-#endif
-#ifndef MRAG_ATTN_STAGGER
   constexpr int D = NS - 1;   // without the half-tile stagger the stage refilled after barrier #t is the one read in iteration t-1
-#else
-  constexpr int D = NS - 2;
-#endif
 #ifdef MRAG_ATTN_STAMPS
   unsigned long long vm_wait = 0, bar_wait = 0;
 #endif
@@ -792,17 +525,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
     vm_wait += w1 - w0; bar_wait += w2 - w1;
 #endif
   };
-  if constexpr (!PIPE) {
+  {
     // iteration t reads K(t), V(t) from stage t % NS.  Barrier #j guarantees tile j has landed for every wave; after it each
     // wave issues tile j + D into the stage of tile j - 2 (ring of NS = D + 2).  The "late" half of the workgroup (waves
     // NW/2..NW-1, the SIMD partners of the early half) runs HALF A TILE BEHIND: it takes barrier #j in the middle of its
     // softmax(j-1), so while one wave of a SIMD is in its MFMA phase (QK^T / PV) its partner is in its exp/convert phase,
     // instead of both queueing on the same pipe right after a common barrier.
-#ifndef MRAG_ATTN_STAGGER   // measured: with two independent workgroups per CU the half-tile stagger LOSES 9 % (A/B, one device)
     const bool late = false;
-#else
-    const bool late = NW >= 8 && !SHORTKV && wave >= NW / 2;
-#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) { issue_k(i, i); issue_v(i, i); }
     if (late) { wait_pair(); issue_k(D % NS, D); issue_v(D % NS, D); }   // barrier #0
@@ -833,41 +562,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       if (!wave_active) { early_issue(); mid(); return; }
       f32x16 s0, s1;
       bf16x8 pb[4];
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
-#if (MRAG_ATTN_UPFRONT & 1) && MRAG_ATTN_MFMA_MAX
       if constexpr (STG >= 0) qk_tile_imm8<STG>(ln, qf, r.negm, s0, s1, early_issue);
-#else
-      if constexpr (STG >= 0) qk_tile_imm<STG>(ln, qf, r.negm, s0, s1, early_issue);
-#endif
       else
-#endif
       qk_tile(smem + (t % NS) * TILE_BYTES, ln, qf, r.negm, s0, s1, early_issue);
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(tc);
 #endif
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
-      if constexpr (decltype(split_c)::value) {
-        softmax_block(t, 0, s0, &s1, r, pb);
-        mid();
-        pv_half(smem + V_BASE + (t % NS) * TILE_BYTES, ln, 0, pb, r.o0, r.o1);
-        softmax_block(t, 1, s1, nullptr, r, pb);
-        pv_half(smem + V_BASE + (t % NS) * TILE_BYTES, ln, 1, pb, r.o0, r.o1);
-      } else {
-        softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
-        pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
-      }
-#else
       softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, s0, s1, s0, s1, r, pb, mid);
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
-#if (MRAG_ATTN_UPFRONT & 2) && MRAG_ATTN_MFMA_MAX
-      if constexpr (STG >= 0) pv_tile_imm16<STG>(ln, pb, r.o0, r.o1);
-#else
       if constexpr (STG >= 0) pv_tile_imm<STG>(ln, pb, r.o0, r.o1);
-#endif
       else
-#endif
       pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
-#endif
 #ifdef MRAG_ATTN_STAMPS
       MRAG_STAMP(tg);
       acc_t[0] += tb - ta; acc_t[1] += tc - tb; acc_t[2] += td - tc; acc_t[3] += te - td; acc_t[4] += tg - te; acc_t[5] += tg - ta;
@@ -875,15 +579,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
         };
     // full unmasked tiles take the per-block pipeline; the ragged last tile (and the masked instantiation) the one-softmax path,
     // in separate loops so that neither path's live state burdens the other
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_SPLIT
-    const int n_split = HAS_MASK ? 0 : ((skv & (KVB - 1)) ? nt - 1 : nt);
-#else
     const int n_split = 0;
-#endif
     using RT = std::integral_constant<int, -1>;
     for (int t = 0; t < n_split; ++t) iter(t, std::true_type{}, RT{});
     int t = n_split;
-#if MRAG_ATTN_WPS >= 4 && MRAG_ATTN_IMM_STAGE
     if constexpr (NS == 4 && NW == 8 && !HAS_MASK && !SHORTKV) {
       // unrolled by the ring depth: stage = t % NS is an immediate (n_split is 0 here, so t starts at a multiple of NS)
       for (; t + NS <= nt; t += NS) {
@@ -893,7 +592,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
         iter(t + 3, std::false_type{}, std::integral_constant<int, 3>{});
       }
     }
-#endif
     for (; t < nt; ++t) iter(t, std::false_type{}, RT{});
 #ifdef MRAG_ATTN_STAMPS
     if (g_stamp_buf && lane == 0 && blockIdx.x < 2048) {
@@ -902,49 +600,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
       g_stamp_buf[((long long)blockIdx.x * NW + wave) * 8 + 7] = (vm_wait << 32) | (bar_wait & 0xffffffffull);
     }
 #endif
-#ifdef MRAG_ATTN_STAGGER
-    if (!late && NW >= 8 && !SHORTKV) __builtin_amdgcn_s_barrier();
-#endif   // barrier #nt pairs with the late half's last rendezvous
-  } else {
-    // software-pipelined: iteration t issues QK^T(t+1) (matrix pipe) ahead of softmax(t) (vector pipe) and PV(t).
-    // It reads K(t+1), V(t) and issues the pair [K(t+D+1), V(t+D)] into the stages of K(t), V(t-1) (read in iteration t-1).
-    issue_k(0, 0);
-#pragma unroll
-    for (int i = 0; i < D; ++i) { issue_k((i + 1) % NS, i + 1); issue_v(i % NS, i); }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * D) : "memory");   // K(0) landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    f32x16 sA0, sA1, sB0, sB1;
-    if (wave_active) qk_tile(smem, ln, qf, r.negm, sA0, sA1);
-    auto step = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
-      wait_pair();
-      issue_k((t + D + 1) % NS, t + D + 1); issue_v((t + D) % NS, t + D);
-      if (!wave_active) return;
-      bf16x8 pb[4];
-      if (t + 1 < nt) {
-        qk_tile(smem + ((t + 1) % NS) * TILE_BYTES, ln, qf, r.negm, n0, n1);
-        softmax_tile<HAS_MASK, true>(p, skv, ln, t, nt, qrow_c, c0, c1, n0, n1, r, pb);
-      } else {
-        softmax_tile<HAS_MASK, false>(p, skv, ln, t, nt, qrow_c, c0, c1, c0, c1, r, pb);
-      }
-      pv_tile(smem + V_BASE + (t % NS) * TILE_BYTES, ln, pb, r.o0, r.o1, r.lacc);
-    };
-    for (int t = 0; t < nt; t += 2) {
-      step(t, sA0, sA1, sB0, sB1);
-      if (t + 1 < nt) step(t + 1, sB0, sB1, sA0, sA1);
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
 
   if (!wave_active) return;
   // ---- epilogue: normalise by the MFMA-accumulated row sum (already complete over both half-waves' keys), fused residual
   if (qrow >= p.Sq) return;
-#if MRAG_ATTN_WPS >= 4
   {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r.lacc[0]), __float_as_uint(r.lacc[0]), false, false);
     r.lacc[0] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-#endif
   if (KVSPLIT && split_unit) {   // partial result of this key chunk; attn_combine_kernel merges the chunks
     const long long prow_i = (long long)(blockIdx.x - p.n_main) * p.rem_rows + wave * 32 + r32;
     float* po = p.part_o + prow_i * 64 + 4 * ln.hh;
@@ -984,18 +649,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && !PIPE && !HAS_MASK) ? MRAG_ATT
 }
 
 
-template <int NW, bool PIPE, bool SHORTKV = false>
+template <int NW, bool SHORTKV = false>
 int launch_attn(hipStream_t s, AttnP p) {
   p.n_qtiles = (p.Sq + NW * 32 - 1) / (NW * 32);
   const dim3 grid(p.n_qtiles * p.B * p.H), block(NW * 64);
   const size_t lds = 2 * NS * TILE_BYTES;
   {
-    const void* kf = (p.mask || p.bias) ? (const void*)attn_fwd_kernel<NW, true, PIPE, SHORTKV> : (const void*)attn_fwd_kernel<NW, false, PIPE, SHORTKV>;
+    const void* kf = (p.mask || p.bias) ? (const void*)attn_fwd_kernel<NW, true, SHORTKV> : (const void*)attn_fwd_kernel<NW, false, SHORTKV>;
     const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (p.mask || p.bias) MRAG_LAUNCH((attn_fwd_kernel<NW, true, PIPE, SHORTKV>), grid, block, lds, s, p);
-  else MRAG_LAUNCH((attn_fwd_kernel<NW, false, PIPE, SHORTKV>), grid, block, lds, s, p);
+  if (p.mask || p.bias) MRAG_LAUNCH((attn_fwd_kernel<NW, true, SHORTKV>), grid, block, lds, s, p);
+  else MRAG_LAUNCH((attn_fwd_kernel<NW, false, SHORTKV>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }
@@ -1067,10 +732,10 @@ int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspa
   p.part_o = (float*)workspace;
   p.part_ml = (float2*)((char*)workspace + (size_t)nbh * pl.splits * pl.rem_rows * 64 * sizeof(float));
   const size_t lds = 2 * NS * TILE_BYTES;
-  const void* kf = (const void*)attn_fwd_kernel<8, false, false, false, true>;
+  const void* kf = (const void*)attn_fwd_kernel<8, false, false, true>;
   const hipError_t e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  MRAG_LAUNCH((attn_fwd_kernel<8, false, false, false, true>), dim3(p.n_main + nbh * pl.splits), dim3(512), lds, s, p);
+  MRAG_LAUNCH((attn_fwd_kernel<8, false, false, true>), dim3(p.n_main + nbh * pl.splits), dim3(512), lds, s, p);
   MRAG_LAUNCH_CHECK();
   MRAG_LAUNCH(attn_combine_kernel, dim3((unsigned)(((long long)nbh * pl.rem_rows + 15) / 16)), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
@@ -1300,8 +965,6 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   p.qscale = a->q_prescaled ? 1.0f : a->scale * 1.4426950408889634f;
   p.out_scale = a->out_scale;
   hipStream_t s = (hipStream_t)stream;
-  // The intra-wave software-pipelined variant (PIPE) measures SLOWER than the staggered-barrier loop on MI355X with
-  // hipcc 7.2's schedule (9.9 ms vs 8.7 ms at S = 17 776); it stays selectable for tuning (tools/microbench.py).
   if (a->Sq <= 16 && a->Skv <= 16 && !masked && !a->resid && !(a->tuning & MRAG_ATTN_TUNE_NO_TINY)) {   // temporal attention of the UNets
     const long long pairs = (long long)a->B * a->H;
     long long blocks = (pairs + 3) / 4;
@@ -1310,14 +973,11 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     MRAG_LAUNCH_CHECK();
     return MRAG_OK;
   }
-  const bool pipe = (a->tuning & MRAG_ATTN_TUNE_PIPE) != 0;
-  if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, false, true>(s, p);
-  const int nw_big = (a->tuning & MRAG_ATTN_TUNE_NW4) ? 4 : 8;
-  if (a->Sq > 128 && nw_big == 4) return launch_attn<4, false>(s, p);
+  if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, true>(s, p);
   const bool legacy = (a->tuning & MRAG_ATTN_TUNE_LEGACY) != 0;
-  const bool may_split = a->Sq > 128 && !pipe && !masked && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
+  const bool may_split = a->Sq > 128 && !masked && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
   if (may_split && ((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
-  if (a->Sq > 128 && !pipe && !masked && !legacy && (a->tuning & (MRAG_ATTN_TUNE_M32 | MRAG_ATTN_TUNE_M32QB1))) {   // attn32.hip: round-2 algorithm on 32x32x16
+  if (a->Sq > 128 && !masked && !legacy && (a->tuning & (MRAG_ATTN_TUNE_M32 | MRAG_ATTN_TUNE_M32QB1))) {   // attn32.hip: round-2 algorithm on 32x32x16
     const bool qb1 = (a->tuning & MRAG_ATTN_TUNE_M32QB1) != 0;
     SplitPlan pl;
     bool split = false;
@@ -1328,7 +988,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     const int rc = mrag_launch_attn32(s, p, split ? &pl : nullptr, a->workspace, qb1 ? 1 : 0);
     if (rc != MRAG_ENOTSUP) return rc;
   }
-  if (a->Sq > 128 && !pipe && !masked && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
+  if (a->Sq > 128 && !masked && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
     SplitPlan pl;
     bool split = false;
     if (may_split) {
@@ -1342,7 +1002,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     const SplitPlan pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, 256, 512);
     if (pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes) return launch_attn_split(s, p, pl, a->workspace);
   }
-  if (a->Sq > 128) return pipe ? launch_attn<8, true>(s, p) : launch_attn<8, false>(s, p);
-  if (a->Sq > 32) return pipe ? launch_attn<2, true>(s, p) : launch_attn<2, false>(s, p);
-  return pipe ? launch_attn<1, true>(s, p) : launch_attn<1, false>(s, p);
+  if (a->Sq > 128) return launch_attn<8>(s, p);
+  if (a->Sq > 32) return launch_attn<2>(s, p);
+  return launch_attn<1>(s, p);
 }

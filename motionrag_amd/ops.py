@@ -22,7 +22,7 @@ LOG2E = 1.4426950408889634
 # Nothing on the launch path reads the environment.
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
-ATTN_TUNE_NO_TINY, ATTN_TUNE_PIPE, ATTN_TUNE_NW4, ATTN_TUNE_LEGACY, ATTN_TUNE_QB4, ATTN_TUNE_QB4W4, ATTN_TUNE_SUBS2, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 2, 4, 8, 16, 32, 64, 128, 256
+ATTN_TUNE_NO_TINY, ATTN_TUNE_LEGACY, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 8, 128, 256
 ATTN_TUNE_M32, ATTN_TUNE_M32QB1 = 512, 1024
 
 

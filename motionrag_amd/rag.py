@@ -9,8 +9,12 @@ Host-side mirror of the reference's retrieval interface:
 
 The reference delegates storage and search to lancedb==0.14.0 (Rust) and embedding to
 sentence-transformers (both third-party, not installed here).  This module keeps the table as
-`<db_path>/<table_name>/{vectors.npy, meta.json}` (fp32 [N, D] + the reference's row schema) and scores on
-the GPU with libmrag_hip.so's `mrag_topk_f32` (sequential-fmaf distances, deterministic ties).  Text
+`<db_path>/<table_name>/{vectors.npy, meta.arrow}`: fp32 [N, D] read through a memory map and uploaded to HBM in
+chunks (the host never holds a second copy), and the reference's row schema as an Arrow IPC file that is memory-mapped
+and read LAZILY -- only the `video` column is touched when the table opens (dictionary-encoded into the int32 group ids
+of the `video != self` filter); result rows are `take`n from the mapped columns.  Sized for what the scan was measured
+at (10^7 rows: 30.7 GB of vectors, no per-row Python objects); tables written by round 2 (`meta.json`) still open.
+Scoring: libmrag_hip.so's `mrag_topk_f32` (sequential-fmaf distances, deterministic ties).  Text
 inputs need an `embedder` callable (text -> [D] fp32); the shipped data path always passes embeddings
 (datamodule.py:233 hands `anno['text_embedding']`).
 """
@@ -36,9 +40,36 @@ def prepare_annotations(annotations: List[dict], text_name: str = "llm_caption",
              "dataset": dataset_name, "video": a["video"], "start_sec": a["start_sec"], "end_sec": a["end_sec"]} for a in annotations]
 
 
+_ARROW_TYPES = {"text": "string", "id": "int64", "uid": "string", "dataset": "string", "video": "string", "start_sec": "float64", "end_sec": "float64"}
+UPLOAD_CHUNK_BYTES = 256 << 20
+
+
+def _rows_to_table(rows: List[dict]):
+    import pyarrow as pa
+    cols = {}
+    for k in SCHEMA:
+        vals = [r.get(k) for r in rows]                  # partial rows (tests, ad-hoc tables): missing fields are nulls
+        try:
+            cols[k] = pa.array(vals, type=getattr(pa, _ARROW_TYPES[k])())
+        except (pa.ArrowInvalid, pa.ArrowTypeError):      # e.g. string ids: keep what the annotations carry
+            cols[k] = pa.array(vals)
+    return pa.table(cols)
+
+
+def _read_meta(tdir: str):
+    """the table's metadata as a (memory-mapped, zero-copy) Arrow table; round-2 tables carry meta.json instead"""
+    import pyarrow as pa
+    apath = os.path.join(tdir, "meta.arrow")
+    if os.path.exists(apath):
+        return pa.ipc.open_file(pa.memory_map(apath, "r")).read_all()
+    with open(os.path.join(tdir, "meta.json")) as f:
+        return _rows_to_table(json.load(f))
+
+
 def add_to_db(annotations: List[dict], embeddings: Optional[np.ndarray] = None, embedder: Optional[Callable] = None,
               text_name: str = "llm_caption", db_path: str = "../data/rag.db") -> None:
     """tools/build_rag_database.py:16-52: append rows (+ their text embeddings) to table `text_name`."""
+    import pyarrow as pa
     tdir = os.path.join(db_path, text_name)
     os.makedirs(tdir, exist_ok=True)
     if embeddings is None:
@@ -48,15 +79,32 @@ def add_to_db(annotations: List[dict], embeddings: Optional[np.ndarray] = None, 
     embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
     if embeddings.shape[0] != len(annotations):
         raise ValueError("one embedding per annotation")
-    vec_path, meta_path = os.path.join(tdir, "vectors.npy"), os.path.join(tdir, "meta.json")
-    rows = [{k: a[k] for k in SCHEMA} for a in annotations]
-    if os.path.exists(vec_path):
-        embeddings = np.concatenate([np.load(vec_path), embeddings], axis=0)
-        with open(meta_path) as f:
-            rows = json.load(f) + rows
-    np.save(vec_path, embeddings)
-    with open(meta_path, "w") as f:
-        json.dump(rows, f)
+    vec_path, meta_path = os.path.join(tdir, "vectors.npy"), os.path.join(tdir, "meta.arrow")
+    table = _rows_to_table(annotations)
+    if os.path.exists(vec_path):                            # append: the old rows are streamed through the page cache, never loaded whole
+        old = np.load(vec_path, mmap_mode="r")
+        if old.shape[1] != embeddings.shape[1]:
+            raise ValueError(f"table holds {old.shape[1]}-dimensional vectors, got {embeddings.shape[1]}")
+        tmp = vec_path + ".tmp.npy"
+        out = np.lib.format.open_memmap(tmp, mode="w+", dtype=np.float32, shape=(old.shape[0] + embeddings.shape[0], old.shape[1]))
+        step = max(1, UPLOAD_CHUNK_BYTES // (4 * old.shape[1]))
+        for i in range(0, old.shape[0], step):
+            j = min(i + step, old.shape[0])
+            out[i:j] = old[i:j]
+        out[old.shape[0]:] = embeddings
+        out.flush()
+        del out, old
+        os.replace(tmp, vec_path)
+        table = pa.concat_tables([_read_meta(tdir), table], promote_options="default")
+    else:
+        np.save(vec_path, embeddings)
+    tmp = meta_path + ".tmp"
+    with pa.OSFile(tmp, "wb") as sink, pa.ipc.new_file(sink, table.schema) as w:
+        w.write_table(table)
+    os.replace(tmp, meta_path)
+    legacy = os.path.join(tdir, "meta.json")
+    if os.path.exists(legacy):
+        os.remove(legacy)
 
 
 class RAGDatabase:
@@ -65,62 +113,94 @@ class RAGDatabase:
 
     def __init__(self, db_path: str, table_name: str, device: str = "cuda", metric: str = "l2", embedder: Optional[Callable] = None):
         tdir = os.path.join(db_path, table_name)
-        self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"))
-        with open(os.path.join(tdir, "meta.json")) as f:
-            self.rows = json.load(f)
+        self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"), mmap_mode="r")      # a view of the file: pages stream through on upload
+        self.meta = _read_meta(tdir)
         self._init_device(device, metric, embedder)
 
     @classmethod
-    def from_arrays(cls, vectors: np.ndarray, rows: List[dict], device: str = "cuda", metric: str = "l2", embedder=None) -> "RAGDatabase":
+    def from_arrays(cls, vectors: np.ndarray, rows, device: str = "cuda", metric: str = "l2", embedder=None) -> "RAGDatabase":
+        """`rows`: list of row dicts in the reference's schema, or an Arrow table with those columns"""
         self = cls.__new__(cls)
-        self.vectors_host = np.ascontiguousarray(vectors, dtype=np.float32)
-        self.rows = rows
+        self.vectors_host = vectors if (isinstance(vectors, np.ndarray) and vectors.dtype == np.float32) else np.ascontiguousarray(vectors, dtype=np.float32)
+        self.meta = _rows_to_table(rows) if isinstance(rows, list) else rows
         self._init_device(device, metric, embedder)
         return self
 
     def _init_device(self, device, metric, embedder):
+        import pyarrow as pa
+        import pyarrow.compute as pc
         if metric not in ("l2", "dot"):
             raise ValueError(f"Invalid metric: {metric}")
         self.metric, self.embedder = metric, embedder
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ops.HipOnly("RAGDatabase scores on the GPU only (libmrag_hip.so); there is no CPU search path")
-        videos = [r["video"] for r in self.rows]
-        self.video_ids = {v: i for i, v in enumerate(dict.fromkeys(videos))}
-        self.group = torch.tensor([self.video_ids[v] for v in videos], dtype=torch.int32, device=self.device)
-        self.vectors = torch.from_numpy(self.vectors_host).to(self.device)   # resident in HBM for every search
+        N, D = self.vectors_host.shape
+        if self.meta.num_rows != N:
+            raise ValueError(f"{N} vectors but {self.meta.num_rows} metadata rows")
+        # group id of a row = index of its video among the distinct videos in order of first appearance (the `video != "<name>"` filter of
+        # datamodule.py:235 compares ids in the kernel): one dictionary encoding of ONE column, no per-row Python objects
+        enc = pc.dictionary_encode(self.meta.column("video").combine_chunks() if self.meta.num_rows else pa.array([], pa.string()))
+        self._videos = enc.dictionary
+        self.group = torch.from_numpy(np.ascontiguousarray(enc.indices.to_numpy(zero_copy_only=False), dtype=np.int32)).to(self.device)
+        self.vectors = torch.empty(N, D, dtype=torch.float32, device=self.device)          # resident in HBM for every search
+        step = max(1, UPLOAD_CHUNK_BYTES // (4 * D))
+        for i in range(0, N, step):                                                        # chunked: the host side is the page cache of the mapped file
+            self.vectors[i:i + step].copy_(torch.from_numpy(np.ascontiguousarray(self.vectors_host[i:i + step])))
         self._plans = {}
 
     def __len__(self):
-        return len(self.rows)
+        return self.meta.num_rows
+
+    @property
+    def rows(self) -> List[dict]:
+        """every row as a dict (debugging / small tables; searches never build this)"""
+        return self.meta.to_pylist()
 
     # ---- result formatting (rag.py:17-34) ----
     def _format(self, rows_idx: np.ndarray, dist: np.ndarray, select: Optional[Sequence[str]], output_format: str):
+        import pyarrow as pa
         cols = list(select) if select is not None else list(SCHEMA)
-        out = []
-        for r, d in zip(rows_idx.tolist(), dist.tolist()):
-            if r < 0:
-                continue
-            rec = {c: self.rows[r][c] for c in cols}
-            rec["_distance"] = d
-            out.append(rec)
+        keep = rows_idx >= 0
+        hit = self.meta.select(cols).take(pa.array(rows_idx[keep].astype(np.int64)))      # only the requested columns of the hit rows leave the map
+        hit = hit.append_column("_distance", pa.array(dist[keep].astype(np.float64)))
         if output_format in ("dict", "list"):
-            return out
+            return hit.to_pylist()
         if output_format == "pandas":
-            import pandas as pd
-            return pd.DataFrame(out)
+            return hit.to_pandas()
         if output_format == "pyarrow":
-            import pyarrow as pa
-            return pa.Table.from_pylist(out)
+            return hit
         raise ValueError(f"Invalid format: {output_format}")
 
     def _exclude_id(self, where: Optional[str]) -> int:
+        """`where` of the reference is an SQL string handed to LanceDB (src/data/rag.py:36-61); the one filter the shipped data path builds is
+        `video != "<name>"` (datamodule.py:235), evaluated here as an id comparison inside the scan.  Anything else is refused up front."""
         if where is None:
             return -1
         m = _WHERE_RE.match(where)
         if not m:
-            raise NotImplementedError(f"only the reference's `video != \"<name>\"` filter is supported, got: {where!r}")
-        return self.video_ids.get(m.group(2), -1)
+            raise ValueError(f"unsupported `where` filter {where!r}: this scan evaluates only the reference's own `video != \"<name>\"` "
+                             f"(src/data/datamodule.py:235); a general SQL predicate needs LanceDB")
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        idx = pc.index_in(pa.scalar(m.group(2)), value_set=self._videos).as_py()
+        return -1 if idx is None else int(idx)
+
+    def _exclude_ids(self, where: Sequence[Optional[str]]) -> List[int]:
+        """one id per query; the names of a batch are looked up in ONE pass over the distinct videos"""
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        names = []
+        for w in where:
+            if w is None:
+                names.append(None)
+                continue
+            m = _WHERE_RE.match(w)
+            if not m:
+                self._exclude_id(w)          # raises the descriptive error
+            names.append(m.group(2))
+        idx = pc.index_in(pa.array(names, pa.string()), value_set=self._videos).to_pylist()
+        return [-1 if (i is None or n is None) else int(i) for i, n in zip(idx, names)]
 
     def _embed(self, text) -> np.ndarray:
         if isinstance(text, str):
@@ -141,7 +221,7 @@ class RAGDatabase:
         Q = q.shape[0]
         group = exclude = None
         if where is not None and any(w is not None for w in where):
-            exclude = torch.tensor([self._exclude_id(w) for w in where], dtype=torch.int32, device=self.device)
+            exclude = torch.tensor(self._exclude_ids(where), dtype=torch.int32, device=self.device)       # every filter parsed BEFORE anything launches
             group = self.group
         if Q <= 4 and top_k <= 64:       # the interactive search (rag.py:63-80): a prepared plan -- one C-ABI call = one launch, no allocation
             plan = self._plans.get((Q, top_k))

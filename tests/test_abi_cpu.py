@@ -111,7 +111,22 @@ def test_rag_table_io_and_filter_parsing(tmp_path):
     assert rows[1]["text"] == "" and rows[2]["uid"] == "coin/2" and set(rows[0]) == set(rag.SCHEMA)
     rag.add_to_db(rows, np.eye(3, 32, dtype=np.float32), text_name="t", db_path=str(tmp_path))
     rag.add_to_db(rows[:1], np.ones((1, 32), np.float32), text_name="t", db_path=str(tmp_path))
-    assert np.load(tmp_path / "t" / "vectors.npy").shape == (4, 32)
+    vec = np.load(tmp_path / "t" / "vectors.npy", mmap_mode="r")
+    assert vec.shape == (4, 32) and np.array_equal(vec[:3], np.eye(3, 32, dtype=np.float32)) and np.all(vec[3] == 1)
+    meta = rag._read_meta(str(tmp_path / "t"))                              # Arrow IPC file, memory-mapped; the reference's row schema
+    assert meta.num_rows == 4 and meta.column_names == list(rag.SCHEMA) and meta.column("video").to_pylist() == ["v0", "v1", "v2", "v0"]
+    assert meta.column("text").to_pylist()[1] == "" and meta.column("id").to_pylist() == [0, 1, 2, 0]
+    with pytest.raises(ValueError):
+        rag.add_to_db(rows[:1], np.ones((1, 16), np.float32), text_name="t", db_path=str(tmp_path))    # dimension mismatch on append
+    # a round-2 table (meta.json beside vectors.npy) still opens, and its next append converts it
+    import json
+    os.makedirs(tmp_path / "old")
+    np.save(tmp_path / "old" / "vectors.npy", np.eye(3, 32, dtype=np.float32))
+    with open(tmp_path / "old" / "meta.json", "w") as f:
+        json.dump(rows, f)
+    assert rag._read_meta(str(tmp_path / "old")).column("uid").to_pylist() == ["coin/0", "coin/1", "coin/2"]
+    rag.add_to_db(rows[2:], np.ones((1, 32), np.float32), text_name="old", db_path=str(tmp_path))
+    assert not os.path.exists(tmp_path / "old" / "meta.json") and rag._read_meta(str(tmp_path / "old")).num_rows == 4
     assert rag._WHERE_RE.match('video != "a b/c.mp4"').group(2) == "a b/c.mp4"
     assert rag._WHERE_RE.match("video != 'x'").group(2) == "x"
     assert rag._WHERE_RE.match("start_sec > 3") is None

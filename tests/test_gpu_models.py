@@ -296,8 +296,48 @@ def test_rag_database_text_search(hip, tmp_path):
     assert res2[0]["id"] == 10 and res2[0]["video"] == "v5.mp4"
     batch = db.text_search_batch(emb[:40], top_k=12, where=[f'video != "v{i // 2}.mp4"' for i in range(40)], select=["video"])
     assert len(batch) == 40 and all(len(b) == 12 for b in batch) and all(b[0]["video"] != f"v{i // 2}.mp4" for i, b in enumerate(batch))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="unsupported `where` filter"):
         db.text_search(text=q, where="start_sec > 3")
+    with pytest.raises(ValueError, match="unsupported `where` filter"):                     # refused before anything of the batch launches
+        db.text_search_batch(emb[:3], top_k=2, where=['video != "v0.mp4"', "id < 4", None])
+    assert db.text_search(text=q, top_k=2, where='video != "no such clip"')[0]["id"] == 10   # a name outside the table excludes nothing
+    tbl = db.text_search(text=q, top_k=5, output_format="pyarrow")
+    assert tbl.num_rows == 5 and tbl.column_names == list(rag.SCHEMA) + ["_distance"]
+    assert list(db.text_search(text=q, top_k=5, output_format="pandas")["id"])[0] == 10
+
+
+def test_rag_database_million_rows_memory_mapped(hip, tmp_path):
+    """the table the scan was measured at does not fit per-row Python objects: 10^6 rows x 128 fp32 written once, opened through a memory map,
+    uploaded in chunks, metadata read lazily from the mapped Arrow file; top-k rows and distances bit-equal to the C oracle, the self-exclusion
+    filter resolved through the dictionary-encoded `video` column"""
+    import pyarrow as pa
+    from motionrag_amd import rag
+    N, D = 1_000_000, 128
+    rng = np.random.default_rng(7)
+    tdir = tmp_path / "big.db" / "motion_caption"
+    os.makedirs(tdir)
+    vec = np.lib.format.open_memmap(tdir / "vectors.npy", mode="w+", dtype=np.float32, shape=(N, D))
+    for i in range(0, N, 100_000):
+        vec[i:i + 100_000] = rng.standard_normal((100_000, D), dtype=np.float32)
+    vec.flush()
+    ids = np.arange(N, dtype=np.int64)
+    videos = pa.array([f"v{i // 3}.mp4" for i in range(N)])
+    table = pa.table({"text": pa.array([""] * N), "id": pa.array(ids), "uid": pa.array([f"openvid/{i}" for i in range(N)]), "dataset": pa.array(["openvid"] * N),
+                      "video": videos, "start_sec": pa.array(np.zeros(N)), "end_sec": pa.array(np.full(N, 4.0))})
+    with pa.OSFile(str(tdir / "meta.arrow"), "wb") as sink, pa.ipc.new_file(sink, table.schema) as w:
+        w.write_table(table)
+    del table, videos
+    db = rag.RAGDatabase(str(tmp_path / "big.db"), "motion_caption", device="cuda")
+    assert len(db) == N and isinstance(db.vectors_host, np.memmap) and db.group.shape == (N,) and int(db.group[-1]) == (N - 1) // 3
+    q = np.asarray(vec[123_456]) + 0.01 * rng.standard_normal(D).astype(np.float32)
+    res = db.text_search(text=q, top_k=12, where='video != "v41152.mp4"', select=["id", "video"])          # 123 456 // 3 = 41 152: the query's own video
+    assert all(r["video"] != "v41152.mp4" for r in res) and len(res) == 12
+    from oracle import topk_ref
+    group = (np.arange(N) // 3).astype(np.int32)
+    want_r, want_d = topk_ref.topk(np.asarray(vec), q[None], 12, "l2", group, np.array([41152], np.int32))
+    assert [r["id"] for r in res] == [int(i) for i in want_r[0]]
+    np.testing.assert_array_equal(np.array([r["_distance"] for r in res], dtype=np.float32), want_d[0].astype(np.float32))
+    assert db.text_search(text=np.asarray(vec[999_999]), top_k=1)[0]["id"] == 999_999                      # the last chunk of the upload landed
 
 
 def test_svd_processor_accepts_tuple_tensor(hip):

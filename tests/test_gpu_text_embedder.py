@@ -1,6 +1,8 @@
 """The retrieval row's text embedder (gte-base-en-v1.5's NewModel: third-party remote code, parity UNPINNED) on the GPU against the fp32 restatement
 oracle/gte_ref.py: a reduced model at several unpadded lengths, the base configuration (12 x 768, 136.8 M parameters), the sentence embedder's length grouping,
 and the embedder plugged into RAGDatabase.text_search."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -67,3 +69,47 @@ def test_sentence_embedder_groups_by_length_and_feeds_text_search(hip, tmp_path)
     db = rag.RAGDatabase(str(tmp_path), "llm_caption", device="cuda", embedder=emb)
     hits = db.text_search("cut the onion", top_k=2)
     assert hits[0]["text"] == "cut the onion" and hits[0]["_distance"] < 1e-3
+
+
+def test_build_rag_database_from_a_local_gte_snapshot(hip, tmp_path):
+    """tools/build_rag_database.py --gte_dir (the reference's build path: captions embedded by the table's embedding function,
+    tools/build_rag_database.py:16-52 there): a synthetic local snapshot -- config.json, a random `model.safetensors` under the checkpoint's `new.`
+    key prefix, a WordPiece tokenizer saved by `transformers` -- is loaded, 300 synthetic captions are embedded on the GPU, written, and searched"""
+    import json
+    import subprocess
+    import sys
+    import safetensors.torch
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    from motionrag_amd import rag
+    from motionrag_amd.text_embedder import NewModel
+    snap = tmp_path / "gte"
+    os.makedirs(snap)
+    words = sorted({w for a in rag.synthetic_captions(300) for w in a["motion_caption"].replace(":", " : ").split()})
+    vocab = list(dict.fromkeys(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ":"] + words + [f"##{d}" for d in "0123456789"] + list("0123456789")))
+    tk = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))          # a BERT-style WordPiece tokenizer, as the checkpoint ships
+    tk.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tk.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tk.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+                            mask_token="[MASK]").save_pretrained(str(snap))
+    cfg = dict(vocab_size=len(vocab) + 7, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, layer_norm_eps=1e-12,
+               max_position_embeddings=512, rope_theta=500000.0, rope_scaling={"type": "ntk", "factor": 2.0})
+    with open(snap / "config.json", "w") as f:
+        json.dump(cfg, f)
+    torch.manual_seed(0)
+    model = NewModel(**{k: v for k, v in cfg.items() if k != "rope_scaling"}, rope_scaling_factor=2.0)
+    sd = {"new." + k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    sd["new.embeddings.position_ids"] = torch.arange(512)[None]                  # buffers of the published checkpoint that the loader must skip
+    sd["pooler.dense.weight"] = torch.zeros(4, 4)
+    safetensors.torch.save_file(sd, str(snap / "model.safetensors"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "build_rag_database.py"), "--db_path", str(tmp_path / "o.db"), "--n_synthetic", "300",
+                          "--gte_dir", str(snap)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = out.stdout.decode().strip().splitlines()[-1]
+    assert "300 rows x 128" in line and "all self-free: True" in line, line
+    db = rag.RAGDatabase(str(tmp_path / "o.db"), "motion_caption", device="cuda")
+    v = np.asarray(db.vectors_host)
+    np.testing.assert_allclose(np.linalg.norm(v, axis=1), 1.0, atol=2e-2)         # L2-normalised sentence embeddings (bf16 model, fp32 normalisation)
+    assert db.text_search(text=v[17], top_k=1)[0]["id"] == 17

@@ -18,10 +18,6 @@ for name, (B, H, S) in (("dit joint", (2, 48, 17776)), ("dc level0", (32, 5, 921
                 (ops.ATTN_TUNE_M32QB1, "attn32 32 rows/wave NW4 x3/CU"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16 (round-1 algorithm)"))
     if os.environ.get("AB_OLD16"):
         variants += ((ops.ATTN_TUNE_W4PF, "attn16 QB2 NW4 x4/CU"), (ops.ATTN_TUNE_W8PF, "attn16 QB2 NW8 x2/CU"))
-    if os.environ.get("AB_SUBS2"):
-        variants += ((ops.ATTN_TUNE_SUBS2, "attn16 QB2 128-key stages"),)
-    if os.environ.get("AB_QB4"):
-        variants += ((ops.ATTN_TUNE_QB4, "attn16 QB4 NW8"), (ops.ATTN_TUNE_QB4W4, "attn16 QB4 NW4"))
     res = {t: [] for t, _ in variants}
     for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         for tune, _ in variants:

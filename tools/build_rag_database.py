@@ -35,7 +35,16 @@ if __name__ == "__main__":
         import safetensors.torch
         from transformers import AutoTokenizer
         from motionrag_amd.text_embedder import NewModel, SentenceEmbedder
-        model = NewModel()
+        cfg = {}
+        if os.path.exists(os.path.join(args.gte_dir, "config.json")):      # the snapshot's own geometry (absent: the published gte-base-en-v1.5 one)
+            import json
+            with open(os.path.join(args.gte_dir, "config.json")) as f:
+                hf = json.load(f)
+            cfg = {k: hf[k] for k in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "layer_norm_eps",
+                                      "max_position_embeddings", "rope_theta") if k in hf}
+            if isinstance(hf.get("rope_scaling"), dict) and "factor" in hf["rope_scaling"]:
+                cfg["rope_scaling_factor"] = float(hf["rope_scaling"]["factor"])
+        model = NewModel(**cfg)
         sd = safetensors.torch.load_file(os.path.join(args.gte_dir, "model.safetensors"))
         model.load_state_dict({k[len("new."):] if k.startswith("new.") else k: v for k, v in sd.items() if "position_ids" not in k and not k.startswith("pooler")}, strict=True)
         tok = AutoTokenizer.from_pretrained(args.gte_dir)

@@ -15,8 +15,7 @@ _E = os.environ
 ops.TUNING["gemm"] = ((ops.GEMM_TUNE_NO_WIDE if _E.get("MRAG_GEMM_NO_WIDE") else 0) | (ops.GEMM_TUNE_NO_STAGED if _E.get("MRAG_GEMM_NO_STAGED") else 0)
                       | (ops.GEMM_TUNE_GEGLU_NO_STAGED if _E.get("MRAG_GEGLU_NO_STAGED") else 0) | (int(_E.get("MRAG_GEMM_CFG", "0")) << 4)
                       | (int(_E.get("MRAG_GEMM_GROUP_M", "0")) << 8))
-ops.TUNING["attn"] = ((ops.ATTN_TUNE_NO_TINY if _E.get("MRAG_ATTN_NO_TINY") else 0) | (ops.ATTN_TUNE_PIPE if _E.get("MRAG_ATTN_PIPE") == "1" else 0)
-                      | (ops.ATTN_TUNE_NW4 if _E.get("MRAG_ATTN_NW") == "4" else 0) | (ops.ATTN_TUNE_LEGACY if _E.get("MRAG_ATTN_LEGACY") else 0))
+ops.TUNING["attn"] = (ops.ATTN_TUNE_NO_TINY if _E.get("MRAG_ATTN_NO_TINY") else 0) | (ops.ATTN_TUNE_LEGACY if _E.get("MRAG_ATTN_LEGACY") else 0)
 ops.TUNING["attn_no_split"] = _E.get("MRAG_ATTN_KV_SPLITS") == "0"
 ops.TUNING["no_qkv_fuse"] = bool(_E.get("MRAG_NO_QKV_FUSE"))
 

@@ -75,7 +75,7 @@ struct TopkP {
   Cand* ws; int* out_rows; float* out_dist;
   long long n_rows; int dim, nq, k, metric, slices, rows_per_slice;
   unsigned* tickets;    // FUSED: one arrival counter per query tile (zero between calls)
-  int wpb;              // waves per workgroup: 4, or 1 for small databases (10 k rows = 157 one-wave workgroups instead of 40 four-wave ones)
+  int wpb;              // waves per workgroup: always 4 (small databases spread by giving each WAVE 16 rows instead of 64: small_db())
 };
 
 // Distance of one (query, row) pair = 16 interleaved fp32 fmaf chains + a fixed 4-level pairwise tree (the definition

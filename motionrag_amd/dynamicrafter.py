@@ -56,6 +56,12 @@ class _Cache:
 _CACHE = _Cache()
 
 
+def _tanh_scalar(p: torch.Tensor) -> float:
+    """tanh of a learnable scalar gate (attention.py:200-202, 216-218) as a host float, read back ONCE per weight version: a `.item()` per
+    attention call is a host sync per layer and cannot be captured in a HIP graph"""
+    return _CACHE.get(("tanh", id(p)), p, lambda: float(torch.tanh(p.detach().float()).item()))
+
+
 def conv3x3(x: torch.Tensor, conv: nn.Conv2d, *, stride: int = 1, upsample: bool = False, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [N, H, W, Cin] -> [N, Ho, Wo, Cout]: implicit GEMM over gathered rows; `resid` (same shape as the output) fused in the epilogue."""
     N, H, W, C = x.shape
@@ -182,12 +188,12 @@ class CrossAttention(nn.Module):
             out = ops.attention(q, k, v, kv_batch_div=Nb // k.shape[0])             # :189
             if self.image_cross_attention:                                          # :191-204
                 k, v = self._kv("kv_ip", self.to_k_ip, self.to_v_ip, context["image"])
-                s = self.image_cross_attention_scale * ((torch.tanh(self.alpha).item() + 1) if self.image_cross_attention_scale_learnable else 1.0)
+                s = self.image_cross_attention_scale * ((_tanh_scalar(self.alpha) + 1) if self.image_cross_attention_scale_learnable else 1.0)
                 ops.attention(q, k, v, out=out, resid=out, kv_batch_div=Nb // k.shape[0], out_scale=float(s))
             if self.action_cross_attention:                                         # :206-220  q_a = to_q_a(out)
                 q_a = ops.linear(out, self.to_q_a.weight).view(Nb, L, H, 64)
                 k, v = self._kv("kv_a", self.to_k_a, self.to_v_a, context["action"])
-                s = self.action_cross_attention_scale * ((torch.tanh(self.alpha_action).item() + 1) if self.action_cross_attention_scale_learnable else 1.0)
+                s = self.action_cross_attention_scale * ((_tanh_scalar(self.alpha_action) + 1) if self.action_cross_attention_scale_learnable else 1.0)
                 ops.attention(q_a, k, v, out=out, resid=out, kv_batch_div=Nb // k.shape[0], out_scale=float(s))
         if resid is not None:
             return ops.linear(out, self.to_out[0].weight, self.to_out[0].bias, epilogue=ops.EPI_RESID, resid=resid)

@@ -549,6 +549,8 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
     if exclude is not None:
         _dev(group, torch.int32, "group"); _dev(exclude, torch.int32, "exclude")
     ws = topk_workspace(db.device, N, Q)
+    if Q <= 4:
+        ws[:64].zero_()      # arrival counters of the single-launch form: re-zeroed on THIS call path (an aborted earlier launch cannot poison it); TopkPlan is the no-extra-launch path
     if out is None:
         rows = torch.empty(Q, k, dtype=torch.int32, device=db.device)
         dist = torch.empty(Q, k, dtype=torch.float32, device=db.device)

@@ -142,12 +142,14 @@ class RAGDatabase:
         # datamodule.py:235 compares ids in the kernel): one dictionary encoding of ONE column, no per-row Python objects
         enc = pc.dictionary_encode(self.meta.column("video").combine_chunks() if self.meta.num_rows else pa.array([], pa.string()))
         self._videos = enc.dictionary
-        self.group = torch.from_numpy(np.ascontiguousarray(enc.indices.to_numpy(zero_copy_only=False), dtype=np.int32)).to(self.device)
+        self.group = torch.from_numpy(np.array(enc.indices.to_numpy(zero_copy_only=False), dtype=np.int32)).to(self.device)     # np.array: a writable copy
         self.vectors = torch.empty(N, D, dtype=torch.float32, device=self.device)          # resident in HBM for every search
         step = max(1, UPLOAD_CHUNK_BYTES // (4 * D))
         for i in range(0, N, step):                                                        # chunked: the host side is the page cache of the mapped file
             self.vectors[i:i + step].copy_(torch.from_numpy(np.ascontiguousarray(self.vectors_host[i:i + step])))
         self._plans = {}
+        import threading
+        self._lock = threading.Lock()
 
     def __len__(self):
         return self.meta.num_rows
@@ -224,15 +226,21 @@ class RAGDatabase:
             exclude = torch.tensor(self._exclude_ids(where), dtype=torch.int32, device=self.device)       # every filter parsed BEFORE anything launches
             group = self.group
         if Q <= 4 and top_k <= 64:       # the interactive search (rag.py:63-80): a prepared plan -- one C-ABI call = one launch, no allocation
-            plan = self._plans.get((Q, top_k))
-            if plan is None:
-                plan = self._plans[(Q, top_k)] = ops.TopkPlan(self.vectors, Q, top_k, metric=self.metric, group=self.group)
-            plan.queries.copy_(q)
-            if exclude is not None:
-                plan.exclude.copy_(exclude)
-            else:
-                plan.exclude.fill_(-1)
-            rows, dist = plan.run()
+            # a plan owns its workspace, arrival counters included: one per (Q, k, STREAM) so that searches issued from different streams never share
+            # counters, and a lock so that two host threads on one stream cannot interleave the copy-in / launch / read-out of one plan
+            key = (Q, top_k, torch.cuda.current_stream(self.device).cuda_stream)
+            with self._lock:
+                plan = self._plans.get(key)
+                if plan is None:
+                    plan = self._plans[key] = ops.TopkPlan(self.vectors, Q, top_k, metric=self.metric, group=self.group)
+                plan.queries.copy_(q)
+                if exclude is not None:
+                    plan.exclude.copy_(exclude)
+                else:
+                    plan.exclude.fill_(-1)
+                rows, dist = plan.run()
+                rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+            return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
         else:
             rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()

@@ -190,6 +190,48 @@ def test_svd_processor_dropin(hip):
     close(got, want)
 
 
+def test_dc_cross_attention_learnable_scale_gate(hip):
+    """lvdm/modules/attention.py:200-202, 216-218: `scale * (tanh(alpha) + 1)` on the image / motion branches (upstream DynamiCrafter-1024 checkpoints set
+    it; the shipped MotionRAG config leaves it off).  The gate is a host scalar cached per weight version: the learnable form equals the fixed-scale form
+    at the same effective scale, follows an in-place update of alpha, and issues no host sync once cached (the call is HIP-graph capturable)"""
+    from motionrag_amd import dynamicrafter as dc
+    g = torch.Generator().manual_seed(24)
+    C, H, cd = 320, 5, 1024
+
+    def build(learn, s_img, s_act):
+        m = dc.CrossAttention(C, context_dim=cd, heads=H, dim_head=64, image_cross_attention=True, image_cross_attention_scale=s_img,
+                              image_cross_attention_scale_learnable=learn, action_cross_attention=True, action_cross_attention_scale=s_act,
+                              action_cross_attention_scale_learnable=learn)
+        gg = torch.Generator().manual_seed(25)
+        for n, p in m.named_parameters():
+            if p.dim() > 0:
+                torch.nn.init.normal_(p, std=0.05, generator=gg)
+        return m.to(DEV, torch.bfloat16)
+    x = torch.randn(4, 144, C, generator=g).to(DEV, torch.bfloat16)
+    ctx = {"prompt": torch.randn(4, 77, cd, generator=g).to(DEV, torch.bfloat16), "image": torch.randn(4, 16, cd, generator=g).to(DEV, torch.bfloat16),
+           "action": torch.randn(4, 25, cd, generator=g).to(DEV, torch.bfloat16)}
+    learn = build(True, 0.7, 1.3)
+    with torch.no_grad():
+        learn.alpha.fill_(0.3); learn.alpha_action.fill_(-0.5)
+    t_img = float(torch.tanh(learn.alpha.float()).item()) + 1.0            # the reference's `.item()` arithmetic, alpha as the bf16 parameter holds it
+    t_act = float(torch.tanh(learn.alpha_action.float()).item()) + 1.0
+    got = learn(x, ctx)
+    want = build(False, 0.7 * t_img, 1.3 * t_act)(x, ctx)
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        learn.alpha.fill_(-2.0)                                              # in-place update (what load_state_dict does): the cached scalar must follow
+    got2 = learn(x, ctx)
+    want2 = build(False, 0.7 * (float(torch.tanh(learn.alpha.float()).item()) + 1.0), 1.3 * t_act)(x, ctx)
+    assert torch.equal(got2, want2) and not torch.equal(got2, got)
+    graph = torch.cuda.HIPGraph() if hasattr(torch.cuda, "HIPGraph") else torch.cuda.CUDAGraph()
+    out = learn(x, ctx)                                                     # warm: scalars cached, workspaces sized
+    with torch.cuda.graph(graph):
+        out = learn(x, ctx)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, got2)
+
+
 def _small_dit(seed=31, layers=2):
     from motionrag_amd.cogvideox import CogVideoXTransformer3DModel
     from oracle import cogvideox_ref

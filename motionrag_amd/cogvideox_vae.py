@@ -160,6 +160,50 @@ _DOUBLING: Dict = {}
 _STREAMS: Dict = {}
 
 
+def concurrent_streams(device, n: int, candidates: int = 8) -> List["torch.cuda.Stream"]:
+    """`n` HIP streams that really run side by side.  The runtime maps a process's streams onto a few hardware queues (round robin at creation), and two
+    streams on one queue serialise: the same tiled decode measured 603-608 ms, 650 ms or 720 ms depending only on how many streams the process had created
+    before (profiles/r3_vae_queue_probe.txt; 597 ms standalone against 722 ms inside bench.py in round 2).  So the pool is PROBED once per process: a
+    one-workgroup spin kernel (`torch.cuda._sleep`, ~0.3 ms) on two streams takes one spin if they overlap and two if they share a queue; candidates are kept
+    while they overlap every stream already chosen.  Falls back to the first `n` candidates when the probe finds no such set."""
+    dev = torch.device(device)
+    cand = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, n))]
+    spin = 600_000                                                            # cycles: a few tenths of a millisecond, far above launch jitter
+
+    def pair_ms(a, b) -> float:
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream(dev)
+        e0.record(cur)
+        for st in (a, b):
+            st.wait_event(e0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin)
+            cur.wait_stream(st)
+        e1.record(cur)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    try:
+        pair_ms(cand[0], cand[1])                                             # warm-up (clock ramp, first-launch costs)
+        m = len(cand)
+        t = {(i, j): pair_ms(cand[i], cand[j]) for i in range(m) for j in range(i + 1, m)}
+        best = min(t.values())                                                # two streams on different queues: one spin; on the same queue: two (bimodal)
+        ok = lambda i, j: t[(min(i, j), max(i, j))] < 1.4 * best
+        for first in range(m):                                                # greedy clique of mutually overlapping streams
+            chosen = [first]
+            for c in range(m):
+                if len(chosen) == n:
+                    break
+                if c not in chosen and all(ok(c, k) for k in chosen):
+                    chosen.append(c)
+            if len(chosen) == n:
+                return [cand[i] for i in chosen]
+    except (RuntimeError, AttributeError):                                   # no spin helper on this build: take them as they come
+        pass
+    return cand[:n]
+
+
 def _frame_doubling(T: int, device) -> torch.Tensor:
     """source frame of every output frame of the temporal nearest x2 (T odd: the first frame stays single)"""
     key = (T, str(device))
@@ -359,7 +403,7 @@ class AutoencoderKLCogVideoX(nn.Module):
             self._warm(net)
             key = (str(x.device), n)
             if key not in _STREAMS:
-                _STREAMS[key] = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+                _STREAMS[key] = concurrent_streams(x.device, n)
             for k, (i, j) in enumerate(origins):
                 side = _STREAMS[key][k % n]
                 side.wait_stream(cur)

@@ -19,9 +19,9 @@ for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_W
             if r["Counter_Name"] != c:
                 continue
             n = r["Kernel_Name"]
-            if "attn16_kernel<3, 4, 1, 3, false," in n:
-                key = "attn16_kernel<3,4,1,3,false,true> B=2 H=48 S=17776"
-            elif "gemm_bf16_kernel<2, 4, 8, 4, 0, 0>" in n and r["Grid_Size"] == "2562048":
+            if "attn16_kernel<3, 4, 3," in n:
+                key = "attn16_kernel<3,4,3,true> B=2 H=48 S=17776"
+            elif "gemm_bf16_kernel<2, 4, 8, 4, 0, 0, false>" in n and r["Grid_Size"] == "2562048":
                 key = "gemm_bf16_kernel<2,4,8,4,NONE> M=35552 N=9216 K=3072"
             else:
                 continue

@@ -8,6 +8,8 @@ class's state-dict keys (`vision_model.embeddings.{class_embedding, patch_embedd
 Head dim 80 is outside the flash kernels (built for 64): the attention of this once-per-clip encoder runs on `mrag_attn_small_bf16` (K / V of a head resident in LDS,
 fp32 FMAs); a tower with head_dim 64 (CLIP-L) takes the flash kernel.  Everything else is the ViT path of motionrag_amd/encoders.py: pixel rows -> patch GEMM ->
 token assembly -> LayerNorm / fused QKV GEMM / attention / output and MLP GEMMs with the residuals in their epilogues."""
+from typing import Optional
+
 import torch
 from torch import nn
 
@@ -53,7 +55,7 @@ class CLIPVisionModelWithProjection(nn.Module):
         self.head_dim = hidden_size // num_attention_heads
         if self.head_dim not in (32, 64, 80, 96, 128) or self.head_dim * num_attention_heads != hidden_size:
             raise NotImplementedError(f"head_dim {self.head_dim}: no attention kernel")
-        self.hidden_size, self.heads, self.patch_size, self.eps = hidden_size, num_attention_heads, patch_size, layer_norm_eps
+        self.hidden_size, self.heads, self.patch_size, self.eps, self.image_size = hidden_size, num_attention_heads, patch_size, layer_norm_eps, image_size
         n_pos = (image_size // patch_size) ** 2 + 1
         vm = self.vision_model = _H()
         vm.embeddings = _H()
@@ -70,15 +72,40 @@ class CLIPVisionModelWithProjection(nn.Module):
     def forward(self, pixel_values: torch.Tensor, **_unused) -> CLIPVisionOutput:
         """already-normalised `pixel_values` [B, 3, H, W] (the feature extractor's output) -> `.image_embeds` [B, projection_dim], `.last_hidden_state`"""
         vm = self.vision_model
-        layers = []
-        for L in vm.encoder.layers:
+        layers = self._layers()
+        x = _tower(pixel_values, vm.embeddings.patch_embedding, vm.embeddings.class_embedding, vm.embeddings.position_embedding.weight, vm.pre_layrnorm, layers,
+                   self.heads, self.head_dim, self.patch_size, self.eps, id(self))
+        pooled = ops.layernorm(x[:, 0].contiguous(), _b(vm.post_layernorm.weight), _b(vm.post_layernorm.bias), self.eps)
+        return CLIPVisionOutput(ops.linear(pooled, _b(self.visual_projection.weight)), x)
+
+
+    MEAN, STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+    def _layers(self):
+        out = []
+        for L in self.vision_model.encoder.layers:
             sa = L.self_attn
             w, b = _CACHE.get(("clip_qkv", id(sa)), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight, sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias),
                               lambda: (torch.cat([_b(sa.q_proj.weight), _b(sa.k_proj.weight), _b(sa.v_proj.weight)], 0).contiguous(),
                                        torch.cat([_b(sa.q_proj.bias), _b(sa.k_proj.bias), _b(sa.v_proj.bias)], 0).contiguous()))
-            layers.append((L.layer_norm1, w, b, sa.out_proj, L.layer_norm2, L.mlp.fc1, L.mlp.fc2))
-        x = _tower(pixel_values, vm.embeddings.patch_embedding, vm.embeddings.class_embedding, vm.embeddings.position_embedding.weight, vm.pre_layrnorm, layers,
-                   self.heads, self.head_dim, self.patch_size, self.eps, id(self))
+            out.append((L.layer_norm1, w, b, sa.out_proj, L.layer_norm2, L.mlp.fc1, L.mlp.fc2))
+        return out
+
+    @torch.no_grad()
+    def encode_image(self, image_pm1: torch.Tensor, size: Optional[int] = None) -> CLIPVisionOutput:
+        """raw image [B, 3, H, W] in [-1, 1] -> `.image_embeds`: the front half of diffusers' `StableVideoDiffusionPipeline._encode_image` in one pass --
+        `_resize_with_antialiasing(image, (224, 224))` (the kornia recipe: Gaussian blur with skimage's sigma rule and a reflect border, then align_corners bicubic),
+        `(x + 1) / 2`, the feature extractor's CLIP mean / std -- as the fused pixel kernel's `kornia-bicubic` mode (encoders.kornia_resize_taps folds blur and
+        interpolation into one tap table per axis; oracle/kornia_resize_ref.py, parity unpinned), written straight as patch-GEMM rows, then the tower."""
+        if not image_pm1.is_cuda:
+            raise ops.HipOnly("CLIP vision tower: GPU tensors only")
+        vm = self.vision_model
+        size = self.image_size if size is None else size
+        B = image_pm1.shape[0]
+        rows = pixels_to_patch_rows(image_pm1[:, None].contiguous(), resize=size, crop=size, mode="kornia-bicubic", patch=(1, self.patch_size, self.patch_size),
+                                    mean=self.MEAN, std=self.STD)
+        x = _tower_from_rows(rows, B, size // self.patch_size, vm.embeddings.patch_embedding, vm.embeddings.class_embedding, vm.embeddings.position_embedding.weight,
+                             vm.pre_layrnorm, self._layers(), self.heads, self.head_dim, self.eps, id(self))
         pooled = ops.layernorm(x[:, 0].contiguous(), _b(vm.post_layernorm.weight), _b(vm.post_layernorm.bias), self.eps)
         return CLIPVisionOutput(ops.linear(pooled, _b(self.visual_projection.weight)), x)
 

@@ -113,7 +113,7 @@ class RAGDatabase:
 
     def __init__(self, db_path: str, table_name: str, device: str = "cuda", metric: str = "l2", embedder: Optional[Callable] = None):
         tdir = os.path.join(db_path, table_name)
-        self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"), mmap_mode="r")      # a view of the file: pages stream through on upload
+        self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"), mmap_mode="c")      # a copy-on-write view of the file (never written): pages stream through on upload
         self.meta = _read_meta(tdir)
         self._init_device(device, metric, embedder)
 

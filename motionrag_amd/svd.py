@@ -88,12 +88,17 @@ class SVDActionPipeline:
 
     # ---- diffusers StableVideoDiffusionPipeline pieces ----
     def _encode_image_base(self, image_pm1: torch.Tensor, device, do_classifier_free_guidance: bool) -> torch.Tensor:
-        """diffusers `_encode_image`: CLIP image embedding [b, 1, 1024]; CFG: cat([zeros, emb]).  The 224x224 antialiased resize + CLIP
-        normalisation are the feature extractor's job (third-party); a `feature_extractor(images=...)` callable is used when given."""
-        x = image_pm1
-        if self.feature_extractor is not None:
-            x = self.feature_extractor(x)
-        emb = self.image_encoder(x.to(device))
+        """diffusers `_encode_image`: CLIP image embedding [b, 1, 1024]; CFG: cat([zeros, emb]).  With the native `clip_vision` tower and no
+        `feature_extractor`, the 224 x 224 antialiased resize + `(x + 1) / 2` + CLIP normalisation run in the tower's fused pixel kernel; a
+        `feature_extractor(images)` callable (any other encoder) gets the [-1, 1] image as before."""
+        if self.feature_extractor is None and hasattr(self.image_encoder, "encode_image"):
+            # the native tower does diffusers' antialiased 224 x 224 resize + (x + 1) / 2 + CLIP normalisation itself (clip_vision.encode_image)
+            emb = self.image_encoder.encode_image(image_pm1.to(device, torch.bfloat16))
+        else:
+            x = image_pm1
+            if self.feature_extractor is not None:
+                x = self.feature_extractor(x)
+            emb = self.image_encoder(x.to(device))
         emb = getattr(emb, "image_embeds", emb)
         emb = emb.unsqueeze(1) if emb.dim() == 2 else emb
         if do_classifier_free_guidance:
@@ -130,15 +135,19 @@ class SVDActionPipeline:
         img = self._image_tensor(image)                                                      # [-1, 1]
         b = img.shape[0]
         ehs = self._encode_image(img, dev, True).to(dev, torch.bfloat16)
-        noise = torch.randn(img.shape, generator=generator, dtype=torch.float32)            # CPU-seeded
-        img_aug = img + noise_aug_strength * noise
+        # diffusers draws both noises with randn_tensor(shape, generator, device, dtype): IN the pipeline dtype (bf16: the reference's VideoProcessorDtype casts the
+        # preprocessed image to vae.dtype, svd/pipelines/pipeline.py:16-22) on the generator's device (a CPU generator by default), and adds in that dtype
+        gdev = generator.device if generator is not None else torch.device("cpu")
+        img_bf = img.to(gdev, torch.bfloat16)
+        noise = torch.randn(img.shape, generator=generator, dtype=torch.bfloat16, device=gdev)
+        img_aug = img_bf + noise_aug_strength * noise
         z = self.vae.encode(img_aug.to(dev))
         z = z.latent_dist.mode() if hasattr(z, "latent_dist") else z                        # [b, 4, h, w] (NOT scaled: diffusers keeps the raw mode)
         image_latents = torch.cat([torch.zeros_like(z), z], dim=0)[:, None].expand(-1, num_frames, -1, -1, -1)
         added = torch.tensor([[float(fps - 1), float(motion_bucket_id), float(noise_aug_strength)]] * (2 * b), device=dev)
         self.scheduler.set_timesteps(num_inference_steps)
         if latents is None:
-            latents = torch.randn(b, num_frames, 4, height // 8, width // 8, generator=generator, dtype=torch.float32) * self.scheduler.init_noise_sigma
+            latents = torch.randn(b, num_frames, 4, height // 8, width // 8, generator=generator, dtype=torch.bfloat16, device=gdev) * self.scheduler.init_noise_sigma
         latents = latents.to(dev, torch.bfloat16).contiguous()
         guidance = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames, device=dev)
         latents = self._denoise(latents, image_latents.to(dev, torch.bfloat16).contiguous(), ehs, added, num_inference_steps, guidance)

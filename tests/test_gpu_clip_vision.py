@@ -68,6 +68,30 @@ def test_clip_vit_h_width_vs_oracle(hip):
     assert rel(out.last_hidden_state, want_last) <= 2e-2 and rel(out.image_embeds, want_emb) <= 2e-2
 
 
+def test_clip_encode_image_is_resize_normalise_then_forward(hip):
+    """`encode_image` = diffusers' SVD `_encode_image` front half -- antialiased 224 x 224 resize of the [-1, 1] image (the kornia recipe the package copied),
+    `(x + 1) / 2`, CLIP mean / std -- fused into the tower's pixel kernel: equal to the tower's `forward` on the oracle's preprocessed pixels, at the SVD
+    resolution; and the SVD pipeline takes this path when it is given no feature extractor"""
+    from motionrag_amd import clip_vision as C
+    from motionrag_amd import svd
+    from oracle import kornia_resize_ref as K
+    torch.manual_seed(19)
+    m = C.CLIPVisionModelWithProjection(num_hidden_layers=2)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "position_embedding" in n or "class_embedding" in n:
+                p.normal_(0.0, 0.02)
+    m = m.to(DEV, torch.bfloat16)
+    img = (torch.rand(2, 3, 576, 1024) * 2 - 1).to(torch.bfloat16)
+    got = m.encode_image(img.to(DEV))
+    want = m(K.preprocess(img.float(), True).to(DEV, torch.bfloat16))                  # oracle pixels -> the same tower
+    assert got.image_embeds.shape == (2, 1024) and rel(got.image_embeds, want.image_embeds.float().cpu()) <= 2e-2
+    assert rel(got.last_hidden_state, want.last_hidden_state.float().cpu()) <= 2e-2
+    pipe = svd.StableVideoDiffusionPipeline(vae=None, image_encoder=m, unet=torch.nn.Linear(1, 1).to(DEV), scheduler=None, feature_extractor=None)
+    emb = pipe._encode_image_base(img.float(), DEV, True)
+    assert emb.shape == (4, 1, 1024) and torch.all(emb[:2] == 0) and torch.equal(emb[2:, 0], got.image_embeds)
+
+
 def _hf_to_openclip_visual(sd, layers):
     out = {"conv1.weight": sd["vision_model.embeddings.patch_embedding.weight"], "class_embedding": sd["vision_model.embeddings.class_embedding"],
            "positional_embedding": sd["vision_model.embeddings.position_embedding.weight"], "ln_pre.weight": sd["vision_model.pre_layrnorm.weight"],

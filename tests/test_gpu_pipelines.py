@@ -212,13 +212,13 @@ def test_svd_ct_pipeline_matches_oracle_loop(hip):
     # ---- oracle loop on the same random stream
     gen = torch.Generator().manual_seed(9)
     img = img255 / 127.5 - 1.0
-    noise = torch.randn(img.shape, generator=gen)
+    noise = torch.randn(img.shape, generator=gen, dtype=torch.bfloat16)                    # randn_tensor draws IN the pipeline dtype
     sig = svd_ref.karras_sigmas(2)
-    lat = (torch.randn(b, Fr, 4, h, w, generator=gen) * float((sig[0] ** 2 + 1) ** 0.5)).to(torch.bfloat16).float()
+    lat = (torch.randn(b, Fr, 4, h, w, generator=gen, dtype=torch.bfloat16) * float((sig[0] ** 2 + 1) ** 0.5)).float()
     emb = ImgEnc()(img).float().unsqueeze(1)
     emb2 = torch.cat([torch.zeros_like(emb), emb])
     act = cama.predict({"ref_videos": ref_videos, "video": img[:, None].expand(-1, 8, -1, -1, -1).to(DEV, torch.bfloat16)}, True).float().cpu()
-    z = VAE().encode((img + 0.02 * noise)).to(torch.bfloat16).float()
+    z = VAE().encode((img.to(torch.bfloat16) + 0.02 * noise)).to(torch.bfloat16).float()   # the noise-augmented image is formed in bf16
     il = torch.cat([torch.zeros_like(z), z])[:, None].expand(-1, Fr, -1, -1, -1)
     ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
     gs = torch.linspace(1.0, 3.0, Fr)
@@ -474,12 +474,12 @@ def test_svd_baseline_pipeline_without_motion_injection(hip):
     got = pipe(image=img255, output_type="latent", generator=torch.Generator().manual_seed(9), **kw).frames
     gen = torch.Generator().manual_seed(9)
     img = img255 / 127.5 - 1.0
-    noise = torch.randn(img.shape, generator=gen)
+    noise = torch.randn(img.shape, generator=gen, dtype=torch.bfloat16)                    # randn_tensor draws IN the pipeline dtype
     sig = svd_ref.karras_sigmas(2)
-    lat = (torch.randn(b, Fr, 4, h, w, generator=gen) * float((sig[0] ** 2 + 1) ** 0.5)).to(torch.bfloat16).float()
+    lat = (torch.randn(b, Fr, 4, h, w, generator=gen, dtype=torch.bfloat16) * float((sig[0] ** 2 + 1) ** 0.5)).float()
     emb = ImgEnc()(img).float().unsqueeze(1)
     emb2 = torch.cat([torch.zeros_like(emb), emb])
-    z = VAE().encode((img + 0.02 * noise)).to(torch.bfloat16).float()
+    z = VAE().encode((img.to(torch.bfloat16) + 0.02 * noise)).to(torch.bfloat16).float()   # the noise-augmented image is formed in bf16
     il = torch.cat([torch.zeros_like(z), z])[:, None].expand(-1, Fr, -1, -1, -1)
     ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
     gs = torch.linspace(1.0, 3.0, Fr)

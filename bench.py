@@ -108,21 +108,22 @@ def _usable_cores() -> int:
 
 def cpu_baseline_sample():
     """fp32 oracle (oracle/cogvideox_ref.py) on the host cores, BASELINE.md section 3's protocol: every core, fp32, ONE real warm-up (same size) and the
-    median of FIVE runs (three if a run takes longer than 6 s), on a sample sized so that the runs take ~20-30 s -- ONE of 42 layers, ONE of the 2 CFG samples, 1 of 13 latent frames
-    (S = 226 + 1350) -- extrapolated to the full step by algorithmic FLOPs."""
+    median of FIVE runs (three if a run takes longer than 6 s), on a sample sized so that the runs take 10-30 s together on the GPU box's host share (16 cores: ~2 s per run) --
+    ONE of 42 layers, ONE of the 2 CFG samples, 4 of 13 latent frames (S = 226 + 5400) -- extrapolated to the full step by algorithmic FLOPs."""
     import platform
     import statistics
     from oracle import cogvideox_ref as R
     cores = _usable_cores()
     torch.set_num_threads(cores)
-    cfg = R.DiTConfig(num_layers=1, frames=1)
+    FR = 4
+    cfg = R.DiTConfig(num_layers=1, frames=FR)
     sd = {k: v for k, v in R.random_dit_sd(cfg, seed=0).items() if k.startswith("transformer_blocks.0.")}
     sd = {k[len("transformer_blocks.0."):]: v for k, v in sd.items()}
     g = torch.Generator().manual_seed(0)
     S = cfg.video_tokens
     h, e = torch.randn(1, S, cfg.dim, generator=g), torch.randn(1, 226, cfg.dim, generator=g)
     temb, ip = torch.randn(1, 512, generator=g), torch.randn(1, 25, 1024, generator=g)
-    rope = R.rope_3d(64, 1, 30, 45)
+    rope = R.rope_3d(64, FR, 30, 45)
     runs = []
     with torch.no_grad():
         for i in range(6):
@@ -141,7 +142,7 @@ def cpu_baseline_sample():
             cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu)
     except OSError:
         pass
-    return dt, flops_sample, cores, (f"1/42 layers x 1/2 CFG samples x 1/13 latent frames (S={St}), fp32 oracle, 1 warm-up + median of {len(runs)} runs "
+    return dt, flops_sample, cores, (f"1/42 layers x 1/2 CFG samples x {FR}/13 latent frames (S={St}), fp32 oracle, 1 warm-up + median of {len(runs)} runs "
                               f"(min {min(runs):.2f} s, max {max(runs):.2f} s), extrapolated by FLOPs; {cpu}")
 
 

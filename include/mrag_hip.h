@@ -103,7 +103,8 @@ typedef struct mrag_gemm_args {
                               K order by the last arriver (bit-reproducible run to run; differs from the plain launch by fp32 summation
                               order only).  OPT-IN: measured slower than the partial round on MI355X               */
 } mrag_gemm_args;
-enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8 };
+enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8,
+       MRAG_GEMM_TUNE_NO_W4 = 1 << 16 /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */ };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */

@@ -12,6 +12,7 @@
 //   * operands swapped in the MFMA (W fragment as A-operand) so each lane owns 4 consecutive
 //     output columns of one row -> 8-byte bf16 stores and a lane-local fused epilogue;
 //   * 1-D grid with a bijective XCD remap so tiles that share an A row-panel sit on one L2.
+#include <type_traits>
 #include "common.h"
 #include "../../include/mrag_hip.h"
 
@@ -92,6 +93,67 @@ __device__ __forceinline__ float epi_act(float v) {
   else if constexpr (EPI == MRAG_EPI_GELU_ERF) return gelu_erf_f(v);
   else if constexpr (EPI == MRAG_EPI_SILU) return silu_f(v);
   else return v;
+}
+
+// ---- direct epilogue (accumulator layout): lane owns row m = .. + (lane & 15), columns n0 + (lane >> 4) * 4 + {0..3} of every 16x16 tile; 8-byte stores.
+// Same rounding points as the LDS-staged epilogue (so a GEMM gives the same bits whichever tile configuration its size selects).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4 (&acc)[TM][TN], const long long bm0, const long long bn0, const int wrow0, const int wcol0, const int lane) {
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  long long wg_b = 0, wg_pos = 0;
+  if constexpr (EPI == MRAG_EPI_GATE_RESID) {
+    wg_b = bm0 / p.rows_per_batch;
+    wg_pos = bm0 - wg_b * p.rows_per_batch;
+  }
+  auto row_bp = [&](long long m, long long& b, long long& pos) {
+    b = wg_b; pos = wg_pos + (m - bm0);
+    while (pos >= p.rows_per_batch) { pos -= p.rows_per_batch; ++b; }
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = bm0 + wrow0 + i * 16 + frag_row;
+    if (m >= p.M) continue;
+    const bf16_t* gate = nullptr;
+    if constexpr (EPI == MRAG_EPI_GATE_RESID) {
+      long long b, pos;
+      row_bp(m, b, pos);
+      gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long long n = bn0 + wcol0 + j * 16 + frag_q * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+        const u32x2 bb = *(const u32x2*)(p.bias + n);
+        v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+        v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+      if constexpr (EPI == MRAG_EPI_GATE_RESID) {
+        const u32x2 gg = *(const u32x2*)(gate + n);
+        v[0] *= __uint_as_float(gg[0] << 16); v[1] *= __uint_as_float(gg[0] & 0xffff0000u);
+        v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
+      }
+      if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+      }
+      if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
+        // the same rounding points as the LDS-staged epilogue above and as the reference's bf16 tensors (`x + gate * linear(.)`: the gated
+        // projection is a bf16 tensor before the residual add) -- so a GEMM gives the same bits whichever tile configuration its size selects
+        // (a sequence-sharded rank runs smaller problems than the unsharded model)
+        const u32x2 rr = *(const u32x2*)(p.resid + m * p.ldr + n);
+        v[0] = bf_round(v[0]) + __uint_as_float(rr[0] << 16); v[1] = bf_round(v[1]) + __uint_as_float(rr[0] & 0xffff0000u);
+        v[2] = bf_round(v[2]) + __uint_as_float(rr[1] << 16); v[3] = bf_round(v[3]) + __uint_as_float(rr[1] & 0xffff0000u);
+      }
+      u32x2 out;
+      out[0] = pack_bf2(v[0], v[1]);
+      out[1] = pack_bf2(v[2], v[3]);
+      *(u32x2*)(p.C + m * p.ldc + n) = out;
+    }
+  }
 }
 
 // One output tile (SK: one run of K-tiles [kt0, kt0 + nk) of it).  `wg` = the tile's index in the logical order.
@@ -714,51 +776,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long long m = bm0 + wm * TM * 16 + i * 16 + frag_row;
-    if (m >= p.M) continue;
-    const bf16_t* gate = nullptr;
-    if constexpr (EPI == MRAG_EPI_GATE_RESID) {
-      long long b, pos;
-      row_bp(m, b, pos);
-      gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const long long n = bn0 + wn * TN * 16 + j * 16 + frag_q * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const u32x2 bb = *(const u32x2*)(p.bias + n);
-        v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-        v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
-      if constexpr (EPI == MRAG_EPI_GATE_RESID) {
-        const u32x2 gg = *(const u32x2*)(gate + n);
-        v[0] *= __uint_as_float(gg[0] << 16); v[1] *= __uint_as_float(gg[0] & 0xffff0000u);
-        v[2] *= __uint_as_float(gg[1] << 16); v[3] *= __uint_as_float(gg[1] & 0xffff0000u);
-      }
-      if constexpr (EPI == MRAG_EPI_RESID) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
-      }
-      if constexpr (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID) {
-        // the same rounding points as the LDS-staged epilogue above and as the reference's bf16 tensors (`x + gate * linear(.)`: the gated
-        // projection is a bf16 tensor before the residual add) -- so a GEMM gives the same bits whichever tile configuration its size selects
-        // (a sequence-sharded rank runs smaller problems than the unsharded model)
-        const u32x2 rr = *(const u32x2*)(p.resid + m * p.ldr + n);
-        v[0] = bf_round(v[0]) + __uint_as_float(rr[0] << 16); v[1] = bf_round(v[1]) + __uint_as_float(rr[0] & 0xffff0000u);
-        v[2] = bf_round(v[2]) + __uint_as_float(rr[1] << 16); v[3] = bf_round(v[3]) + __uint_as_float(rr[1] & 0xffff0000u);
-      }
-      u32x2 out;
-      out[0] = pack_bf2(v[0], v[1]);
-      out[1] = pack_bf2(v[2], v[3]);
-      *(u32x2*)(p.C + m * p.ldc + n) = out;
-    }
-  }
+  epilogue_direct<TM, TN, EPI>(p, acc, bm0, bn0, wm * TM * 16, wn * TN * 16, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, int CONV = 0, bool SK = false>
@@ -823,6 +841,367 @@ inline SkPlan plan_streamk(long long M, long long N, long long K) {
   pl.bytes = SK_TICKET_BYTES + (size_t)rem * pl.maxparts * 256 * 256 * sizeof(float);
   pl.use = true;
   return pl;
+}
+
+// ---- the four-wave kernel's epilogue: 128x128 per wave.
+// Fast path (the wave's 128 x 128 outputs all inside the matrix, 16-byte aligned rows, one gate vector for the whole wave tile -- every tile of the DiT but
+// the last row of tiles): sixteen rows at a time go from the accumulator layout (lane: row (lane & 15), columns (lane >> 4) * 4 + {0..3} of every 16x16
+// tile) through two PRIVATE 4-KB LDS buffers of the wave (the 32 KB the operand stages leave free -- those hold the NEXT tile's first two K-tiles by now;
+// 16 rows x 256 B, 16-byte chunk c of row r at ((c ^ r) * 16): the 8-byte writes and the 16-byte reads both spread over every bank) into the row layout
+// (lane: row (lane >> 4) of four, chunk (lane & 15)) and leave as whole 256-byte row segments -- 32 sixteen-byte stores per lane instead of 64 eight-byte
+// pieces of sixteen rows each (direct form: 20 k cycles per tile; every CU of a round stores at the same time and the L2s take a 32-byte partial-line write
+// as a transaction of its own).  No predication, no 64-bit multiplies (pointers step by scalar multiples of the leading dimension), no barrier (the
+// buffers are the wave's own; row group i is written while i - 1 is read back).  vmcnt is one in-order counter: the residual vectors of row group i + 1 are
+// requested BEFORE the stores of i - 1, so waiting for them never waits for a store.  Bias, activation, gate, the bf16 rounding and the residual add happen
+// in the accumulator layout: the rounding points of the other epilogues (bit-equal results).
+// General path (edge tiles, a sample or text / video boundary inside the wave's rows, unaligned C): 8-byte predicated stores from the accumulator layout.
+template <int EPI>
+__device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&acc)[8][8], const long long bm0, const long long bn0, const int wave, const int wrow0,
+                                            const int wcol0, const int lane_in) {
+  constexpr bool HAS_R = (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID), HAS_G = (EPI == MRAG_EPI_GATE_RESID);
+  // the lane id is laundered through an empty asm: everything below that depends on the lane only (LDS addresses, column offsets, row pointers) would
+  // otherwise be hoisted out of the tile loop and kept in registers ACROSS the K loop, whose 128 fragment registers leave no room -- hipcc then spills
+  // around the loop and parks the reload's `s_waitcnt vmcnt(0)` in the loop header, which drains the DMA ring once per K-tile (measured: +33 % K-loop time)
+  int lane_e = lane_in;
+  asm volatile("" : "+v"(lane_e));
+  const int lane = lane_e;
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  const long long n0 = bn0 + wcol0 + frag_q * 4;                       // + 16 j
+  const long long m0 = bm0 + wrow0;                                    // the wave's first row (wave-uniform)
+  // sample / position of the wave's first row (GATE_RESID)
+  long long g_b = 0, g_pos = 0;
+  if constexpr (HAS_G) {
+    g_b = m0 / p.rows_per_batch;
+    g_pos = m0 - g_b * p.rows_per_batch;
+  }
+  if (m0 >= p.M) return;                                               // (a wave below the matrix: nothing to store)
+  const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);            // the wave's valid rows (wave-uniform): < 128 in the last row of tiles only
+  bool fast = p.staged && bn0 + wcol0 + 128 <= p.N;
+  if constexpr (HAS_G) fast = fast && g_pos + mrows - 1 < p.rows_per_batch && ((g_pos < p.split) == (g_pos + mrows - 1 < p.split));
+  auto add_resid = [&](u32x2 out, const u32x2 r2) __attribute__((always_inline)) -> u32x2 {
+    out[0] = pack_bf2(__uint_as_float(out[0] << 16) + __uint_as_float(r2[0] << 16), __uint_as_float(out[0] & 0xffff0000u) + __uint_as_float(r2[0] & 0xffff0000u));
+    out[1] = pack_bf2(__uint_as_float(out[1] << 16) + __uint_as_float(r2[1] << 16), __uint_as_float(out[1] & 0xffff0000u) + __uint_as_float(r2[1] & 0xffff0000u));
+    return out;
+  };
+  auto acc_math = [&](const int i, const int j, const u32x2 b2, const u32x2 g2) __attribute__((always_inline)) -> u32x2 {   // bias, activation, gate, scale; packed (ONE rounding)
+    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+    v[0] += __uint_as_float(b2[0] << 16); v[1] += __uint_as_float(b2[0] & 0xffff0000u);
+    v[2] += __uint_as_float(b2[1] << 16); v[3] += __uint_as_float(b2[1] & 0xffff0000u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+    if constexpr (HAS_G) {
+      v[0] *= __uint_as_float(g2[0] << 16); v[1] *= __uint_as_float(g2[0] & 0xffff0000u);
+      v[2] *= __uint_as_float(g2[1] << 16); v[3] *= __uint_as_float(g2[1] & 0xffff0000u);
+    }
+    if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+    }
+    return u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  };
+  if (fast) {
+    u32x2 bias[8], gate[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bias[j] = p.bias ? *(const u32x2*)(p.bias + n0 + 16 * j) : u32x2{0u, 0u};
+      if constexpr (HAS_G) gate[j] = *(const u32x2*)((g_pos < p.split ? p.gate0 : p.gate1) + g_b * p.gate_stride + n0 + 16 * j);
+      else gate[j] = u32x2{0u, 0u};
+    }
+    const int r4 = lane >> 4, chunk = lane & 15;                        // row layout
+    const bf16_t* rbase = HAS_R ? p.resid + m0 * p.ldr + n0 : nullptr;  // + row * ldr
+    bf16_t* cbase = p.C + (m0 + r4) * p.ldc + (bn0 + wcol0 + chunk * 8);
+    char* wput = smem + 131072 + wave * 8192 + frag_row * 256 + (frag_q & 1) * 8;
+    const char* wget = smem + 131072 + wave * 8192 + r4 * 256;
+    const int xput = frag_q >> 1;
+    constexpr int RD = 4;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use)
+    u32x2 rr[RD][8];
+    auto fetch = [&](const int i, const int slot) __attribute__((always_inline)) {
+      if constexpr (HAS_R) {
+        if (16 * i >= mrows) return;                                     // (row group below the matrix)
+        const int row = 16 * i + frag_row;
+        const bf16_t* rrow = rbase + (long long)(row < mrows ? row : mrows - 1) * p.ldr;   // rows below the matrix re-read the last valid one
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rr[slot][j] = *(const u32x2*)(rrow + 16 * j);
+      }
+    };
+    auto put = [&](const int i) __attribute__((always_inline)) {        // row group i -> LDS buffer i & 1 (accumulator layout)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        u32x2 out = acc_math(i, j, bias[j], gate[j]);
+        if constexpr (HAS_R) out = add_resid(out, rr[i % RD][j]);
+        *(u32x2*)(wput + (i & 1) * 4096 + (((2 * j + xput) ^ frag_row) * 16)) = out;
+      }
+    };
+    auto get_store = [&](const int i) __attribute__((always_inline)) {  // LDS buffer i & 1 -> global (row layout)
+      u32x4 val[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) val[q] = *(const u32x4*)(wget + (i & 1) * 4096 + q * 1024 + ((chunk ^ (q * 4 + r4)) * 16));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (16 * i + 4 * q + r4 < mrows) *(u32x4*)(cbase + (long long)(16 * i + 4 * q) * p.ldc) = val[q];
+    };
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i) fetch(i, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_barrier(0);   // one row group at a time: hipcc's scheduler otherwise hoists the accumulator reads of all eight and spills
+      if (i + RD - 1 < 8) fetch(i + RD - 1, (i + RD - 1) % RD);
+      if (16 * i < mrows) put(i);
+      if (i > 0 && 16 * (i - 1) < mrows) get_store(i - 1);     // (one wave, in-order LDS: these reads see the writes of iteration i - 1; the writes of i + 1 come after them)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (16 * 7 < mrows) get_store(7);
+    // a wait hipcc can SEE, for everything but the last four stores: its vmcnt bookkeeping then carries no pending load into the K loop.  (Without it
+    // the first fragment read of the loop -- inline asm that redefines registers this epilogue loaded into -- got a compiler-made `s_waitcnt vmcnt(0)` in the
+    // loop header: the DMA ring drained once per K-tile, +33 % K-loop time.)
+    __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) expcnt(7) lgkmcnt(0)
+    return;
+  }
+  // ---- general path
+  auto ncol = [&](const int j) __attribute__((always_inline)) { const long long n = n0 + 16 * j; return n < p.N ? n : p.N - 4; };   // (N % 4 == 0)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                                         // (fully unrolled: the accumulators are registers, never indexed at run time)
+    __builtin_amdgcn_sched_barrier(0);
+    const long long m = m0 + i * 16 + frag_row;
+    const bool mok = m < p.M;
+    const long long mc = mok ? m : p.M - 1;
+    const bf16_t* gate = nullptr;
+    if constexpr (HAS_G) {
+      long long b = g_b, pos = g_pos + (mc - m0);
+      while (pos >= p.rows_per_batch) { pos -= p.rows_per_batch; ++b; }
+      gate = (pos < p.split ? p.gate0 : p.gate1) + b * p.gate_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long n = ncol(j);
+      const u32x2 b2 = p.bias ? *(const u32x2*)(p.bias + n) : u32x2{0u, 0u};
+      u32x2 g2 = u32x2{0u, 0u};
+      if constexpr (HAS_G) g2 = *(const u32x2*)(gate + n);
+      u32x2 out = acc_math(i, j, b2, g2);
+      if constexpr (HAS_R) out = add_resid(out, *(const u32x2*)(p.resid + mc * p.ldr + n));
+      if (mok && n0 + 16 * j < p.N) *(u32x2*)(p.C + mc * p.ldc + n) = out;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): see the fast path (this path runs on edge tiles only)
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// logical tile L -> (tile_m, tile_n): groups of group_m m-tiles walked n-major (see gemm_tile)
+__device__ __forceinline__ void tile_coords(const GemmP& p, const int L, int& tile_m, int& tile_n) {
+  const int gw = p.group_m * p.tiles_n;
+  const int first_m = (L / gw) * p.group_m;
+  const int gsz = min(p.tiles_m - first_m, p.group_m);
+  tile_m = first_m + (L % gw) % gsz;
+  tile_n = (L % gw) / gsz;
+}
+
+// ---- 256x256 tiles on FOUR waves (one per SIMD, 128x128 per wave, the 256 accumulator registers pinned in AGPRs), PERSISTENT workgroups (one per CU)
+// whose K-tile stream runs across tile boundaries, and an instruction-level hand schedule.
+// * Per 64-deep K-tile and wave the matrix pipe sees 128 MFMAs with one memory instruction behind every second one: 32 fragment reads (2/3 of the 8-wave
+//   tile's LDS bytes per FLOP) and 16 LDS-DMA pieces (scalar base + loop-invariant 32-bit lane offset: no vector address arithmetic in the loop), two
+//   barriers, two counted waits.  Every statement of the K loop is volatile inline asm: hipcc only allocates registers.  (Round-3 attempts with 8-MFMA
+//   blocks and bursts of reads / pieces lost 3-15 % to the 8-wave loop: one wave per SIMD has no partner to hide a burst behind.)
+// * The DMA cursor runs two K-tiles ahead of the MFMAs and simply walks into the workgroup's NEXT tile: when a tile's last MFMA retires, the first two
+//   K-tiles of the next one are in LDS and its first fragments in registers, so the matrix pipe idles only for the epilogue's own instructions -- not for
+//   a workgroup launch, an address set-up and a cold first fetch per tile (measured on the non-persistent form of this loop: 17 us per tile, 18 % of a
+//   K = 3072 tile).  vmcnt is ONE in-order counter for loads and stores: the epilogue first waits for the (old) DMA pieces, then stores, and the first K-tile
+//   behind it runs the variant without a counted wait, so no wait in the loop ever stands behind a store that has just been issued.
+// LDS: two 64-KB stages [A rows 0..255 | W rows 0..255], 128-byte rows, 16-byte chunk c of row r at ((c ^ (r & 7)) * 16).
+// K-tile g of the stream (stage s = g & 1):  k-step 0 MFMAs | reads of (g, k-step 1) .. lgkmcnt(0), BARRIER (stage s is free) .. DMA of K-tile g + 2 -> stage s
+//                                            k-step 1 MFMAs | vmcnt (K-tile g + 1 landed), BARRIER .. reads of (g + 1, k-step 0) .. rest of the DMA
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr unsigned STAGE = 65536, WOFF = 32768;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int tiles = p.tiles_m * p.tiles_n, nk = (int)(p.K / 64), G = (int)gridDim.x;
+  const int slot = xcd_remap((int)blockIdx.x, G);   // this workgroup's tiles: slot, slot + G, ... (round r of the grid = what a one-tile-per-workgroup launch dispatches)
+  // ---- DMA cursor: (tile d_r of this workgroup, K-tile d_kt).  Piece q = wave + 4 i, i = 0..15 (i < 8: A rows 8 q .. 8 q + 7, else W rows 8 (q - 32) ..);
+  // lane -> row (lane >> 3) of the piece, source chunk (lane & 7) ^ row
+  unsigned voff[16];
+  const bf16_t *baseA = p.A, *baseW = p.W;
+  int d_r = 0, d_kt = 0;
+  bool d_valid = false;
+  auto cursor_set = [&](const int r) __attribute__((always_inline)) {
+    const int L = r * G + slot;
+    d_valid = L < tiles;
+    if (!d_valid) return;                 // the stream has ended: the cursor stays where it is (see `advance`)
+    int tm, tn;
+    tile_coords(p, L, tm, tn);
+    const long long bm0 = (long long)tm * 256, bn0 = (long long)tn * 256;
+    int lane_c = lane;                      // laundered (see epilogue_w4): nothing lane-derived of this block may stay live across the K loop
+    asm volatile("" : "+v"(lane_c));
+    const int prow = lane_c >> 3, pchk = (lane_c & 7) ^ prow;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = wave_s + 4 * i;
+      long long r8 = (i < 8) ? 8 * q + prow : 8 * (q - 32) + prow;
+      const long long lim = (i < 8) ? p.M - bm0 : p.N - bn0;          // clamp: tail rows re-read the tile's last valid row, stores are masked
+      r8 = r8 < lim ? r8 : lim - 1;
+      voff[i] = (unsigned)((r8 * ((i < 8) ? p.lda : p.ldw) + pchk * 8) * 2);
+    }
+    baseA = p.A + bm0 * p.lda;
+    baseW = p.W + bn0 * p.ldw;
+  };
+  // past the end of the stream the cursor stays on its last K-tile: the loop below has ONE instruction stream (one register allocation for the 256 pinned
+  // accumulators -- with one body per stream state hipcc spilled accumulators at the joins), so the last two K-tiles of a workgroup re-request a K-tile
+  // into a stage nobody reads again (two redundant L2 reads per workgroup) instead of branching around their DMA
+  auto advance = [&]() __attribute__((always_inline)) {
+    if (!d_valid) return;
+    if (d_kt + 1 < nk) { ++d_kt; return; }
+    cursor_set(d_r + 1);
+    if (d_valid) { ++d_r; d_kt = 0; }
+  };
+  const unsigned smem_u = (unsigned)(size_t)smem;
+  // fragment reads: lane (row r = lane & 15, k-quarter q = lane >> 4) reads chunk (q [+ 4]) ^ (r & 7) of its row
+  const unsigned fr = lane & 15, fq = lane >> 4, swz = lane & 7;
+  const unsigned c0 = ((fq + 0) ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;
+  const unsigned rowA = smem_u + (wm * 128 + fr) * 128, rowW = smem_u + WOFF + (wn * 128 + fr) * 128;
+  f32x4 acc[8][8];
+  u32x4 a0[8], w0[8], a1[8], w1[8];
+#define MRAG_W4_MF(I, J, W, A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(W[J]), "v"(A[I]))
+#define MRAG_W4_RD(D, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(D) : "v"(ADDR), "n"(OFF) : "memory")
+#define MRAG_W4_LGKM0(W, A)                                                                                          \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
+                   : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]), "+v"(W[6]), "+v"(W[7]),   \
+                     "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7])    \
+                   :: "memory")
+  unsigned aw1, aa1, aw0, aa0, stage_u;   // function scope: clang rejects asm operands that name an enclosing LAMBDA's locals from a nested lambda
+  auto dma = [&](auto I) __attribute__((always_inline)) {                // piece wave + 4 i of the cursor's K-tile into the stage at LDS address stage_u
+    constexpr int i = decltype(I)::value;
+    (void)&voff;                          // (clang does not capture a variable that a generic lambda names only in asm operands)
+    const bf16_t* sb = (i < 8 ? baseA : baseW) + (long long)d_kt * 64;
+    const unsigned lds = stage_u + (unsigned)(wave_s + 4 * i) * 1024u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff[i]), "s"(sb), "s"(lds) : "memory", "m0");
+  };
+  // one K-tile of the stream.  `counted`: the wait in front of the second barrier (false for the K-tile right behind an epilogue, which waited for every piece)
+  auto kstep = [&](const unsigned g, const bool counted) __attribute__((always_inline)) {
+    const unsigned so = (g & 1) ? STAGE : 0u, sn = STAGE - so;        // this K-tile's stage offset, the other stage's
+    aw1 = rowW + so + c1; aa1 = rowA + so + c1;                       // (g, k-step 1)
+    aw0 = rowW + sn + c0; aa0 = rowA + sn + c0;                       // (g + 1, k-step 0)
+    stage_u = smem_u + so;
+    MRAG_W4_LGKM0(w0, a0);
+    // ---- k-step 0: 64 MFMAs on (w0, a0)
+    static_for<32>([&](auto S) __attribute__((always_inline)) {
+      constexpr int sl = decltype(S)::value, i = (2 * sl) / 8, j = (2 * sl) % 8;
+      (void)&acc; (void)&w0; (void)&a0; (void)&w1; (void)&a1; (void)&aw1; (void)&aa1;
+      MRAG_W4_MF(i, j, w0, a0);
+      if constexpr (sl < 8) MRAG_W4_RD(w1[sl], aw1, sl * 2048);
+      else if constexpr (sl < 16) MRAG_W4_RD(a1[sl - 8], aa1, (sl - 8) * 2048);
+      else if constexpr (sl == 22) { MRAG_W4_LGKM0(w1, a1); asm volatile("s_barrier" ::: "memory"); }
+      else if constexpr (sl >= 23 && (sl & 1)) dma(std::integral_constant<int, (sl - 23) / 2>{});   // pieces 0..4
+      MRAG_W4_MF(i, j + 1, w0, a0);
+    });
+    // ---- k-step 1: 64 MFMAs on (w1, a1)
+    if (counted) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // K-tile g + 1 has landed (5 pieces of g + 2 in flight)
+    asm volatile("s_barrier" ::: "memory");                            // ... for every wave
+    static_for<32>([&](auto S) __attribute__((always_inline)) {
+      constexpr int sl = decltype(S)::value, i = (2 * sl) / 8, j = (2 * sl) % 8;
+      (void)&acc; (void)&w0; (void)&a0; (void)&w1; (void)&a1; (void)&aw0; (void)&aa0;
+      MRAG_W4_MF(i, j, w1, a1);
+      if constexpr (sl < 8) MRAG_W4_RD(w0[sl], aw0, sl * 2048);
+      else if constexpr (sl < 16) MRAG_W4_RD(a0[sl - 8], aa0, (sl - 8) * 2048);
+      else if constexpr (sl >= 16 && sl < 27) dma(std::integral_constant<int, sl - 11>{});          // pieces 5..15
+      MRAG_W4_MF(i, j + 1, w1, a1);
+    });
+  };
+#ifdef MRAG_GEMM_STAMPS
+  unsigned long long q_acc[6] = {0, 0, 0, 0, 0, 0}, q0, q1, q2, q3, q4, q_in;
+  MRAG_GSTAMP(q_in);
+#endif
+  // ---- prologue: the stream's first two K-tiles, the first fragments
+  cursor_set(0);
+  if (!d_valid) return;
+  stage_u = smem_u;
+  static_for<16>([&](auto I) __attribute__((always_inline)) { dma(I); });
+  advance();
+  stage_u = smem_u + STAGE;
+  static_for<16>([&](auto I) __attribute__((always_inline)) { dma(I); });
+  advance();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  aw0 = rowW + c0; aa0 = rowA + c0;
+  static_for<8>([&](auto J) __attribute__((always_inline)) { constexpr int j = decltype(J)::value; (void)&w0; (void)&aw0; MRAG_W4_RD(w0[j], aw0, j * 2048); });
+  static_for<8>([&](auto J) __attribute__((always_inline)) { constexpr int j = decltype(J)::value; (void)&a0; (void)&aa0; MRAG_W4_RD(a0[j], aa0, j * 2048); });
+  unsigned g = 0;
+  for (int r = 0;; ++r) {
+    const int L = r * G + slot;
+    if (L >= tiles) break;
+    MRAG_GSTAMP(q0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 4" ::: "memory");   // accumulator writes -> first MFMA (the asm MFMAs are invisible to hipcc's hazard pass)
+    MRAG_GSTAMP(q1);
+    for (int t = 0; t < nk; ++t, ++g) {
+      kstep(g, !(t == 0 && r > 0));
+      advance();
+    }
+    MRAG_GSTAMP(q2);
+    // the MFMAs above are invisible to hipcc's hazard pass: the accumulators are read (v_accvgpr_read) only after the matrix pipe has drained; every DMA piece
+    // in flight (issued BEFORE the stores below) is waited for here, so the next counted wait in the loop comes two K-tiles after the stores
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+    MRAG_GSTAMP(q3);
+    int tm, tn;
+    tile_coords(p, L, tm, tn);
+    epilogue_w4<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
+#ifdef MRAG_GEMM_STAMPS
+    MRAG_GSTAMP(q4);
+    q_acc[0] += q1 - q0; q_acc[1] += q2 - q1; q_acc[2] += q3 - q2; q_acc[3] += q4 - q3; q_acc[4] += 1;
+#endif
+  }
+#ifdef MRAG_GEMM_STAMPS
+  MRAG_GSTAMP(q4);
+  if (g_gemm_stamp_buf && lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = g_gemm_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 5; ++k) o[k] = q_acc[k];
+    o[5] = q4 - q_in;
+  }
+#endif
+#undef MRAG_W4_MF
+#undef MRAG_W4_RD
+#undef MRAG_W4_LGKM0
+}
+
+// the persistent four-wave launch: one workgroup per CU, 128 KB of LDS
+inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
+  GemmP p = p0;
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (int)((p.N + 255) / 256);
+  p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
+  const long long tiles = (long long)p.tiles_m * p.tiles_n;
+  const dim3 grid((unsigned)(tiles < SK_CUS ? tiles : SK_CUS)), block(256);
+  // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
+  p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
+  if (p.tuning & MRAG_GEMM_TUNE_NO_STAGED) p.staged = 0;
+  const size_t lds = 131072 + 32768;   // two operand stages + 8 KB of epilogue staging per wave: all 160 KB of a CU
+#define MRAG_W4_CASE(E)                                                                                \
+  case E: {                                                                                            \
+    auto kfn = gemm_w4_kernel<E>;                                                                      \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
+    break;                                                                                             \
+  }
+  switch (epi) {
+    MRAG_W4_CASE(MRAG_EPI_NONE)
+    MRAG_W4_CASE(MRAG_EPI_GELU_TANH)
+    MRAG_W4_CASE(MRAG_EPI_RESID)
+    MRAG_W4_CASE(MRAG_EPI_GATE_RESID)
+    default: return MRAG_ENOTSUP;
+  }
+#undef MRAG_W4_CASE
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
 }
 
 template <int WM, int WN, int TM, int TN, int CONV = 0>
@@ -938,6 +1317,19 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   if (const int cfg = (a->tuning >> 4) & 0xf) {   // developer knob (tools/microbench.py); 0 = the shipped choice below
     if (cfg == 1 && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, epi);   // 256x256, 16 waves (4 per SIMD)
     if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, epi);                  // 128x128, 4 waves, 2 workgroups per CU
+    if (cfg == 3 && t256 >= 192) {                                           // 256x256, 4 waves, persistent, hand-scheduled
+      const int rc = launch_w4(s, p, epi);
+      if (rc != MRAG_ENOTSUP) return rc;
+    }
+  }
+  // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
+  // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
+  // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
+  if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
+      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID) &&
+      a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0))) {
+    const int rc = launch_w4(s, p, epi);
+    if (rc != MRAG_ENOTSUP) return rc;
   }
   if (t256 >= 192 && wide_n_pays(a->N, a->tuning) && a->epilogue != MRAG_EPI_GEGLU) return launch_cfg<2, 4, 8, 5>(s, p, epi);   // 256x320 tile
   if (t256 >= 192 && a->workspace && (a->tuning & MRAG_GEMM_TUNE_STREAMK) &&

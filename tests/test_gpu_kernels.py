@@ -80,6 +80,59 @@ def test_gemm_epilogues(hip, epi, M, N, K):
     close(got, want, scale=acc.abs().mean().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 14, 256 * 16, 320), (256 * 21 + 77, 1280, 1024), (17 * 1024 + 130, 640, 1984), (256 * 300, 256, 64 * 3)])
+def test_gemm_persistent_four_wave_kernel(hip, M, N, K):
+    """the persistent four-wave 256x256 kernel (gemm_w4_kernel: one workgroup per CU walking its tiles, the K-tile stream running across tile boundaries,
+    accumulators pinned in AGPRs, LDS-staged fast epilogue / predicated general epilogue) gives the SAME BITS as the 8-wave tile it replaces for every
+    epilogue it carries -- same K order per output, same rounding points -- and both equal the fp32 reference: whole tiles, a ragged last row of tiles
+    (rows of a wave tile cut anywhere), one tile per workgroup only, fewer tiles than CUs' second round, a sample boundary and the text / video split
+    inside a wave's rows (general epilogue path), K of 3 K-tiles"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV), bf(torch.randn(N, generator=g)).to(DEV)
+    r = bf(torch.randn(M, N, generator=g)).to(DEV)
+    rpb = 4000 + 37                                                  # sample boundaries fall inside wave tiles
+    nb = -(-M // rpb)
+    g0, g1 = (bf(torch.randn(nb, N, generator=g)).to(DEV) for _ in range(2))
+    acc = x.float() @ w.float().t() + b.float()
+    rows = torch.arange(M, device=DEV)
+    gate = torch.where(((rows % rpb) < 226)[:, None], g0[rows // rpb].float(), g1[rows // rpb].float())
+    cases = {"none": (dict(), acc), "gelu": (dict(epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(acc, approximate="tanh")),
+             "resid": (dict(epilogue=ops.EPI_RESID, resid=r), r.float() + acc.to(torch.bfloat16).float()),
+             "resid scaled": (dict(epilogue=ops.EPI_RESID, resid=r, acc_scale=0.375), r.float() + (0.375 * acc).to(torch.bfloat16).float()),
+             "gate": (dict(epilogue=ops.EPI_GATE_RESID, resid=r, gate0=g0, gate1=g1, rows_per_batch=rpb, split=226, gate_stride=N), r.float() + (gate * acc).to(torch.bfloat16).float())}
+    for name, (kw, want) in cases.items():
+        try:
+            ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_W4
+            eight = ops.linear(x, w, b, **kw)
+            ops.TUNING["gemm"] = 3 << 4                              # the four-wave kernel whatever the dispatch rule says about this shape
+            four = ops.linear(x, w, b, **kw)
+            inplace = r.clone()
+            if "resid" in kw:                                        # in place over the residual, as the DiT calls it
+                ops.linear(x, w, b, out=inplace, **{**kw, "resid": inplace})
+        finally:
+            ops.TUNING["gemm"] = 0
+        assert torch.equal(four, eight), f"{name}: {(four.float() - eight.float()).abs().max().item()}"
+        assert "resid" not in kw or torch.equal(inplace, four), name
+        close(four, want, scale=want.abs().mean().item())
+    # a strided output / residual (a column block of a wider tensor) and an unaligned one (general epilogue: 8-byte stores)
+    wide = torch.zeros(M, N + 136, device=DEV, dtype=torch.bfloat16)
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_W4
+    try:
+        plain = ops.linear(x, w, b)
+    finally:
+        ops.TUNING["gemm"] = 0
+    for off in (128, 4):
+        try:
+            ops.TUNING["gemm"] = 3 << 4
+            ops.linear(x, w, b, out=wide[:, off:off + N])
+        finally:
+            ops.TUNING["gemm"] = 0
+        assert torch.equal(wide[:, off:off + N], plain), off
+        assert int((wide[:, :off] != 0).sum().item()) == 0 and int((wide[:, off + N:] != 0).sum().item()) == 0
+        wide.zero_()
+
+
 @pytest.mark.parametrize("M,N,K", [(4352, 4096, 1024), (5000, 3840, 3072), (8300, 3072, 2048)])
 def test_gemm_stream_k_tail(hip, M, N, K):
     """stream-K for the partial last round of 256x256 tiles (272 tiles = 1 round + 16: 64 units of a quarter tile; 300 tiles = 1 + 44: 176 uneven

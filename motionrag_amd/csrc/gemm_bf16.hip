@@ -81,6 +81,52 @@ __device__ __forceinline__ float sum8_dpp(float x) {
   return x;
 }
 
+// one row's 8 features of a head in the row layout (the 8 lanes 8g .. 8g + 7 hold the head's 64 features): per-head LayerNorm across those lanes, RoPE on the
+// lane's four (even, odd) pairs, Q pre-multiplied -- the arithmetic of qknorm_rope_kernel (norm.hip).  Shared by the 8-wave and the four-wave kernels (same bits).
+__device__ __forceinline__ u32x4 qk_row_math(u32x4 val, const bool has_gamma, const bool has_beta, const float (&gam)[8], const float (&bet)[8], const float eps,
+                                             const bool has_rope, const bool vid, const f32x4 (&t4)[4], const bool premul_on, const float premul) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(val[e] << 16); v[2 * e + 1] = __uint_as_float(val[e] & 0xffff0000u); }
+  if (has_gamma) {
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[e];
+    sum = sum8_dpp(sum);
+    const float mean = sum * (1.0f / 64.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+    sq = sum8_dpp(sq);
+    const float rstd = rsqrtf(sq * (1.0f / 64.0f) + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e];
+    if (has_beta) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bet[e];
+    }
+  }
+  if (has_rope) {
+    const float cc[8] = {t4[0][0], t4[0][1], t4[0][2], t4[0][3], t4[1][0], t4[1][1], t4[1][2], t4[1][3]};
+    const float ss[8] = {t4[2][0], t4[2][1], t4[2][2], t4[2][3], t4[3][0], t4[3][1], t4[3][2], t4[3][3]};
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+      const float a = v[2 * i2], b2 = v[2 * i2 + 1];
+      const float oa = a * cc[2 * i2] - b2 * ss[2 * i2];
+      const float ob = b2 * cc[2 * i2 + 1] + a * ss[2 * i2 + 1];
+      v[2 * i2] = vid ? oa : a;
+      v[2 * i2 + 1] = vid ? ob : b2;
+    }
+  }
+  if (premul_on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= premul;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) val[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+  return val;
+}
+
 // internal epilogue id: MRAG_EPI_GEGLU with the tanh gate (mrag_gemm_args.geglu_act = 1, T5's gated-gelu): its own instantiation, so the erf kernels of the
 // UNets (epilogue-bound at K = 320) carry neither a branch nor the second activation's registers
 constexpr int EPI_GEGLU_TANH = 8;
@@ -610,48 +656,8 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
           const int row = g * 8 + rsub;
           const long long m = bm0 + wm * TM * 16 + row;
           u32x4 val = *(const u32x4*)(wbase + row * ROWB + chunk * 16);
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(val[e] << 16); v[2 * e + 1] = __uint_as_float(val[e] & 0xffff0000u); }
-          if (gm) {
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[e];
-            sum = sum8_dpp(sum);
-            const float mean = sum * (1.0f / 64.0f);
-            float sq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
-            sq = sum8_dpp(sq);
-            const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.qk_eps);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e];
-            if (bt) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += bet[e];
-            }
-          }
-          if (has_rope) {
-            const f32x4(&t4)[4] = qk_tab[g % QK_RING];
-            const float cc[8] = {t4[0][0], t4[0][1], t4[0][2], t4[0][3], t4[1][0], t4[1][1], t4[1][2], t4[1][3]};
-            const float ss[8] = {t4[2][0], t4[2][1], t4[2][2], t4[2][3], t4[3][0], t4[3][1], t4[3][2], t4[3][3]};
-            const bool vid = (qk_video >> g) & 1u;
-#pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-              const float a = v[2 * i2], b2 = v[2 * i2 + 1];
-              const float oa = a * cc[2 * i2] - b2 * ss[2 * i2];
-              const float ob = b2 * cc[2 * i2 + 1] + a * ss[2 * i2 + 1];
-              v[2 * i2] = vid ? oa : a;
-              v[2 * i2 + 1] = vid ? ob : b2;
-            }
-            if (g + QK_RING < 16) qk_fetch(g + QK_RING);   // refill the slot just consumed
-          }
-          if (qk_which == 0 && p.q_premul != 1.0f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.q_premul;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) val[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+          val = qk_row_math(val, gm != nullptr, bt != nullptr, gam, bet, p.qk_eps, has_rope, (qk_video >> g) & 1u, qk_tab[g % QK_RING], qk_which == 0 && p.q_premul != 1.0f, p.q_premul);
+          if (has_rope && g + QK_RING < 16) qk_fetch(g + QK_RING);   // refill the slot just consumed
           if (m < p.M) *(u32x4*)(p.C + m * p.ldc + n) = val;
         }
       }
@@ -858,7 +864,7 @@ inline SkPlan plan_streamk(long long M, long long N, long long K) {
 template <int EPI>
 __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&acc)[8][8], const long long bm0, const long long bn0, const int wave, const int wrow0,
                                             const int wcol0, const int lane_in) {
-  constexpr bool HAS_R = (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID), HAS_G = (EPI == MRAG_EPI_GATE_RESID);
+  constexpr bool HAS_R = (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID), HAS_G = (EPI == MRAG_EPI_GATE_RESID), QK = (EPI == MRAG_EPI_QKNORM_ROPE);
   // the lane id is laundered through an empty asm: everything below that depends on the lane only (LDS addresses, column offsets, row pointers) would
   // otherwise be hoisted out of the tile loop and kept in registers ACROSS the K loop, whose 128 fragment registers leave no room -- hipcc then spills
   // around the loop and parks the reload's `s_waitcnt vmcnt(0)` in the loop header, which drains the DMA ring once per K-tile (measured: +33 % K-loop time)
@@ -870,7 +876,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
   const long long m0 = bm0 + wrow0;                                    // the wave's first row (wave-uniform)
   // sample / position of the wave's first row (GATE_RESID)
   long long g_b = 0, g_pos = 0;
-  if constexpr (HAS_G) {
+  if constexpr (HAS_G || QK) {
     g_b = m0 / p.rows_per_batch;
     g_pos = m0 - g_b * p.rows_per_batch;
   }
@@ -913,6 +919,50 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     char* wput = smem + 131072 + wave * 8192 + frag_row * 256 + (frag_q & 1) * 8;
     const char* wget = smem + 131072 + wave * 8192 + r4 * 256;
     const int xput = frag_q >> 1;
+    // QKNORM_ROPE (the fused QKV projection): the wave's 128 columns are two heads of ONE third (q_dmodel % 128 == 0), in the row layout the 8 lanes
+    // (r4, chunk >> 3) hold a row of a head: qk_row_math on every 16-byte vector between the LDS read and the store.  The fp32 cos / sin rows (64 B per
+    // lane and row) come through a ring of three (row-of-four) steps, each slot refilled as it is consumed
+    int qk_which = 2;
+    bool has_rope = false;
+    const bf16_t *gm = nullptr, *bt = nullptr;
+    float gam[8], bet[8];
+    f32x4 qk_tab[QK ? 3 : 1][4];
+    unsigned qk_video = 0;                                              // bit s: this lane's row of step s lies past the text rows
+    auto qk_fetch = [&](const int st) __attribute__((always_inline)) {   // step st = rows 4 st .. 4 st + 3 of the wave tile
+      if constexpr (QK) {
+        const int row = 4 * st + r4;
+        long long pos = g_pos + (row < mrows ? row : mrows - 1);
+        while (pos >= p.rows_per_batch) pos -= p.rows_per_batch;
+        const int rp = (int)pos - p.rope_text_len;
+        if (rp >= 0) qk_video |= 1u << st;
+        const long long ro = (long long)(rp > 0 ? rp : 0) * 64 + (chunk & 7) * 8;
+        f32x4(&dst)[4] = qk_tab[st % 3];
+        dst[0] = *(const f32x4*)(p.rcos + ro); dst[1] = *(const f32x4*)(p.rcos + ro + 4);
+        dst[2] = *(const f32x4*)(p.rsin + ro); dst[3] = *(const f32x4*)(p.rsin + ro + 4);
+      }
+    };
+    if constexpr (QK) {
+      qk_which = p.qk_first + (int)((bn0 + wcol0) / p.qk_D);
+      has_rope = p.rcos != nullptr && qk_which < 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gam[e] = 1.f; bet[e] = 0.f; }
+      if (qk_which < 2) {
+        gm = qk_which ? p.kg : p.qg;
+        bt = qk_which ? p.kb : p.qb;
+        const int d0 = (chunk & 7) * 8;
+        if (gm) {
+          const u32x4 graw = *(const u32x4*)(gm + d0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { gam[2 * e] = __uint_as_float(graw[e] << 16); gam[2 * e + 1] = __uint_as_float(graw[e] & 0xffff0000u); }
+          if (bt) {
+            const u32x4 braw = *(const u32x4*)(bt + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bet[2 * e] = __uint_as_float(braw[e] << 16); bet[2 * e + 1] = __uint_as_float(braw[e] & 0xffff0000u); }
+          }
+        }
+      }
+      if (has_rope) { qk_fetch(0); qk_fetch(1); qk_fetch(2); }
+    }
     constexpr int RD = 4;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use)
     u32x2 rr[RD][8];
     auto fetch = [&](const int i, const int slot) __attribute__((always_inline)) {
@@ -937,8 +987,16 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
 #pragma unroll
       for (int q = 0; q < 4; ++q) val[q] = *(const u32x4*)(wget + (i & 1) * 4096 + q * 1024 + ((chunk ^ (q * 4 + r4)) * 16));
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (QK) {
+          const int st = 4 * i + q;
+          if (qk_which < 2) {
+            val[q] = qk_row_math(val[q], gm != nullptr, bt != nullptr, gam, bet, p.qk_eps, has_rope, (qk_video >> st) & 1u, qk_tab[st % 3], qk_which == 0 && p.q_premul != 1.0f, p.q_premul);
+            if (has_rope && st + 3 < 32) qk_fetch(st + 3);             // refill the slot just consumed
+          }
+        }
         if (16 * i + 4 * q + r4 < mrows) *(u32x4*)(cbase + (long long)(16 * i + 4 * q) * p.ldc) = val[q];
+      }
     };
 #pragma unroll
     for (int i = 0; i < RD - 1; ++i) fetch(i, i);
@@ -958,6 +1016,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     return;
   }
   // ---- general path
+  if constexpr (QK) return;             // (never dispatched without the fast path's conditions: launch_w4)
   auto ncol = [&](const int j) __attribute__((always_inline)) { const long long n = n0 + 16 * j; return n < p.N ? n : p.N - 4; };   // (N % 4 == 0)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {                                         // (fully unrolled: the accumulators are registers, never indexed at run time)
@@ -1197,6 +1256,14 @@ inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
     MRAG_W4_CASE(MRAG_EPI_GELU_TANH)
     MRAG_W4_CASE(MRAG_EPI_RESID)
     MRAG_W4_CASE(MRAG_EPI_GATE_RESID)
+    case MRAG_EPI_QKNORM_ROPE: {          // fast epilogue path only: whole 128-column wave tiles inside one third, aligned rows
+      if (!p.staged || p.N % 128 != 0 || p.qk_D % 128 != 0) return MRAG_ENOTSUP;
+      auto kfn = gemm_w4_kernel<MRAG_EPI_QKNORM_ROPE>;
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+      break;
+    }
     default: return MRAG_ENOTSUP;
   }
 #undef MRAG_W4_CASE
@@ -1326,7 +1393,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
   if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
-      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID) &&
+      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE) &&
       a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0))) {
     const int rc = launch_w4(s, p, epi);
     if (rc != MRAG_ENOTSUP) return rc;

@@ -133,6 +133,37 @@ def test_gemm_persistent_four_wave_kernel(hip, M, N, K):
         wide.zero_()
 
 
+@pytest.mark.parametrize("B,S,H,text,first,n", [(2, 3000 + 11, 4, 226, 0, 3), (2, 256 * 24 + 5, 8, 17, 1, 2), (3, 2048, 6, 0, 0, 3)])
+def test_qkv_gemm_four_wave_kernel_matches_eight_wave(hip, B, S, H, text, first, n):
+    """the fused QKV projection (per-head qk LayerNorm + RoPE + Q pre-multiplication in the GEMM epilogue) on the persistent four-wave kernel: the same bits
+    as on the 8-wave tile (the row math is one shared function; the four-wave row layout holds two heads per wave tile), for Q|K|V and the K|V form of a
+    sequence-sharded rank, with sample boundaries and the text / video boundary inside wave tiles and a ragged last row of tiles"""
+    from motionrag_amd import ops
+    D, K = H * 64, 640
+    g = torch.Generator().manual_seed(B * S + H)
+    x = bf(torch.randn(B, S, K, generator=g)).to(DEV)
+    w = bf(torch.randn(n * D, K, generator=g) * K ** -0.5).to(DEV)
+    b = bf(torch.randn(n * D, generator=g)).to(DEV)
+    qg, qb, kg, kb = (bf(torch.randn(64, generator=g)).to(DEV) for _ in range(4))
+    ang = torch.rand(S - text, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
+    outs = {}
+    for name, t in (("eight", ops.GEMM_TUNE_NO_W4), ("four", 0)):
+        ops.TUNING["gemm"] = t
+        try:
+            outs[name] = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text, q_premul=0.18, first=first)
+        finally:
+            ops.TUNING["gemm"] = 0
+    assert torch.equal(outs["four"], outs["eight"]), (outs["four"].float() - outs["eight"].float()).abs().max().item()
+    ops.TUNING["no_qkv_fuse"] = True                                  # the unfused pair of kernels: same arithmetic up to the order of the bf16 roundings
+    try:
+        two = ops.qkv_linear_qknorm_rope(x, w, b, H, qg, qb, kg, kb, cos, sin, text, q_premul=0.18, first=first) if (first == 0 and n == 3) else None
+    finally:
+        ops.TUNING["no_qkv_fuse"] = False
+    if two is not None:
+        close(outs["four"], two.float(), scale=two.float().abs().mean().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(4352, 4096, 1024), (5000, 3840, 3072), (8300, 3072, 2048)])
 def test_gemm_stream_k_tail(hip, M, N, K):
     """stream-K for the partial last round of 256x256 tiles (272 tiles = 1 round + 16: 64 units of a quarter tile; 300 tiles = 1 + 44: 176 uneven

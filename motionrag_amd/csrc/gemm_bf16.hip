@@ -1044,6 +1044,65 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
   __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): see the fast path (this path runs on edge tiles only)
 }
 
+// ---- the four-wave kernel's GEGLU epilogue (W rows interleaved in 16-row [value | gate] groups: the even 16-column MFMA tile of a pair holds the values, the
+// odd one the gates of the same 16 outputs, in the same lanes; C is [M, N / 2]): the wave's 128 x 64 outputs, sixteen rows at a time through two private
+// 2-KB LDS buffers (128-byte rows, 16-byte chunk c of row r at ((c ^ (r & 7)) * 16)) into whole 128-byte row segments.  The arithmetic of the 8-wave GEGLU
+// epilogues: both halves rounded to bf16 before the product (nn.Linear's output dtype).  Launched only with whole 128-column wave tiles and 16-byte aligned rows.
+template <int EPI>
+__device__ __forceinline__ void epilogue_w4_geglu(const GemmP& p, char* smem, f32x4 (&acc)[8][8], const long long bm0, const long long bn0, const int wave, const int wrow0,
+                                                  const int wcol0, const int lane_in) {
+  int lane_e = lane_in;                                                // laundered: see epilogue_w4
+  asm volatile("" : "+v"(lane_e));
+  const int lane = lane_e;
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  const long long m0 = bm0 + wrow0;
+  if (m0 >= p.M) return;
+  const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
+  const long long n0 = bn0 + wcol0 + frag_q * 4;                       // value columns of pair jj at n0 + 32 jj, gates 16 further
+  u32x2 bv[4], bg[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    bv[jj] = p.bias ? *(const u32x2*)(p.bias + n0 + 32 * jj) : u32x2{0u, 0u};
+    bg[jj] = p.bias ? *(const u32x2*)(p.bias + n0 + 32 * jj + 16) : u32x2{0u, 0u};
+  }
+  const int r8 = lane >> 3, chunk = lane & 7;                          // row layout: 8 rows x 8 chunks per instruction
+  bf16_t* cbase = p.C + (m0 + r8) * p.ldc + ((bn0 + wcol0) >> 1) + chunk * 8;
+  char* wput = smem + 131072 + wave * 8192 + frag_row * 128 + (frag_q & 1) * 8;
+  const char* wget = smem + 131072 + wave * 8192 + r8 * 128 + ((chunk ^ r8) * 16);   // rows r8 and r8 + 8 share (row & 7)
+  const int xput = frag_q >> 1, sw = frag_row & 7;
+  auto put = [&](const int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float v[4] = {acc[i][2 * jj][0], acc[i][2 * jj][1], acc[i][2 * jj][2], acc[i][2 * jj][3]};
+      float g[4] = {acc[i][2 * jj + 1][0], acc[i][2 * jj + 1][1], acc[i][2 * jj + 1][2], acc[i][2 * jj + 1][3]};
+      v[0] += __uint_as_float(bv[jj][0] << 16); v[1] += __uint_as_float(bv[jj][0] & 0xffff0000u);
+      v[2] += __uint_as_float(bv[jj][1] << 16); v[3] += __uint_as_float(bv[jj][1] & 0xffff0000u);
+      g[0] += __uint_as_float(bg[jj][0] << 16); g[1] += __uint_as_float(bg[jj][0] & 0xffff0000u);
+      g[2] += __uint_as_float(bg[jj][1] << 16); g[3] += __uint_as_float(bg[jj][1] & 0xffff0000u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
+      *(u32x2*)(wput + (i & 1) * 2048 + (((2 * jj + xput) ^ sw) * 16)) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    }
+  };
+  auto get_store = [&](const int i) __attribute__((always_inline)) {
+    u32x4 val[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) val[q] = *(const u32x4*)(wget + (i & 1) * 2048 + q * 1024);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (16 * i + 8 * q + r8 < mrows) *(u32x4*)(cbase + (long long)(16 * i + 8 * q) * p.ldc) = val[q];
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (16 * i < mrows) put(i);
+    if (i > 0 && 16 * (i - 1) < mrows) get_store(i - 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (16 * 7 < mrows) get_store(7);
+  __builtin_amdgcn_s_waitcnt(0x0072);     // vmcnt(2) expcnt(7) lgkmcnt(0): a wait hipcc can see (see epilogue_w4)
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1212,7 +1271,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     MRAG_GSTAMP(q3);
     int tm, tn;
     tile_coords(p, L, tm, tn);
-    epilogue_w4<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
+    if constexpr (is_geglu<EPI>) epilogue_w4_geglu<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
+    else epilogue_w4<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
 #ifdef MRAG_GEMM_STAMPS
     MRAG_GSTAMP(q4);
     q_acc[0] += q1 - q0; q_acc[1] += q2 - q1; q_acc[2] += q3 - q2; q_acc[3] += q4 - q3; q_acc[4] += 1;
@@ -1256,6 +1316,22 @@ inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
     MRAG_W4_CASE(MRAG_EPI_GELU_TANH)
     MRAG_W4_CASE(MRAG_EPI_RESID)
     MRAG_W4_CASE(MRAG_EPI_GATE_RESID)
+    case MRAG_EPI_GEGLU:
+    case EPI_GEGLU_TANH: {                // whole 128-column wave tiles, aligned rows of C [M, N / 2]
+      if (!p.staged || p.N % 128 != 0) return MRAG_ENOTSUP;
+      if (epi == MRAG_EPI_GEGLU) {
+        auto kfn = gemm_w4_kernel<MRAG_EPI_GEGLU>;
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+      } else {
+        auto kfn = gemm_w4_kernel<EPI_GEGLU_TANH>;
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+      }
+      break;
+    }
     case MRAG_EPI_QKNORM_ROPE: {          // fast epilogue path only: whole 128-column wave tiles inside one third, aligned rows
       if (!p.staged || p.N % 128 != 0 || p.qk_D % 128 != 0) return MRAG_ENOTSUP;
       auto kfn = gemm_w4_kernel<MRAG_EPI_QKNORM_ROPE>;
@@ -1393,7 +1469,8 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
   if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
-      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE) &&
+      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
+       epi == EPI_GEGLU_TANH) &&
       a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0))) {
     const int rc = launch_w4(s, p, epi);
     if (rc != MRAG_ENOTSUP) return rc;

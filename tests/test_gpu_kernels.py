@@ -115,6 +115,20 @@ def test_gemm_persistent_four_wave_kernel(hip, M, N, K):
         assert torch.equal(four, eight), f"{name}: {(four.float() - eight.float()).abs().max().item()}"
         assert "resid" not in kw or torch.equal(inplace, four), name
         close(four, want, scale=want.abs().mean().item())
+    # GEGLU (value * gelu(gate) of interleaved weight rows -> [M, N / 2]), erf and tanh gates
+    wi, bi = ops.geglu_interleave(w, b)
+    for tanh in (False, True):
+        outs = {}
+        for name, t in (("eight", ops.GEMM_TUNE_NO_W4), ("four", 3 << 4)):
+            ops.TUNING["gemm"] = t
+            try:
+                outs[name] = ops.linear(x, wi, bi, epilogue=ops.EPI_GEGLU, geglu_tanh=tanh)
+            finally:
+                ops.TUNING["gemm"] = 0
+        assert torch.equal(outs["four"], outs["eight"]), f"geglu tanh={tanh}"
+        a16 = acc.to(torch.bfloat16).float()
+        want = a16[:, :N // 2] * torch.nn.functional.gelu(a16[:, N // 2:], approximate="tanh" if tanh else "none")
+        close(outs["four"], want, scale=want.abs().mean().item())
     # a strided output / residual (a column block of a wider tensor) and an unaligned one (general epilogue: 8-byte stores)
     wide = torch.zeros(M, N + 136, device=DEV, dtype=torch.bfloat16)
     ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_W4

@@ -13,7 +13,8 @@ DEV = "cuda"
 g = torch.Generator().manual_seed(1)
 SHAPES = [("QKV", 35552, 9216, 3072, "none"), ("to_out", 35552, 3072, 3072, "gate"), ("FF1", 35552, 12288, 3072, "gelu"), ("FF2", 35552, 3072, 12288, "gate")]
 if os.environ.get("UNET"):
-    SHAPES += [("L0 qkv", 258048, 960, 320, "none"), ("L1 to_out", 64512, 640, 640, "resid"), ("L2 ff2", 16128, 1280, 5120, "resid"), ("odd", 100037, 2564, 320, "resid"),
+    SHAPES += [("L0 GEGLU", 258048, 2560, 320, "geglu"), ("L1 GEGLU", 64512, 5120, 640, "geglu"), ("L2 GEGLU", 16128, 10240, 1280, "geglu"), ("odd GEGLU", 100037, 2560, 320, "geglu"),
+               ("L0 qkv", 258048, 960, 320, "none"), ("L1 to_out", 64512, 640, 640, "resid"), ("L2 ff2", 16128, 1280, 5120, "resid"), ("odd", 100037, 2564, 320, "resid"),
                ("odd gate", 70001, 1028, 192, "gate"), ("odd M gate", 35552 + 77, 3072, 3072, "gate"), ("odd M gelu", 70001, 1024, 640, "gelu"), ("odd M resid", 64512 + 130, 640, 640, "resid"), ("k64", 70000, 1024, 64, "gelu"), ("k128", 70000, 1024, 128, "none")]
 S = 17776
 for name, M, N, K, epi in SHAPES:
@@ -22,6 +23,9 @@ for name, M, N, K, epi in SHAPES:
     b = torch.randn(N, generator=g).to(DEV, torch.bfloat16)
     out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     r = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16) if epi in ("gate", "resid") else None
+    if epi == "geglu":
+        wi, bi = ops.geglu_interleave(w, b)
+        out2 = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
     nb = -(-M // min(S, M))
     g0, g1 = (torch.randn(nb, N, generator=g).to(DEV, torch.bfloat16) for _ in range(2))
 
@@ -33,6 +37,8 @@ for name, M, N, K, epi in SHAPES:
                     return ops.linear(x, w, b, out=out, epilogue=ops.EPI_GATE_RESID, resid=r, gate0=g0, gate1=g1, rows_per_batch=min(S, M), split=226, gate_stride=N)
                 if epi == "resid":
                     return ops.linear(x, w, b, out=out, epilogue=ops.EPI_RESID, resid=r)
+                if epi == "geglu":
+                    return ops.linear(x, wi, bi, out=out2, epilogue=ops.EPI_GEGLU)
                 if epi == "gelu":
                     return ops.linear(x, w, b, out=out, epilogue=ops.EPI_GELU_TANH)
                 return ops.linear(x, w, b, out=out)

@@ -880,7 +880,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     g_b = m0 / p.rows_per_batch;
     g_pos = m0 - g_b * p.rows_per_batch;
   }
-  if (m0 >= p.M) return;                                               // (a wave below the matrix: nothing to store)
+  if (m0 >= p.M || bn0 + wcol0 >= p.N) return;                         // (a wave tile outside the matrix: nothing to store)
   const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);            // the wave's valid rows (wave-uniform): < 128 in the last row of tiles only
   bool fast = p.staged && bn0 + wcol0 + 128 <= p.N;
   if constexpr (HAS_G) fast = fast && g_pos + mrows - 1 < p.rows_per_batch && ((g_pos < p.split) == (g_pos + mrows - 1 < p.split));
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void epilogue_w4_geglu(const GemmP& p, char* smem, f3
   const int lane = lane_e;
   const int frag_row = lane & 15, frag_q = lane >> 4;
   const long long m0 = bm0 + wrow0;
-  if (m0 >= p.M) return;
+  if (m0 >= p.M || bn0 + wcol0 >= p.N) return;                         // a wave tile outside the matrix (N % 128 == 0: a wave's columns are all in or all out)
   const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
   const long long n0 = bn0 + wcol0 + frag_q * 4;                       // value columns of pair jj at n0 + 32 jj, gates 16 further
   u32x2 bv[4], bg[4];

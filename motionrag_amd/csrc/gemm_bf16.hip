@@ -963,11 +963,10 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
       }
       if (has_rope) { qk_fetch(0); qk_fetch(1); qk_fetch(2); }
     }
-    constexpr int RD = 4;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use)
+    constexpr int RD = 2;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use; deeper rings measured no faster and cost registers)
     u32x2 rr[RD][8];
     auto fetch = [&](const int i, const int slot) __attribute__((always_inline)) {
       if constexpr (HAS_R) {
-        if (16 * i >= mrows) return;                                     // (row group below the matrix)
         const int row = 16 * i + frag_row;
         const bf16_t* rrow = rbase + (long long)(row < mrows ? row : mrows - 1) * p.ldr;   // rows below the matrix re-read the last valid one
 #pragma unroll
@@ -1003,12 +1002,14 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       __builtin_amdgcn_sched_barrier(0);   // one row group at a time: hipcc's scheduler otherwise hoists the accumulator reads of all eight and spills
+      // (row groups below the matrix are computed like the others -- their loads re-read the last valid row, only their stores are masked: every load is
+      // issued and consumed unconditionally, so hipcc's vmcnt bookkeeping is exact and carries nothing pending into the K loop)
       if (i + RD - 1 < 8) fetch(i + RD - 1, (i + RD - 1) % RD);
-      if (16 * i < mrows) put(i);
-      if (i > 0 && 16 * (i - 1) < mrows) get_store(i - 1);     // (one wave, in-order LDS: these reads see the writes of iteration i - 1; the writes of i + 1 come after them)
+      put(i);
+      if (i > 0) get_store(i - 1);     // (one wave, in-order LDS: these reads see the writes of iteration i - 1; the writes of i + 1 come after them)
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (16 * 7 < mrows) get_store(7);
+    get_store(7);
     // a wait hipcc can SEE, for everything but the last four stores: its vmcnt bookkeeping then carries no pending load into the K loop.  (Without it
     // the first fragment read of the loop -- inline asm that redefines registers this epilogue loaded into -- got a compiler-made `s_waitcnt vmcnt(0)` in the
     // loop header: the DMA ring drained once per K-tile, +33 % K-loop time.)
@@ -1095,11 +1096,11 @@ __device__ __forceinline__ void epilogue_w4_geglu(const GemmP& p, char* smem, f3
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     __builtin_amdgcn_sched_barrier(0);
-    if (16 * i < mrows) put(i);
-    if (i > 0 && 16 * (i - 1) < mrows) get_store(i - 1);
+    put(i);                                                            // (rows below the matrix: computed, not stored)
+    if (i > 0) get_store(i - 1);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (16 * 7 < mrows) get_store(7);
+  get_store(7);
   __builtin_amdgcn_s_waitcnt(0x0072);     // vmcnt(2) expcnt(7) lgkmcnt(0): a wait hipcc can see (see epilogue_w4)
 }
 

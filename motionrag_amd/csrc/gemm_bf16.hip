@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     for (int i = 0; i < RD - 1; ++i) fetch(i, i);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_barrier(0);   // one row group at a time: hipcc's scheduler otherwise hoists the accumulator reads of all eight and spills
+      __builtin_amdgcn_sched_barrier(0);   // one row group at a time (keeps the live ranges of a group's 32 accumulator reads short)
       // (row groups below the matrix are computed like the others -- their loads re-read the last valid row, only their stores are masked: every load is
       // issued and consumed unconditionally, so hipcc's vmcnt bookkeeping is exact and carries nothing pending into the K loop)
       if (i + RD - 1 < 8) fetch(i + RD - 1, (i + RD - 1) % RD);
@@ -1010,10 +1010,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     }
     __builtin_amdgcn_sched_barrier(0);
     get_store(7);
-    // a wait hipcc can SEE, for everything but the last four stores: its vmcnt bookkeeping then carries no pending load into the K loop.  (Without it
-    // the first fragment read of the loop -- inline asm that redefines registers this epilogue loaded into -- got a compiler-made `s_waitcnt vmcnt(0)` in the
-    // loop header: the DMA ring drained once per K-tile, +33 % K-loop time.)
-    __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) expcnt(7) lgkmcnt(0)
+    // (every load of this path was consumed above, so hipcc's vmcnt bookkeeping carries nothing pending into the K loop: an explicit wait here would only
+    // expose the latency of the stores just issued -- tests/test_gemm_w4_isa_cpu.py checks the compiled loop)
     return;
   }
   // ---- general path
@@ -1101,7 +1099,6 @@ __device__ __forceinline__ void epilogue_w4_geglu(const GemmP& p, char* smem, f3
   }
   __builtin_amdgcn_sched_barrier(0);
   get_store(7);
-  __builtin_amdgcn_s_waitcnt(0x0072);     // vmcnt(2) expcnt(7) lgkmcnt(0): a wait hipcc can see (see epilogue_w4)
 }
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from motionrag_amd._lib import GemmArgs  # noqa: E402
 
-L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmrag_diag.so"))
+L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("MRAG_DIAG_LIB", "libmrag_diag.so")))
 L.mrag_gemm_bf16.argtypes = [ctypes.c_void_p, ctypes.POINTER(GemmArgs)]
 SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(35552, 9216, 3072), (35552, 3072, 12288), (258048, 960, 320)]
 EPI = os.environ.get("EPI", "none")

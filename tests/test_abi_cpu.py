@@ -44,6 +44,19 @@ def test_struct_layouts_match_the_header():
         assert names == [f[0] for f in st._fields_], (cname, names)
 
 
+def test_tuning_constants_match_the_header():
+    """the developer knobs ops.py passes in `tuning` are the header's enumerators (one set of meanings on both sides of the C ABI)"""
+    import re
+    from motionrag_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mrag_hip.h")).read()
+    vals = {}
+    for name, expr in re.findall(r"(MRAG_(?:GEMM|ATTN)_TUNE_\w+)\s*=\s*([^,}/]+)", hdr):
+        vals[name] = eval(expr.strip(), {}, {})          # "8", "1 << 16"
+    for py in ("GEMM_TUNE_NO_WIDE", "GEMM_TUNE_NO_STAGED", "GEMM_TUNE_GEGLU_NO_STAGED", "GEMM_TUNE_STREAMK", "GEMM_TUNE_NO_W4",
+               "ATTN_TUNE_NO_TINY", "ATTN_TUNE_LEGACY", "ATTN_TUNE_W4PF", "ATTN_TUNE_W8PF", "ATTN_TUNE_M32", "ATTN_TUNE_M32QB1"):
+        assert vals["MRAG_" + py] == getattr(ops, py), py
+
+
 def test_ops_refuse_cpu_tensors():
     from motionrag_amd import ops, rag
     x = torch.zeros(4, 64, dtype=torch.bfloat16)

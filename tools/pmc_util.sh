@@ -1,5 +1,5 @@
 # developer tool: matrix-pipe utilisation of the two dominant kernels from rocprofv3 PMC counters (one counter per pass, kernel trace only):
-#   SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) for the joint attention and the 256x256 GEMM at the BASELINE shapes.
+#   SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) for the joint attention and the GEMMs at the BASELINE shapes (8-wave tile and, since round 3, the persistent four-wave kernel).
 # Writes gpurun_out/pmc_util/summary.json (copy to profiles/).
 export TMPDIR=/tmp
 R=$PWD
@@ -23,6 +23,8 @@ for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_W
                 key = "attn16_kernel<3,4,3,true> B=2 H=48 S=17776"
             elif "gemm_bf16_kernel<2, 4, 8, 4, 0, 0, false>" in n and r["Grid_Size"] == "2562048":
                 key = "gemm_bf16_kernel<2,4,8,4,NONE> M=35552 N=9216 K=3072"
+            elif "gemm_w4_kernel<" in n:
+                key = "gemm_w4_kernel<" + n.split("gemm_w4_kernel<")[1].split(">")[0] + "> (persistent four-wave GEMM, the DiT shapes of microbench.py gemm, averaged over its launches)"
             else:
                 continue
             acc[key].append(float(r["Counter_Value"]))

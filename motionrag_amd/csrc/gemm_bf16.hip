@@ -29,6 +29,9 @@ extern "C" int mrag_debug_set_gemm_stamp_buffer(void* p) { return (int)hipMemcpy
 #else
 #define MRAG_GSTAMP(T) do {} while (0)
 #endif
+#ifndef MRAG_W4_RESID_DEPTH
+#define MRAG_W4_RESID_DEPTH 2   // residual row groups in flight in the four-wave kernel's epilogue (developer knob: tools/build_variant.sh)
+#endif
 #ifndef MRAG_GEMM_TRACE
 #define MRAG_GEMM_TRACE 0
 #endif
@@ -963,7 +966,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
       }
       if (has_rope) { qk_fetch(0); qk_fetch(1); qk_fetch(2); }
     }
-    constexpr int RD = 2;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use; deeper rings measured no faster and cost registers)
+    constexpr int RD = MRAG_W4_RESID_DEPTH;                                               // residual row groups in flight (requested RD - 1 groups ahead of their use; deeper rings measured no faster and cost registers)
     u32x2 rr[RD][8];
     auto fetch = [&](const int i, const int slot) __attribute__((always_inline)) {
       if constexpr (HAS_R) {

@@ -129,6 +129,25 @@ def test_gemm_persistent_four_wave_kernel(hip, M, N, K):
         a16 = acc.to(torch.bfloat16).float()
         want = a16[:, :N // 2] * torch.nn.functional.gelu(a16[:, N // 2:], approximate="tanh" if tanh else "none")
         close(outs["four"], want, scale=want.abs().mean().item())
+    # two launches in flight on two streams (each wants every CU's whole LDS: the workgroups of the second fill CUs as the first one's leave): same bits
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    ops.TUNING["gemm"] = 3 << 4
+    try:
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                ops.linear(x, w, b, out=o1, epilogue=ops.EPI_GELU_TANH)
+            with torch.cuda.stream(s2):
+                ops.linear(x, w, b, out=o2, epilogue=ops.EPI_RESID, resid=r)
+    finally:
+        ops.TUNING["gemm"] = 0
+    torch.cuda.synchronize()
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_W4
+    try:
+        assert torch.equal(o1, ops.linear(x, w, b, epilogue=ops.EPI_GELU_TANH)) and torch.equal(o2, ops.linear(x, w, b, epilogue=ops.EPI_RESID, resid=r))
+    finally:
+        ops.TUNING["gemm"] = 0
     # a strided output / residual (a column block of a wider tensor) and an unaligned one (general epilogue: 8-byte stores)
     wide = torch.zeros(M, N + 136, device=DEV, dtype=torch.bfloat16)
     ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_W4

@@ -38,6 +38,17 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * (t * x));      // exp(-2u) = exp2(-2 log2(e) u)
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// the same function on two values with packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add: five vector instructions + two v_exp + two v_rcp for TWO values,
+// 4.5 issue slots per value against 7): the identical operations per value, so the identical bits.  For epilogues that one wave per SIMD issues alone.
+__device__ __forceinline__ f32x2 gelu_tanh_f2(const f32x2 x) {
+  const f32x2 c2 = {0.0356774081363001f, 0.0356774081363001f}, c1 = {0.7978845608028654f, 0.7978845608028654f};
+  const f32x2 t = __builtin_elementwise_fma(x * x, c2, c1);
+  const f32x2 z = (t * x) * -2.8853900817779268f;
+  f32x2 e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+  e = e + 1.0f;
+  const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return x * r;
+}
 // exact-erf GELU.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): one v_rcp + one v_exp + 7 FMAs
 // instead of the ~40-instruction branchy libm erff -- in a short-K GEMM (K = 320 GEGLU projections) the libm call was
 // ~20k of a workgroup's ~43k cycles.

@@ -896,8 +896,13 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
     v[0] += __uint_as_float(b2[0] << 16); v[1] += __uint_as_float(b2[0] & 0xffff0000u);
     v[2] += __uint_as_float(b2[1] << 16); v[3] += __uint_as_float(b2[1] & 0xffff0000u);
+    if constexpr (EPI == MRAG_EPI_GELU_TANH) {                          // packed form: same bits, 4.5 instead of 7 issue slots per value
+      const f32x2 lo = gelu_tanh_f2(f32x2{v[0], v[1]}), hi = gelu_tanh_f2(f32x2{v[2], v[3]});
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+      for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+    }
     if constexpr (HAS_G) {
       v[0] *= __uint_as_float(g2[0] << 16); v[1] *= __uint_as_float(g2[0] & 0xffff0000u);
       v[2] *= __uint_as_float(g2[1] << 16); v[3] *= __uint_as_float(g2[1] & 0xffff0000u);

@@ -303,6 +303,7 @@ class APAdapterAttnProcessor2_0(nn.Module):
             out = out.transpose(-1, -2).reshape(b, c, hh, ww)
             if attn.residual_connection:
                 out = ops.add(out.contiguous(), residual.contiguous())
-        if attn.rescale_output_factor != 1.0:
-            raise NotImplementedError("rescale_output_factor != 1 is not used by the SVD attn2 sites")
+        if attn.rescale_output_factor != 1.0:                                      # :139 (1.0 on every SVD attn2 site: one extra pass otherwise)
+            out = out.contiguous()
+            out = ops.axpby(out, out, 1.0 / float(attn.rescale_output_factor), 0.0)
         return out

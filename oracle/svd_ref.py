@@ -68,14 +68,32 @@ def plain_attention(w: SD, x, ctx, heads):
 
 def adapter_cross_attention(w: SD, x, image_ctx, ip_ctx, heads, scale=1.0):
     """attn_processor.py:18-141: cross-attention to the image embedding, then the motion branch whose query is
-    `to_q_ip(attention output)` (:93-100), added with `scale` (:127), then `to_out` (:129-131)."""
+    `to_q_ip(attention output)` (:93-100), keys / values repeated '(b r)' over the frames of a sample (:109-111), added with `scale`
+    (:127; skipped when 0, :93-99), then `to_out` (:129-131).
+    PINNED to the reference's own class: tests/golden/svd_attn_processor.npz (oracle/gen_golden_attn_processor.py)."""
     o = attention(linear(w.sub("to_q"), x), linear(w.sub("to_k"), image_ctx), linear(w.sub("to_v"), image_ctx), heads)
-    if ip_ctx is not None:
+    if ip_ctx is not None and scale != 0:
         p = w.sub("processor")
         ipq = F.linear(o, p("to_q_ip.0.weight"))
         ipk, ipv = F.linear(ip_ctx, p("to_k_ip.0.weight")), F.linear(ip_ctx, p("to_v_ip.0.weight"))
-        o = o + scale * attention(ipq, ipk, ipv, heads)
+        r = x.size(0) // ip_ctx.size(0)
+        o = o + scale * attention(ipq, ipk.repeat_interleave(r, dim=0), ipv.repeat_interleave(r, dim=0), heads)
     return linear(w.sub("to_out.0"), o)
+
+
+def adapter_processor_call(w: SD, hidden, image_ctx, ip_ctx, heads, scale=1.0, residual_connection=False, rescale_output_factor=1.0):
+    """the rest of `APAdapterAttnProcessor2_0.__call__`: the 4-D `[b, c, h, w]` form (:48-50, :133-134), `residual_connection` (:136-137)
+    and `rescale_output_factor` (:139)"""
+    x = hidden
+    if hidden.ndim == 4:
+        b, c, hh, ww = hidden.shape
+        x = hidden.view(b, c, hh * ww).transpose(1, 2)
+    out = adapter_cross_attention(w, x, image_ctx, ip_ctx, heads, scale)
+    if hidden.ndim == 4:
+        out = out.transpose(-1, -2).reshape(b, c, hh, ww)
+    if residual_connection:
+        out = out + hidden
+    return out / rescale_output_factor
 
 
 def feed_forward(w: SD, x):

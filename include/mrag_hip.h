@@ -154,12 +154,10 @@ typedef struct mrag_attn_args {
 } mrag_attn_args;
 enum { MRAG_ATTN_TUNE_NO_TINY = 1,   /* never take the <= 16-key one-wave-per-pair kernel          */
                                      /* 2, 4: retired (intra-wave pipelined tile, 4-wave long-sequence workgroups: measured slower, code pruned in round 3) */
-       MRAG_ATTN_TUNE_LEGACY = 8,    /* long unmasked sequences through the 32x32x16 kernel        */
-                                     /* 16, 32, 64: retired (64 rows per wave, 128-key stages)     */
-       MRAG_ATTN_TUNE_W4PF = 128,    /* attn16: 4-wave workgroups x 3 per CU, fragment prefetch    */
-       MRAG_ATTN_TUNE_W8PF = 256,    /* attn16: 32 rows per wave, 8-wave workgroups, two per CU    */
-       MRAG_ATTN_TUNE_M32 = 512,     /* attn32: the attn16 algorithm on 32x32x16, 64 rows per wave */
-       MRAG_ATTN_TUNE_M32QB1 = 1024 };/* attn32 with 32 rows per wave, three workgroups per CU      */
+       MRAG_ATTN_TUNE_LEGACY = 8 };  /* long unmasked sequences through the 32x32x16 kernel (the masked / biased path's kernel, kept
+                                        selectable so tests can compare the two families on one input)                          */
+                                     /* every other bit: retired A/B variants (ABI 8 removed 128..1024: the attn16 workgroup-shape variants and
+                                        the attn32 family now live in tools/exp/ with their measurement tables)                  */
 
 int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* args);
 
@@ -398,6 +396,12 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /* gap).  Rows with group[r] == exclude[q] are                                  */
 /* skipped (the `video != "<self>"` filter, src/data/datamodule.py:235).      */
 /* Output sorted by (dist asc, row asc); missing entries are row = -1.        */
+/* `postfilter` selects WHEN the filter applies -- lancedb's                    */
+/* `LanceQueryBuilder.where(where, prefilter=False)` (0.14.0's default, the    */
+/* form src/data/rag.py:57-58 calls): 1 = the k nearest rows are selected      */
+/* without the filter, excluded rows are then dropped and the survivors move   */
+/* up (fewer than k results possible: the tail is row -1, dist +inf);          */
+/* 0 = prefilter, excluded rows never enter the selection.                     */
 /* ------------------------------------------------------------------------ */
 /* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
  * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a
@@ -406,7 +410,7 @@ int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries);
 int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim,
                   const float* queries, const int32_t* exclude, int32_t n_queries,
                   int32_t k, int32_t metric,
-                  int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes);
+                  int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes, int32_t postfilter);
 
 /* ------------------------------------------------------------------------ */
 /* Spatio-temporal UNet denoisers (DynamiCrafter lvdm, SVD): channels-last   */

@@ -16,11 +16,11 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn32.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
-ABI_VERSION = 7
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
+ABI_VERSION = 8
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"],
-               "attn16.hip": ["-fno-slp-vectorize"], "attn32.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
+               "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -228,7 +228,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_topk_workspace_bytes.argtypes = [c_int64, c_int32]
     L.mrag_topk_workspace_bytes.restype = c_int64
     L.mrag_topk_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
-                                c_int32, c_void_p, c_void_p, c_void_p, c_int64]
+                                c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32]
     L.mrag_groupnorm_workspace_bytes.argtypes = [c_int64, c_int64, c_int32]
     L.mrag_groupnorm_workspace_bytes.restype = c_int64
     L.mrag_groupnorm_bf16.argtypes = [c_void_p, POINTER(GroupNormArgs)]

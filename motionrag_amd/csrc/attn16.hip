@@ -411,9 +411,6 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
   if ((long long)p.Skv * p.k_ss * 2 >= 0xffffffffLL || (long long)p.Skv * p.v_ss * 2 >= 0xffffffffLL) return MRAG_ENOTSUP;   // walked 32-bit DMA offsets
-  // the two developer variants tools/attn_ab.py still compares against (both without the key-split tail):
-  if (tuning & MRAG_ATTN_TUNE_W4PF) return launch16_plain<2, 4, 2>(s, p);     // 32 rows per wave, 4-wave workgroups, FOUR per CU (2-stage ring)
-  if (tuning & MRAG_ATTN_TUNE_W8PF) return launch16_plain<2, 8, 4>(s, p);     // round-2 first form: 32 rows per wave, 8-wave workgroups, two per CU
   if (pl) {
     if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 192) return MRAG_ENOTSUP;
     return launch16_split<3, 4, 3>(s, p, pl, workspace);

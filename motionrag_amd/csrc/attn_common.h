@@ -26,8 +26,6 @@ int mrag_launch_attn_combine(hipStream_t s, const AttnP& p);
 // attn16.hip: long unmasked sequences (Sq > 128, Skv >= 256) on v_mfma_f32_16x16x32_bf16; returns MRAG_ENOTSUP for shapes it does not take
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning);
 
-// attn32.hip: the same algorithm on v_mfma_f32_32x32x16_bf16 (variant 0: 64 rows per wave, 256-row workgroups; 1: 32 rows per wave, 128-row workgroups)
-int mrag_launch_attn32(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int variant);
 
 // v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max per operand
 __device__ __forceinline__ float max3_asm(float a, float b, float c) {

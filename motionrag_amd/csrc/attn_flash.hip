@@ -977,17 +977,6 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
   const bool legacy = (a->tuning & MRAG_ATTN_TUNE_LEGACY) != 0;
   const bool may_split = a->Sq > 128 && !masked && a->workspace;   // key-split tail for the ragged last query tile (plan_kv_split)
   if (may_split && ((uintptr_t)a->workspace & 15) != 0) return MRAG_EINVAL;
-  if (a->Sq > 128 && !masked && !legacy && (a->tuning & (MRAG_ATTN_TUNE_M32 | MRAG_ATTN_TUNE_M32QB1))) {   // attn32.hip: round-2 algorithm on 32x32x16
-    const bool qb1 = (a->tuning & MRAG_ATTN_TUNE_M32QB1) != 0;
-    SplitPlan pl;
-    bool split = false;
-    if (may_split && !qb1) {
-      pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, 256, 512);
-      split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
-    }
-    const int rc = mrag_launch_attn32(s, p, split ? &pl : nullptr, a->workspace, qb1 ? 1 : 0);
-    if (rc != MRAG_ENOTSUP) return rc;
-  }
   if (a->Sq > 128 && !masked && !legacy) {        // long unmasked sequences: the 16x16x32 family (attn16.hip), 192-row workgroups
     SplitPlan pl;
     bool split = false;

@@ -14,7 +14,10 @@
 //     reversed batch, then one bitonic merge); batches that cannot enter the current top-k are
 //     skipped with one ballot;
 //   * order is (distance asc, row asc) -> deterministic ties; excluded rows (`video != self`)
-//     and padding carry distance +inf / row INT_MAX and come out as row -1.
+//     and padding carry distance +inf / row INT_MAX and come out as row -1;
+//   * filter order (lancedb's `where(filter, prefilter=...)`): prefilter -> excluded rows never enter the selection (k results whenever k
+//     rows pass); postfilter (lancedb 0.14.0's default) -> the k nearest rows are selected WITHOUT the filter, the excluded ones are then
+//     dropped from that list and the survivors move up (possibly fewer than k results; the tail is row -1 / +inf).
 #include "common.h"
 #include "../../include/mrag_hip.h"
 #include <limits.h>
@@ -74,6 +77,7 @@ struct TopkP {
   const float* db; const int* group; const float* q; const int* excl;
   Cand* ws; int* out_rows; float* out_dist;
   long long n_rows; int dim, nq, k, metric, slices, rows_per_slice;
+  const int* post_group;  // postfilter: group ids consulted AFTER selection (then `group` above is null and the scan excludes nothing)
   unsigned* tickets;    // FUSED: one arrival counter per query tile (zero between calls)
   int wpb;              // waves per workgroup: always 4 (small databases spread by giving each WAVE 16 rows instead of 64: small_db())
 };
@@ -321,7 +325,22 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   __syncthreads();
   if (wave == 0) {
     for (int w = 1; w < nw; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
-    if (lane < p.k) {
+    if (p.post_group) {
+      // lancedb's postfilter: the k nearest are final; rows of the excluded group leave the list, the rest keep their order and move up
+      const bool ok = lane < p.k && run.r != INT_MAX;
+      const bool keep = ok && p.post_group[ok ? run.r : 0] != p.excl[q];
+      const unsigned long long m = __ballot(keep);
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      const int kept = __popcll(m);
+      if (keep) {
+        p.out_rows[(long long)q * p.k + pos] = run.r;
+        p.out_dist[(long long)q * p.k + pos] = run.d;
+      }
+      if (lane >= kept && lane < p.k) {
+        p.out_rows[(long long)q * p.k + lane] = -1;
+        p.out_dist[(long long)q * p.k + lane] = INFINITY;
+      }
+    } else if (lane < p.k) {
       const bool ok = run.r != INT_MAX;
       p.out_rows[(long long)q * p.k + lane] = ok ? run.r : -1;
       p.out_dist[(long long)q * p.k + lane] = run.d;
@@ -368,7 +387,7 @@ extern "C" int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries) 
 
 extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim, const float* queries,
                              const int32_t* exclude, int32_t n_queries, int32_t k, int32_t metric, int32_t* out_rows, float* out_dist,
-                             void* workspace, int64_t workspace_bytes) {
+                             void* workspace, int64_t workspace_bytes, int32_t postfilter) {
   if (!db || !queries || !out_rows || !out_dist || !workspace) return MRAG_EINVAL;
   if (n_rows <= 0 || n_rows > INT_MAX - 1 || n_queries <= 0 || dim <= 0) return MRAG_EINVAL;
   if (k <= 0 || k > 64) return MRAG_ENOTSUP;
@@ -378,7 +397,9 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   if (((uintptr_t)db | (uintptr_t)queries) & 15) return MRAG_EINVAL;
   if (workspace_bytes < mrag_topk_workspace_bytes(n_rows, n_queries)) return MRAG_EINVAL;
   TopkP p{};
-  p.db = db; p.group = exclude ? group : nullptr; p.q = queries; p.excl = exclude;
+  if (postfilter != 0 && postfilter != 1) return MRAG_EINVAL;
+  const bool post = postfilter && exclude;
+  p.db = db; p.group = (exclude && !post) ? group : nullptr; p.post_group = post ? group : nullptr; p.q = queries; p.excl = exclude;
   p.tickets = (unsigned*)workspace; p.ws = (Cand*)((char*)workspace + kTicketBytes); p.out_rows = out_rows; p.out_dist = out_dist;
   p.n_rows = n_rows; p.dim = dim; p.nq = n_queries; p.k = k; p.metric = metric;
   plan(n_rows, n_queries, &p.slices, &p.rows_per_slice);

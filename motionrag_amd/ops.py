@@ -22,8 +22,7 @@ LOG2E = 1.4426950408889634
 # Nothing on the launch path reads the environment.
 TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
-ATTN_TUNE_NO_TINY, ATTN_TUNE_LEGACY, ATTN_TUNE_W4PF, ATTN_TUNE_W8PF = 1, 8, 128, 256
-ATTN_TUNE_M32, ATTN_TUNE_M32QB1 = 512, 1024
+ATTN_TUNE_NO_TINY, ATTN_TUNE_LEGACY = 1, 8
 
 
 class HipOnly(RuntimeError):
@@ -538,9 +537,10 @@ def topk_workspace(device: torch.device, N: int, Q: int) -> torch.Tensor:
 
 
 def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None,
-         exclude: Optional[torch.Tensor] = None, out: Optional[tuple] = None):
+         exclude: Optional[torch.Tensor] = None, out: Optional[tuple] = None, postfilter: bool = False):
     """flat-scan top-k: returns (rows int32 [Q, k], dist fp32 [Q, k]) sorted by (dist asc, row asc).  `out` = (rows, dist) buffers to fill
-    (a caller that searches repeatedly keeps them: no allocation on the call path)."""
+    (a caller that searches repeatedly keeps them: no allocation on the call path).  `postfilter`: rows of the excluded group are dropped
+    AFTER the k nearest were selected (lancedb's `where(..., prefilter=False)`; possibly < k results, tail row -1) instead of before."""
     _dev(db, torch.float32, "db"); _dev(queries, torch.float32, "queries")
     if not db.is_contiguous() or not queries.is_contiguous():
         raise ValueError("topk: contiguous db / queries required")
@@ -560,7 +560,7 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
         if tuple(rows.shape) != (Q, k) or tuple(dist.shape) != (Q, k) or rows.dtype != torch.int32 or dist.dtype != torch.float32:
             raise ValueError("topk: out = (int32 [Q, k], float32 [Q, k])")
     check(_lib.lib().mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
-                                   _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws.numel()), "mrag_topk_f32")
+                                   _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws.numel(), int(bool(postfilter))), "mrag_topk_f32")
     return rows, dist
 
 
@@ -570,7 +570,8 @@ class TopkPlan:
     allocated on the call path (the latency-bound interactive search of src/data/rag.py:63-80: 10 k rows stream in ~7 us, everything above
     that was host overhead).  `graph=True` additionally records the launch in a HIP graph (`replay()`)."""
 
-    def __init__(self, db: torch.Tensor, n_queries: int, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None, graph: bool = False):
+    def __init__(self, db: torch.Tensor, n_queries: int, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None, graph: bool = False,
+                 postfilter: bool = False):
         _dev(db, torch.float32, "db")
         if not db.is_contiguous():
             raise ValueError("TopkPlan: contiguous db required")
@@ -585,7 +586,7 @@ class TopkPlan:
         self._ws = torch.zeros(L.mrag_topk_workspace_bytes(N, n_queries), dtype=torch.uint8, device=dev)   # private: counters stay consistent
         self._fn = L.mrag_topk_f32
         self._args = (_p(db), _p(group) if group is not None else None, N, D, _p(self.queries), _p(self.exclude) if group is not None else None,
-                      n_queries, k, {"l2": 0, "dot": 1}[metric], _p(self.rows), _p(self.dist), _p(self._ws), self._ws.numel())
+                      n_queries, k, {"l2": 0, "dot": 1}[metric], _p(self.rows), _p(self.dist), _p(self._ws), self._ws.numel(), int(bool(postfilter)))
         self._graph = None
         if graph:
             self.run()

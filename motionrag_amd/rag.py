@@ -14,7 +14,18 @@ chunks (the host never holds a second copy), and the reference's row schema as a
 and read LAZILY -- only the `video` column is touched when the table opens (dictionary-encoded into the int32 group ids
 of the `video != self` filter); result rows are `take`n from the mapped columns.  Sized for what the scan was measured
 at (10^7 rows: 30.7 GB of vectors, no per-row Python objects); tables written by round 2 (`meta.json`) still open.
-Scoring: libmrag_hip.so's `mrag_topk_f32` (sequential-fmaf distances, deterministic ties).  Text
+Scoring: libmrag_hip.so's `mrag_topk_f32` (sequential-fmaf distances, deterministic ties).
+
+Filter order.  The reference builds `table.search(v).limit(k)...where(where)` (src/data/rag.py:54-58), i.e. lancedb 0.14.0's
+`LanceQueryBuilder.where(where, prefilter=False)` (lancedb/query.py of that release: "prefilter: bool, default False -- if True, apply the
+filter before vector search, otherwise the filter is applied on the result of vector search"; the default only became True in later
+releases).  That is a POST-filter: the k nearest rows are taken first, rows failing `video != "<self>"` are then dropped, and FEWER than k
+rows can come back.  `RAGDatabase(prefilter=False)` (the default) reproduces this order in the kernel's final merge; `prefilter=True`
+excludes rows before selection (always k results while k rows pass).  lancedb is not installed here, so the default is cited, not executed:
+if a deployment's lancedb applies the filter first, construct with `prefilter=True`.  The reference over-fetches `ref_video_num + 3`
+(datamodule.py:234) and keeps the first `ref_video_num` (dataset.py:296): the two orders differ for a query only when more than 3 of its 12
+nearest rows are clips of its own video; `get_ref_videos` then pads with zero videos (and, like the reference, a shorter distance list).
+Text
 inputs need an `embedder` callable (text -> [D] fp32); the shipped data path always passes embeddings
 (datamodule.py:233 hands `anno['text_embedding']`).
 """
@@ -111,16 +122,19 @@ class RAGDatabase:
     """src/data/rag.py:11-15; `metric` is LanceDB's: 'l2' (its default without an index; `_distance` is the squared
     L2 distance) or 'dot' (`_distance = 1 - dot`, the metric of the index build_rag_database.py:52 creates)."""
 
-    def __init__(self, db_path: str, table_name: str, device: str = "cuda", metric: str = "l2", embedder: Optional[Callable] = None):
+    def __init__(self, db_path: str, table_name: str, device: str = "cuda", metric: str = "l2", embedder: Optional[Callable] = None,
+                 prefilter: bool = False):
+        self.prefilter = bool(prefilter)          # lancedb's `where(..., prefilter=)`; False = its 0.14.0 default (module docstring)
         tdir = os.path.join(db_path, table_name)
         self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"), mmap_mode="c")      # a copy-on-write view of the file (never written): pages stream through on upload
         self.meta = _read_meta(tdir)
         self._init_device(device, metric, embedder)
 
     @classmethod
-    def from_arrays(cls, vectors: np.ndarray, rows, device: str = "cuda", metric: str = "l2", embedder=None) -> "RAGDatabase":
+    def from_arrays(cls, vectors: np.ndarray, rows, device: str = "cuda", metric: str = "l2", embedder=None, prefilter: bool = False) -> "RAGDatabase":
         """`rows`: list of row dicts in the reference's schema, or an Arrow table with those columns"""
         self = cls.__new__(cls)
+        self.prefilter = bool(prefilter)
         self.vectors_host = vectors if (isinstance(vectors, np.ndarray) and vectors.dtype == np.float32) else np.ascontiguousarray(vectors, dtype=np.float32)
         self.meta = _rows_to_table(rows) if isinstance(rows, list) else rows
         self._init_device(device, metric, embedder)
@@ -214,8 +228,10 @@ class RAGDatabase:
         return np.ascontiguousarray(text, dtype=np.float32).reshape(-1)
 
     def text_search_batch(self, embeddings, top_k: int = 10, where: Optional[Sequence[Optional[str]]] = None,
-                          select: Optional[Sequence[str]] = None, output_format: str = "dict"):
-        """all queries of datamodule.py:231-236 in one launch: embeddings [Q, D]; `where` one filter per query."""
+                          select: Optional[Sequence[str]] = None, output_format: str = "dict", prefilter: Optional[bool] = None):
+        """all queries of datamodule.py:231-236 in one launch: embeddings [Q, D]; `where` one filter per query.  `prefilter` overrides the
+        database's filter order for this call (None = `self.prefilter`); with the post-filter a query may return fewer than `top_k` rows."""
+        post = not (self.prefilter if prefilter is None else prefilter)
         if isinstance(embeddings, torch.Tensor):
             q = embeddings.to(self.device, torch.float32).contiguous()
         else:
@@ -228,11 +244,11 @@ class RAGDatabase:
         if Q <= 4 and top_k <= 64:       # the interactive search (rag.py:63-80): a prepared plan -- one C-ABI call = one launch, no allocation
             # a plan owns its workspace, arrival counters included: one per (Q, k, STREAM) so that searches issued from different streams never share
             # counters, and a lock so that two host threads on one stream cannot interleave the copy-in / launch / read-out of one plan
-            key = (Q, top_k, torch.cuda.current_stream(self.device).cuda_stream)
+            key = (Q, top_k, torch.cuda.current_stream(self.device).cuda_stream, post)
             with self._lock:
                 plan = self._plans.get(key)
                 if plan is None:
-                    plan = self._plans[key] = ops.TopkPlan(self.vectors, Q, top_k, metric=self.metric, group=self.group)
+                    plan = self._plans[key] = ops.TopkPlan(self.vectors, Q, top_k, metric=self.metric, group=self.group, postfilter=post)
                 plan.queries.copy_(q)
                 if exclude is not None:
                     plan.exclude.copy_(exclude)
@@ -242,12 +258,13 @@ class RAGDatabase:
                 rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
             return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
         else:
-            rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude)
+            rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude, postfilter=post)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
         return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
 
     def vector_search(self, vector, vector_column_name: str = None, top_k: int = 10, table=None, where: str = None,
-                      select: List[str] = None, nprobes: int = 50, refine_factor: int = 30, output_format: str = "dict"):
+                      select: List[str] = None, nprobes: int = 50, refine_factor: int = 30, output_format: str = "dict",
+                      prefilter: Optional[bool] = None):
         """rag.py:36-61 (flat scan: nprobes / refine_factor only matter for LanceDB's IVF index and are accepted for
         signature compatibility)."""
         if vector_column_name not in (None, "text_embedding"):
@@ -255,13 +272,13 @@ class RAGDatabase:
         if table is not None:
             raise NotImplementedError("temporary tables are only used by text_image_search (not on the shipped path)")
         emb = self._embed(vector)[None]
-        return self.text_search_batch(emb, top_k, [where], select, output_format)[0]
+        return self.text_search_batch(emb, top_k, [where], select, output_format, prefilter=prefilter)[0]
 
     def text_search(self, text, top_k: int = 10, table=None, where: str = None, select: List[str] = None, nprobes: int = 50,
-                    refine_factor: int = 30, output_format: str = "dict"):
-        """rag.py:63-80"""
+                    refine_factor: int = 30, output_format: str = "dict", prefilter: Optional[bool] = None):
+        """rag.py:63-80 (`prefilter`: not a reference argument; None = the database's filter order)"""
         return self.vector_search(text, vector_column_name="text_embedding", top_k=top_k, table=table, where=where, select=select,
-                                  nprobes=nprobes, refine_factor=refine_factor, output_format=output_format)
+                                  nprobes=nprobes, refine_factor=refine_factor, output_format=output_format, prefilter=prefilter)
 
 
 # ---------------------------------------------------------------------------------------------- callers either side of the search

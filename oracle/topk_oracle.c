@@ -8,9 +8,13 @@
  * index (tools/build_rag_database.py:51-52 only builds one above 1 M rows) every row is scored and the
  * k smallest distances are returned in ascending order; `_distance` is the squared L2 distance (LanceDB
  * default metric "l2") or 1 - dot for metric "dot" (the metric the reference's index uses).  The
- * `where` prefilter removes rows before selection (the caller over-fetches k+3 and keeps k:
- * src/data/datamodule.py:234, src/data/dataset.py:296).  PARITY UNPINNED against LanceDB itself: the
- * reference holds no test or golden vector for retrieval.
+ * Filter order: lancedb's `LanceQueryBuilder.where(where, prefilter=False)` -- the call src/data/rag.py:57-58 makes with 0.14.0's default --
+ * applies the filter to the RESULT of the vector search (postfilter = 1 below: the k nearest rows are selected, rows failing the filter
+ * are dropped, fewer than k rows may remain); `prefilter=True` removes rows before selection (postfilter = 0).  Both are restated; the
+ * caller over-fetches k+3 and keeps k (src/data/datamodule.py:234, src/data/dataset.py:296), so the two orders give the same first 9 rows
+ * unless more than 3 of the 12 nearest rows belong to the query's own video.  PARITY UNPINNED against LanceDB itself: the reference holds
+ * no test or golden vector for retrieval, and lancedb is not installed here (the default is cited from the 0.14.0 package's
+ * `lancedb/query.py`, `def where(self, where: str, prefilter: bool = False)`).
  *
  * Two scoring modes:
  *   mode 0: float32, 16 interleaved fmaf chains + a fixed pairwise tree (chain16 below) -- the exact evaluation
@@ -65,7 +69,7 @@ static double score(const float* q, const float* x, int dim, int metric, int mod
 
 /* out_rows [nq, k] int32, out_dist [nq, k] double */
 int topk_oracle(const float* db, const int32_t* group, int64_t n_rows, int dim, const float* queries, const int32_t* exclude,
-                int nq, int k, int metric, int mode, int32_t* out_rows, double* out_dist) {
+                int nq, int k, int metric, int mode, int postfilter, int32_t* out_rows, double* out_dist) {
   if (k <= 0 || n_rows <= 0 || nq <= 0) return -1;
   cand_t* best = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
   if (!best) return -2;
@@ -73,13 +77,19 @@ int topk_oracle(const float* db, const int32_t* group, int64_t n_rows, int dim, 
     int nb = 0;
     const float* q = queries + (size_t)qi * dim;
     for (int64_t r = 0; r < n_rows; ++r) {
-      if (exclude && group && group[r] == exclude[qi]) continue;
+      if (!postfilter && exclude && group && group[r] == exclude[qi]) continue;
       cand_t c; c.d = score(q, db + (size_t)r * dim, dim, metric, mode); c.r = (int32_t)r;
       if (nb == k && !cand_less(c, best[k - 1])) continue;
       int pos = nb < k ? nb : k - 1;           /* insertion into the sorted list */
       while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
       best[pos] = c;
       if (nb < k) ++nb;
+    }
+    if (postfilter && exclude && group) {        /* drop the excluded rows from the selected list; survivors keep their order */
+      int w = 0;
+      for (int j = 0; j < nb; ++j)
+        if (group[best[j].r] != exclude[qi]) best[w++] = best[j];
+      nb = w;
     }
     for (int j = 0; j < k; ++j) {
       out_rows[(size_t)qi * k + j] = j < nb ? best[j].r : -1;

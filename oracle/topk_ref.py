@@ -19,9 +19,10 @@ def build() -> str:
     return _SO
 
 
-def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, mode: str = "f32chain"):
+def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, mode: str = "f32chain",
+         postfilter: bool = False):
     """returns (rows int32 [Q, k], dist float64 [Q, k]); mode 'f32chain' (bit-comparable with the HIP
-    kernel) or 'f64'."""
+    kernel) or 'f64'.  `postfilter`: lancedb's `where(..., prefilter=False)` order (topk_oracle.c header)."""
     lib = ctypes.CDLL(build())
     db = np.ascontiguousarray(db, dtype=np.float32)
     queries = np.ascontiguousarray(queries, dtype=np.float32)
@@ -35,17 +36,24 @@ def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=
         exclude = np.ascontiguousarray(exclude, dtype=np.int32)
         gp, ep = group.ctypes.data_as(ctypes.c_void_p), exclude.ctypes.data_as(ctypes.c_void_p)
     lib.topk_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     rc = lib.topk_oracle(db.ctypes.data_as(ctypes.c_void_p), gp, n, d, queries.ctypes.data_as(ctypes.c_void_p), ep, q, k,
-                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1}[mode], rows.ctypes.data_as(ctypes.c_void_p),
+                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1}[mode], int(bool(postfilter)), rows.ctypes.data_as(ctypes.c_void_p),
                          dist.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
         raise RuntimeError(f"topk_oracle rc={rc}")
     return rows, dist
 
 
-def topk_numpy(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None):
+def topk_numpy(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, postfilter: bool = False):
     """float64 numpy restatement (small cases): stable argsort on (dist, row)."""
+    if postfilter and exclude is not None:
+        rows, d = topk_numpy(db, queries, k, metric)                 # the k nearest, unfiltered ...
+        out_r, out_d = np.full_like(rows, -1), np.full_like(d, np.inf)
+        for qi in range(rows.shape[0]):                              # ... then the filter; survivors move up
+            keep = [j for j in range(k) if rows[qi, j] >= 0 and np.asarray(group)[rows[qi, j]] != np.asarray(exclude)[qi]]
+            out_r[qi, :len(keep)], out_d[qi, :len(keep)] = rows[qi, keep], d[qi, keep]
+        return out_r, out_d
     db64, q64 = db.astype(np.float64), queries.astype(np.float64)
     if metric == "l2":
         dist = ((q64[:, None, :] - db64[None, :, :]) ** 2).sum(-1)

@@ -407,60 +407,6 @@ def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
     close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)           # the two kernel families agree to a bf16 ulp or two
 
 
-@pytest.mark.parametrize("variant", ["M32", "M32QB1"])
-def test_attention32_family_matches_reference_and_attn16(hip, variant):
-    """attn32.hip: the attn16 algorithm (max as the MFMA's C operand, lazy re-centre, P from accumulators to B operand) on 32x32x16 -- a developer
-    A/B variant.  Same forced branches as the attn16 test (finite blow-up, inf, a spike inside the slid-back ragged last
-    stage, low first tile), plus ragged query tiles, a fused residual, kv batch repeat, and the key-split tail of the 256-row variant"""
-    from motionrag_amd import ops
-    tune = getattr(ops, "ATTN_TUNE_" + variant)
-    g = torch.Generator().manual_seed(18)
-    B, H, Sq, Skv = 1, 2, 300, 1000
-    q, k, v = (torch.randn(B, S, H, 64, generator=g) for S in (Sq, Skv, Skv))
-    k[:, :64] -= 3.0 * q[:, :1].mean(dim=1, keepdim=True)
-    unit = lambda r: q[:, r] / q[:, r].norm(dim=-1, keepdim=True)
-    k[:, 300] = 20.0 * unit(7)
-    k[:, 700] = 104.0 * unit(200)
-    k[:, 701] = 21.5 * unit(7)
-    k[:, 990] = 45.0 * unit(290)
-    k[:, 40] = 30.0 * unit(100)          # a spike in the SECOND 32-key block of the very first stage (re-centre right after the first block fixed m)
-    q, k, v = bf(q), bf(k), bf(v)
-    q_r = bf(q * (0.125 * 1.4426950408889634)) / (0.125 * 1.4426950408889634)
-    base = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
-    ops.TUNING["attn"] = tune
-    try:
-        got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
-        close(got, sdpa_ref(q_r, k, v), scale=0.3, rtol=3e-2, atol_frac=0.15)        # one more forced spike than the attn16 test: 0.0395 on one element of 38 400 (bf16 Q', bf16 P)
-        close(got, base.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)
-        # plain random shapes: ragged query tiles / key stages, strided fused-QKV views, fused residual with a repeated K / V batch
-        for (b, h, sq, skv) in ((2, 3, 300, 300), (1, 2, 1000, 777), (1, 1, 257, 258)):
-            gq = torch.Generator().manual_seed(b * 100 + sq)
-            qq, kk, vv = (bf(torch.randn(b, S, h, 64, generator=gq)) for S in (sq, skv, skv))
-            close(ops.attention(qq.to(DEV), kk.to(DEV), vv.to(DEV)), sdpa_ref(qq, kk, vv), scale=0.3)
-        qkv = bf(torch.randn(4, 333, 3, 3, 64, generator=g)).to(DEV)
-        kv = bf(torch.randn(2, 320, 2, 3, 64, generator=g))
-        resid = bf(torch.randn(4, 333, 192, generator=g))
-        out = ops.attention(qkv[:, :, 0], kv[:, :, 0].to(DEV), kv[:, :, 1].to(DEV), resid=resid.to(DEV), kv_batch_div=2, out_scale=0.75)
-        close(out, resid.float() + 0.75 * sdpa_ref(qkv[:, :, 0].cpu(), kv[:, :, 0], kv[:, :, 1], kv_div=2), scale=1.0)
-        # key-split tail (256-row variant): 64 x 256 + 112 rows; the tail rows equal the reference and the unsplit launch to a bf16 ulp or two
-        B2, H2, Sq2, Skv2 = 1, 16, 64 * 256 + 112, 4200
-        q2 = bf(torch.randn(B2, Sq2, H2, 64, generator=g))
-        k2, v2 = (bf(torch.randn(B2, Skv2, H2, 64, generator=g)) for _ in range(2))
-        k2[:, 3000] = bf(9.0 * q2[:, Sq2 - 5] / q2[:, Sq2 - 5].norm(dim=-1, keepdim=True))
-        rows = torch.cat([torch.arange(Sq2 - 112, Sq2), torch.randint(0, Sq2 - 112, (80,), generator=g)])
-        want = sdpa_ref(q2[:, rows], k2, v2)
-        outs = {}
-        for nosplit in (False, True):
-            ops.TUNING["attn_no_split"] = nosplit
-            outs[nosplit] = ops.attention(q2.to(DEV), k2.to(DEV), v2.to(DEV))
-            close(outs[nosplit][:, rows.to(DEV)], want, scale=0.05, rtol=3e-2, atol_frac=5e-2)
-        assert torch.equal(outs[False][:, :Sq2 - 112], outs[True][:, :Sq2 - 112])
-        if variant == "M32":
-            assert not torch.equal(outs[False][:, Sq2 - 112:], outs[True][:, Sq2 - 112:])         # the tail really took the key-split path
-    finally:
-        ops.TUNING["attn"], ops.TUNING["attn_no_split"] = 0, False
-
-
 def test_attention_large_sequence_properties(hip):
     """BASELINE-size sequence (S = 17 776, the CogVideoX joint length), checked through size-independent properties:
     (1) with V = ones the output is exactly 1 (softmax rows sum to one); (2) permuting the keys/values does not change
@@ -667,6 +613,42 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
     np.testing.assert_array_equal(rows2.cpu().numpy(), topk_ref.topk(db, q, k, metric)[0])
 
 
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("Q", [1, 3, 5, 40])
+def test_topk_filter_order_bit_exact(hip, metric, Q):
+    """lancedb's post-filter (`where(..., prefilter=False)`: the k nearest first, then the filter) and the pre-filter against the C oracle in the
+    matching mode, bit for bit, on a database with 6 clips per video where the two orders give different lists; Q = 1 / 3 run the fused
+    single-launch form, 5 the query-tile scan + merge kernel, 40 the 16-query tiles"""
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    from test_oracle_golden import multi_clip_db
+    rng = np.random.default_rng(100 + Q)
+    db, group = multi_clip_db(rng, n_videos=200, clips=6, dim=128)
+    own = rng.integers(0, 200, Q).astype(np.int32)
+    q = (db[own * 6 + 1] + 0.01 * rng.standard_normal((Q, 128))).astype(np.float32)
+    if Q >= 5:
+        own[-1] = 777                        # an id no row carries: nothing is excluded in either order
+    dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, own))
+    lists = {}
+    for post in (False, True):
+        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32chain", postfilter=post)
+        rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post)
+        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+        lists[post] = rows.cpu().numpy()
+    assert (lists[False] >= 0).all()
+    short = (lists[True] >= 0).sum(axis=1)
+    assert short[0] == 6 and (short <= 12).all()                                          # 6 of the 12 nearest were the query's own video
+    if Q >= 5:
+        assert short[-1] == 12 and np.array_equal(lists[True][-1], lists[False][-1])
+    # a prepared plan (the interactive path) in post-filter order gives the same list
+    if Q <= 4:
+        plan = ops.TopkPlan(dbd, Q, 12, metric=metric, group=gd, postfilter=True)
+        plan.queries.copy_(qd); plan.exclude.copy_(ed)
+        r, _ = plan.run()
+        np.testing.assert_array_equal(r.cpu().numpy(), lists[True])
+
+
 def test_topk_ties_and_short_results(hip):
     from motionrag_amd import ops
     db = np.zeros((40, 32), dtype=np.float32)
@@ -679,6 +661,9 @@ def test_topk_ties_and_short_results(hip):
                           exclude=torch.tensor([0, 5], dtype=torch.int32, device=DEV))
     assert rows.cpu().tolist() == [[38, 39, -1, -1], [0, 1, 2, 4]]
     assert torch.isinf(dist[0, 2:]).all()
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 4, group=group.to(DEV),
+                          exclude=torch.tensor([0, 5], dtype=torch.int32, device=DEV), postfilter=True)
+    assert rows.cpu().tolist() == [[-1, -1, -1, -1], [0, 1, 2, 4]] and torch.isinf(dist[0]).all()      # the 4 nearest all carry the excluded id
 
 
 def test_topk_baseline_size(hip):

@@ -324,13 +324,19 @@ def test_rag_database_text_search(hip, tmp_path):
     rows = rag.prepare_annotations(annos, text_name="motion_caption", dataset_name="openvid")
     rag.add_to_db(rows[:1000], emb[:1000], text_name="motion_caption", db_path=str(tmp_path / "openvid.db"))
     rag.add_to_db(rows[1000:], emb[1000:], text_name="motion_caption", db_path=str(tmp_path / "openvid.db"))     # chunked append
-    db = rag.RAGDatabase(str(tmp_path / "openvid.db"), "motion_caption", device="cuda")
+    db = rag.RAGDatabase(str(tmp_path / "openvid.db"), "motion_caption", device="cuda", prefilter=True)
     assert len(db) == N
     q = emb[10] + 0.01 * rng.standard_normal(D).astype(np.float32)
     res = db.text_search(text=q, top_k=12, where='video != "v5.mp4"', select=["video", "start_sec", "end_sec"])
     group = np.array([i // 2 for i in range(N)], dtype=np.int32)
     want_r, want_d = topk_ref.topk(emb, q[None], 12, "l2", group, np.array([5], np.int32))
     assert [r["start_sec"] for r in res] == [float(i) for i in want_r[0]]
+    # lancedb 0.14.0's order (the default of RAGDatabase): the 12 nearest first, then the filter -> the query's own clip leaves 11 rows
+    post = rag.RAGDatabase(str(tmp_path / "openvid.db"), "motion_caption", device="cuda").text_search(text=q, top_k=12, where='video != "v5.mp4"', select=["start_sec"])
+    pr, pd = topk_ref.topk(emb, q[None], 12, "l2", group, np.array([5], np.int32), postfilter=True)
+    assert len(post) == 11 and [r["start_sec"] for r in post] == [float(i) for i in pr[0][:11]]
+    np.testing.assert_array_equal(np.array([r["_distance"] for r in post], dtype=np.float32), pd[0][:11].astype(np.float32))
+    assert db.text_search(text=q, top_k=12, where='video != "v5.mp4"', select=["start_sec"], prefilter=False) == post       # per-call override
     assert set(res[0].keys()) == {"video", "start_sec", "end_sec", "_distance"}
     np.testing.assert_array_equal(np.array([r["_distance"] for r in res], dtype=np.float32), want_d[0].astype(np.float32))
     assert all(r["video"] != "v5.mp4" for r in res)
@@ -369,7 +375,7 @@ def test_rag_database_million_rows_memory_mapped(hip, tmp_path):
     with pa.OSFile(str(tdir / "meta.arrow"), "wb") as sink, pa.ipc.new_file(sink, table.schema) as w:
         w.write_table(table)
     del table, videos
-    db = rag.RAGDatabase(str(tmp_path / "big.db"), "motion_caption", device="cuda")
+    db = rag.RAGDatabase(str(tmp_path / "big.db"), "motion_caption", device="cuda", prefilter=True)
     assert len(db) == N and isinstance(db.vectors_host, np.memmap) and db.group.shape == (N,) and int(db.group[-1]) == (N - 1) // 3
     q = np.asarray(vec[123_456]) + 0.01 * rng.standard_normal(D).astype(np.float32)
     res = db.text_search(text=q, top_k=12, where='video != "v41152.mp4"', select=["id", "video"])          # 123 456 // 3 = 41 152: the query's own video
@@ -379,6 +385,9 @@ def test_rag_database_million_rows_memory_mapped(hip, tmp_path):
     want_r, want_d = topk_ref.topk(np.asarray(vec), q[None], 12, "l2", group, np.array([41152], np.int32))
     assert [r["id"] for r in res] == [int(i) for i in want_r[0]]
     np.testing.assert_array_equal(np.array([r["_distance"] for r in res], dtype=np.float32), want_d[0].astype(np.float32))
+    post = db.text_search(text=q, top_k=12, where='video != "v41152.mp4"', select=["id"], prefilter=False)   # lancedb's post-filter: row 123 456 itself leaves the list
+    pr, _ = topk_ref.topk(np.asarray(vec), q[None], 12, "l2", group, np.array([41152], np.int32), postfilter=True)
+    assert [r["id"] for r in post] == [int(i) for i in pr[0] if i >= 0] and len(post) == 11
     assert db.text_search(text=np.asarray(vec[999_999]), top_k=1)[0]["id"] == 999_999                      # the last chunk of the upload landed
 
 

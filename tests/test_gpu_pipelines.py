@@ -249,7 +249,7 @@ def test_retrieval_consumer_contract_and_fan_out(hip):
     annos = rag.synthetic_captions(600)
     embed = rag.hash_embedder(768)
     emb = np.stack([embed(a["motion_caption"]) for a in annos])
-    db = rag.RAGDatabase.from_arrays(emb, rag.prepare_annotations(annos, "motion_caption", "openvid"))
+    db = rag.RAGDatabase.from_arrays(emb, rag.prepare_annotations(annos, "motion_caption", "openvid"), prefilter=True)
     for a, e in zip(annos, emb):
         a["text_embedding"] = e
     rag.attach_ref_videos(annos, db, ref_video_num=9, chunk=256)
@@ -271,6 +271,46 @@ def test_retrieval_consumer_contract_and_fan_out(hip):
     assert refs[0, 0, 0, 0, 0].item() == float(int(a["ref_videos"][0]["video"][5:11]))
     refs, dist = rag.get_ref_videos(a, video, load_clip, ref_video_num=9, uncond_video_ratio=1.0)        # all references dropped
     assert dist == [1.0] * 9 and refs.abs().max().item() == 0
+
+
+def test_retrieval_filter_order_on_multi_clip_videos(hip):
+    """src/data/rag.py:54-58 on a table with 6 clips per video (the multi-clip datasets MotionRAG retrieves from): lancedb 0.14.0 applies
+    `video != "<self>"` AFTER taking the K + 3 = 12 nearest rows, so a query whose own video fills 5 of them gets 7 references, not 9;
+    `get_ref_videos` (dataset.py:285-312) then leaves zero videos in the unused slots and a distance list as long as the rows it was handed.
+    Both filter orders bit-exact against the C oracle in the matching mode."""
+    from motionrag_amd import rag
+    from oracle import topk_ref
+    from test_oracle_golden import multi_clip_db
+    rng = np.random.default_rng(5)
+    emb, group = multi_clip_db(rng, n_videos=120, clips=6, dim=768, spread=0.02)
+    annos = [{"motion_caption": f"clip {i}", "id": i, "video": f"video_{i // 6:04d}.mp4", "start_sec": float(4 * (i % 6)), "end_sec": float(4 * (i % 6) + 4)}
+             for i in range(len(emb))]
+    rows = rag.prepare_annotations(annos, "motion_caption", "openvid")
+    queries = [dict(a, text_embedding=emb[a["id"]]) for a in annos[3::97]]          # the query clips are themselves rows of the table
+    own = np.array([a["id"] // 6 for a in queries], np.int32)
+    q = np.stack([a["text_embedding"] for a in queries])
+    got = {}
+    for pre in (False, True):
+        db = rag.RAGDatabase.from_arrays(emb, rows, prefilter=pre)
+        qa = [dict(a) for a in queries]
+        rag.attach_ref_videos(qa, db, ref_video_num=9)
+        want_r, want_d = topk_ref.topk(emb, q, 12, "l2", group, own, mode="f32chain", postfilter=not pre)
+        for a, wr, wd in zip(qa, want_r, want_d):
+            keep = wr >= 0
+            assert [(r["video"], r["start_sec"]) for r in a["ref_videos"]] == [(annos[i]["video"], annos[i]["start_sec"]) for i in wr[keep]]
+            np.testing.assert_array_equal(np.array([r["_distance"] for r in a["ref_videos"]], np.float32), wd[keep].astype(np.float32))
+            assert all(r["video"] != a["video"] for r in a["ref_videos"])
+        got[pre] = qa
+    assert all(len(a["ref_videos"]) == 12 for a in got[True])                      # pre-filter: always K + 3 rows
+    assert all(len(a["ref_videos"]) == 6 for a in got[False])                      # lancedb's order: the query's 6 clips were in the 12 nearest
+    for a_post, a_pre in zip(got[False], got[True]):
+        assert a_post["ref_videos"] == a_pre["ref_videos"][:6]                     # the survivors are the head of the pre-filtered list
+    a = got[False][0]
+    video = torch.randn(1, 8, 3, 4, 4)
+    refs, dist = rag.get_ref_videos(a, video, lambda row: torch.full((1, 8, 3, 4, 4), row["start_sec"] + 1.0), ref_video_num=9)
+    assert refs.shape == (9, 8, 3, 4, 4) and len(dist) == 6                        # dataset.py:296: only the rows that exist are visited
+    assert refs[6:].abs().max().item() == 0 and all(refs[i].abs().min().item() > 0 for i in range(6))
+    assert dist == [r["_distance"] for r in a["ref_videos"]]
 
 
 def test_svd_ct_pipeline_all_native_components(hip):

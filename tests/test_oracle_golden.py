@@ -179,6 +179,46 @@ def test_topk_oracle_c_vs_numpy(metric):
         assert not np.any(group[r32[qi]] == excl[qi])
 
 
+def multi_clip_db(rng, n_videos=50, clips=6, dim=64, spread=0.05):
+    """a database in which every video contributes `clips` near-duplicate clips (the multi-clip-per-video datasets MotionRAG retrieves from):
+    a query built from one clip has its own video's other clips among its nearest rows, so lancedb's post-filter and a pre-filter disagree"""
+    centres = rng.standard_normal((n_videos, dim)).astype(np.float32)
+    db = np.repeat(centres, clips, axis=0) + spread * rng.standard_normal((n_videos * clips, dim)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    group = (np.arange(n_videos * clips) // clips).astype(np.int32)
+    return db, group
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_topk_oracle_filter_order(metric):
+    """lancedb `where(..., prefilter=False)` (post-filter, 0.14.0's default) against `prefilter=True`: C oracle == numpy restatement in both
+    orders; the orders differ exactly where the query's own video fills the head of the unfiltered list"""
+    rng = np.random.default_rng(11)
+    db, group = multi_clip_db(rng)
+    own = np.array([0, 7, 31, 49], np.int32)
+    q = db[own * 6 + 2] + 0.01 * rng.standard_normal((4, 64)).astype(np.float32)
+    k = 12
+    r_pre, d_pre = topk_ref.topk(db, q, k, metric, group, own, mode="f64")
+    r_post, d_post = topk_ref.topk(db, q, k, metric, group, own, mode="f64", postfilter=True)
+    for rows, dist, post in ((r_pre, d_pre, False), (r_post, d_post, True)):
+        rn, dn = topk_ref.topk_numpy(db, q, k, metric, group, own, postfilter=post)
+        np.testing.assert_array_equal(rows, rn)
+        np.testing.assert_allclose(dist, dn, rtol=1e-12, atol=1e-12)
+    r_none, _ = topk_ref.topk(db, q, k, metric, mode="f64")
+    for qi in range(4):
+        assert (r_pre[qi] >= 0).all() and not np.any(group[r_pre[qi]] == own[qi])               # pre-filter: always k rows
+        n_own = int(np.sum(group[r_none[qi]] == own[qi]))
+        assert n_own == 6                                                                     # all six clips of the query's video lead the unfiltered list
+        kept = r_post[qi][r_post[qi] >= 0]
+        assert len(kept) == k - n_own and (r_post[qi][len(kept):] == -1).all() and np.isinf(d_post[qi][len(kept):]).all()
+        np.testing.assert_array_equal(kept, [r for r in r_none[qi] if group[r] != own[qi]])     # survivors keep their order
+        np.testing.assert_array_equal(kept, r_pre[qi][:len(kept)])                             # ... and are the head of the pre-filtered list
+    # the fp32-chain mode (what the HIP kernel is compared with bit for bit) ranks the same rows in both orders
+    np.testing.assert_array_equal(topk_ref.topk(db, q, k, metric, group, own, postfilter=True)[0], r_post)
+    # no exclusion given: the flag changes nothing
+    np.testing.assert_array_equal(topk_ref.topk(db, q, k, metric, postfilter=True)[0], r_none)
+
+
 def test_topk_oracle_ties_and_short_results():
     db = np.zeros((5, 32), dtype=np.float32)
     db[3, 0] = 1.0
@@ -187,6 +227,8 @@ def test_topk_oracle_ties_and_short_results():
     assert rows.tolist() == [[0, 1, 2, 4]] and dist.tolist() == [[0.0, 0.0, 0.0, 0.0]]     # ties by ascending row
     rows, dist = topk_ref.topk(db, q, 8, "l2", group=np.zeros(5, np.int32) + np.array([0, 0, 0, 1, 1], np.int32), exclude=np.array([0], np.int32))
     assert rows.tolist() == [[4, 3, -1, -1, -1, -1, -1, -1]] and np.isinf(dist[0, 2:]).all()
+    rows, dist = topk_ref.topk(db, q, 4, "l2", group=np.array([0, 0, 0, 1, 1], np.int32), exclude=np.array([0], np.int32), postfilter=True)
+    assert rows.tolist() == [[4, -1, -1, -1]] and dist[0, 0] == 0.0 and np.isinf(dist[0, 1:]).all()     # the 4 nearest are rows 0, 1, 2, 4: one survives
 
 
 # ---------------------------------------------------------------------------------------------- DynamiCrafter UNet (G8-G12)

@@ -14,10 +14,8 @@ for name, (B, H, S) in (("dit joint", (2, 48, 17776)), ("dc level0", (32, 5, 921
     qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
     out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
     fl = 4.0 * B * H * S * S * 64
-    variants = ((0, "attn16 QB3 NW4 x3/CU (shipped)"), (ops.ATTN_TUNE_M32, "attn32 (round-2 algorithm on 32x32x16) 64 rows/wave NW4 x2/CU"),
-                (ops.ATTN_TUNE_M32QB1, "attn32 32 rows/wave NW4 x3/CU"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16 (round-1 algorithm)"))
-    if os.environ.get("AB_OLD16"):
-        variants += ((ops.ATTN_TUNE_W4PF, "attn16 QB2 NW4 x4/CU"), (ops.ATTN_TUNE_W8PF, "attn16 QB2 NW8 x2/CU"))
+    # the attn32 family and the attn16 workgroup-shape variants this script compared in rounds 2-3 are archived in tools/exp/ (ABI 8)
+    variants = ((0, "attn16 QB3 NW4 x3/CU (shipped)"), (ops.ATTN_TUNE_LEGACY, "legacy 32x32x16 (round-1 algorithm)"))
     res = {t: [] for t, _ in variants}
     for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         for tune, _ in variants:

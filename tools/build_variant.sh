@@ -2,8 +2,8 @@
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 OBJ=/tmp/mrag_variant_$NAME; mkdir -p $OBJ
-for f in api gemm_bf16 attn_flash attn16 attn32 attn_fp8 comm norm pointwise preprocess topk unet_ops cama_seq attn_small; do   # motionrag_amd/_lib.py: SOURCES
-  EXTRA=""; case $f in attn_flash|attn16|attn32) EXTRA="-fno-slp-vectorize";; esac
+for f in api gemm_bf16 attn_flash attn16 attn_fp8 comm norm pointwise preprocess topk unet_ops cama_seq attn_small; do   # motionrag_amd/_lib.py: SOURCES
+  EXTRA=""; case $f in attn_flash|attn16) EXTRA="-fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment $EXTRA "$@" -c motionrag_amd/csrc/$f.hip -o $OBJ/$f.o &
 done
 wait

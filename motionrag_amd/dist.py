@@ -20,9 +20,10 @@ def shard_clips(n_clips: int, world: int, rank: int) -> range:
     return range(start, start + q + (1 if rank < r else 0))
 
 
-def gather_latents(latents: torch.Tensor, world: int) -> torch.Tensor:
-    """[b, ...] per rank -> [world * b, ...] on every rank (rank-major order); identity for world == 1"""
-    if world == 1:
+def gather_latents(latents: torch.Tensor, world: int, force: bool = False) -> torch.Tensor:
+    """[b, ...] per rank -> [world * b, ...] on every rank (rank-major order); identity for world == 1 unless `force` (a one-rank process
+    group started by a launcher: the collective then runs through the backend all the same -- bench.py under `--nproc-per-node 1`)"""
+    if world == 1 and not (force and dist.is_initialized()):
         return latents
     x = latents.contiguous()
     if x.is_cuda and dist.get_backend() == "gloo":    # developer runs of the N > 1 path on one GPU (bench.py MRAG_BENCH_ONE_GPU): stage through the host

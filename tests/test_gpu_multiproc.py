@@ -53,6 +53,35 @@ def test_two_rank_sequence_and_cfg_sharding_reproduce_the_single_gpu_clip(hip, t
     assert _bench(2, "clips")["n_gpus"] == 2      # the judged default: one clip per rank + the end-of-loop all-gather
 
 
+@pytest.mark.timeout(1800)
+def test_one_rank_launcher_runs_the_collectives_through_rccl(hip, tmp_path):
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` on this one-GPU box: `init_process_group("nccl", device_id=...)`, the end-of-loop
+    `all_gather_into_tensor` of the clips (dist.gather_latents) and -- with `--shard sequence` -- the per-block asynchronous K / V
+    `all_gather_into_tensor(async_op=True)` + `.wait()` (SequenceParallel.all_gather_rows_async) execute THROUGH RCCL with one rank (no
+    MRAG_BENCH_ONE_GPU: the transport is nccl, not gloo).  The clips must equal the launcher-less run's: bit for bit in clip mode (same kernels,
+    the gather of one rank is a copy), to bf16 rounding of a few rows in sequence mode (K|V and Q are projected by two GEMM launches there)."""
+    import numpy as np
+    env = {k: v for k, v in os.environ.items() if k != "MRAG_BENCH_ONE_GPU"}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    plain = _run([sys.executable, "bench.py", "--gpus", "1", "--check", str(tmp_path / "plain.npy")] + COMMON, env)
+    assert plain["process_group"] is None
+    want = np.load(tmp_path / "plain.npy")
+    for shard in ("clips", "sequence"):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        got = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                    "bench.py", "--gpus", "1", "--shard", shard, "--check", str(tmp_path / f"{shard}.npy")] + COMMON, env)
+        assert got["process_group"] == "nccl, world 1" and got["n_gpus"] == 1
+        assert got["config"]["parallelism"] == ("sp1" if shard == "sequence" else "dp1")
+        x = np.load(tmp_path / f"{shard}.npy")
+        if shard == "clips":
+            np.testing.assert_array_equal(x, want)
+        else:
+            rel = float(np.linalg.norm(x - want) / np.linalg.norm(want))
+            assert rel <= 5e-3, f"sequence mode over RCCL: relative Frobenius difference {rel:.4f}"
+
+
 def test_bench_refuses_a_mismatched_launcher(hip):
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)

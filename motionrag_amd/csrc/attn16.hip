@@ -33,6 +33,14 @@ constexpr int TILE_BYTES = KVB * 128;
 // LDS: K ring of NS stages, then the V ring
 constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
 
+
+#ifndef MRAG_ATTN16_KGROUP
+#define MRAG_ATTN16_KGROUP 2           // K fragment reads per group of the score MFMAs: 2 (one key block) or 4 (two key blocks: round 3)
+#endif
+#ifndef MRAG_ATTN16_OPTIMISTIC
+#define MRAG_ATTN16_OPTIMISTIC 1       // 0: every pass in the safe (checked) form -- the round-3 loop, kept buildable for A/B runs (tools/build_variant.sh)
+#endif
+
 struct Lane16 {
   unsigned ka[2];     // LDS byte address (stage 0, key block 0) of this lane's K fragment for k-step 0 / 1
   unsigned va[4];     // LDS byte address (stage 0, keys 4 g + q) of this lane's V^T read for d-block 0..3
@@ -43,6 +51,30 @@ struct Lane16 {
 // (Requesting both groups up front -- 150 -> 168 VGPRs forced -- lost 4 % when it cost the third workgroup per CU; pruned in round 3.)
 template <int OFF, int QB, typename Between>
 __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
+#if MRAG_ATTN16_KGROUP == 2
+  // one key block (2 fragment reads, 2 QB MFMAs) at a time: 8 VGPRs of K fragments live instead of 16 -- the room the row-sum accumulators of the
+  // optimistic sweep need at 168 VGPRs (three workgroups per CU)
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    u32x4 kf[2];
+    if (kb == 0) {
+      asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(kf[0]), "=&v"(kf[1]) : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF) : "memory");
+      between();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]) :: "memory");
+    } else if (kb == 1) {
+      asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(kf[0]), "=&v"(kf[1]) : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 2048) : "memory");
+    } else if (kb == 2) {
+      asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(kf[0]), "=&v"(kf[1]) : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 4096) : "memory");
+    } else {
+      asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(kf[0]), "=&v"(kf[1]) : "v"(ln.ka[0]), "v"(ln.ka[1]), "n"(OFF + 6144) : "memory");
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[0]), qf[qb][0], negm[qb], 0, 0, 0);
+      s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[1]), qf[qb][1], s[kb][qb], 0, 0, 0);
+    }
+  }
+#else
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
     u32x4 kf[4];                           // [2 * kbl + ks]
@@ -66,11 +98,14 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
         s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl + 1]), qf[qb][1], s[2 * half + kbl][qb], 0, 0, 0);
       }
   }
+#endif
 }
 
-// O^T += V^T . P^T: per 32-key step 4 d-blocks x 2 transposed reads, QB MFMAs per fragment.  EXEC is all ones (wave-uniform control flow only).
-template <int VOFF, int QB>
-__device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB]) {
+// LSUM: the row sums ride the matrix pipe too -- l^T[., q] += ONES . P^T, one more MFMA per 32-key step and query block whose A operand is the
+// constant all-ones fragment: every register of lane (q, g) then holds the COMPLETE sum over the tile's keys of the bf16 P values that multiply V
+// (2 MFMAs = 16 issue cycles per 16 x 64 scores instead of 8 v_dot2c + 2 v_add on the busier vector pipe).
+template <int VOFF, int QB, bool LSUM = false>
+__device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB], f32x4 (*lacc)[QB] = nullptr) {
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     u32x2 lo[4], hi[4];   // d-block db: keys 32 st + 4 g .. (+3) and 32 st + 16 + 4 g .. (+3)
@@ -95,6 +130,11 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
       const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[st][qb], o[db][qb], 0, 0, 0);
+    }
+    if constexpr (LSUM) {
+      const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) (*lacc)[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[st][qb], (*lacc)[qb], 0, 0, 0);
     }
   }
 }
@@ -202,15 +242,8 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : 4) void attn16_kernel(const 
   }
 
   f32x4 o[4][QB], negm[QB];
-  float m[QB], l[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    m[qb] = 0.f; l[qb] = 0.f;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
+  f32x4 lacc[QB];          // OPTIMISTIC sweep: row sums accumulated by the matrix pipe (pv16<LSUM>): every register = the complete sum of the lane's query
+  float m[QB], l[QB];      // safe sweep: per-lane partial row sums (folded over the 4 lane groups in the epilogue)
   const int nt = (skv + SK - 1) / SK;     // stages
   constexpr int D = NS - 1;
   auto wait_pair = [&]() {   // all but the (D - 1) youngest tile pairs of this wave have landed; then rendezvous
@@ -218,8 +251,6 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : 4) void attn16_kernel(const 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-#pragma unroll
-  for (int i = 0; i < D; ++i) issue_kv(i, i);
 
   // exact row maximum of the lane's queries over one tile's scores (first tile and the rare re-centre path only)
   auto tile_max = [&](const f32x4 (&s)[4][QB], float (&tm)[QB]) {
@@ -236,112 +267,188 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : 4) void attn16_kernel(const 
     }
   };
 
-  auto tile = [&](int t, auto off_c, auto hook) {
-    constexpr int OFF = decltype(off_c)::value, SUB = 0;
-    f32x4 s[4][QB];
-    float ps[QB];
-    const bool ragged = (t == nt - 1) && (skv & (SK - 1));
-    const int gkey = skv - SK + SUB * KVB + 4 * ln.g;   // slid-back last stage: first key of this lane's group in key block 0 of this tile
-    // Pass 1 is the whole story except on the first tile and on a tile whose row sums explode (a score beat the stale max by more than
-    // ~20 log2 units: never on real activations): those re-centre -- exact tile maximum, m moves, O and l are rescaled by the exact
-    // factor -- and, for an exploded tile, the score MFMAs are simply run again (its K stage is still resident).
-    bool recentre = (t == 0 && SUB == 0);
-    bf16x8 pb[2][QB];
-    for (int pass = 0;; ++pass) {
-      if (pass == 0) qk16<OFF, QB>(ln, qf, negm, s, hook);
-      else qk16<OFF, QB>(ln, qf, negm, s, NoHook16());
-      if (ragged) {   // keys before t * 64 were consumed by the previous tile
-        asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
-        const int lo = t * SK;
+  // One pass over the keys, in one of two forms:
+  //   FAST (optimistic): NO running maximum.  P = exp2(S) straight from the score MFMAs (C operand = 0), rounded to bf16; O^T += V^T P^T and the row
+  //     sums l^T += ONES P^T both on the matrix pipe (pv16<LSUM>); nothing per tile is checked.  Softmax is invariant under a common factor
+  //     per row: subtracting a maximum only changes O and l by 2^-m, which cancels in O / l, and fp32 / bf16 keep the same RELATIVE precision at
+  //     any magnitude -- so the maximum matters only where exp2 would leave the floating-point range: a row whose largest score (in log2 units,
+  //     scale * log2 e folded into Q) is above ~+100 or below ~-100, i.e. a logit beyond +-69 nats.  The END of the sweep checks every row sum of
+  //     the workgroup, 2^-100 <= l <= 2^100 (which leaves 2^27 of fp32 headroom for |O| <= l max|V| and catches inf / NaN / all-underflow); if
+  //     ANY row fails, the workgroup runs the pass again in the
+  //   SAFE form (round 2/3's loop): the first tile fixes the running max m (carried into the score MFMAs as their C operand), per-tile partial
+  //     row sums on the vector pipe, a tile whose sum exceeds 2^24 re-centres -- exact tile maximum, m moves, O and l rescaled -- and re-runs
+  //     its score MFMAs.
+  // Per 16 x 64 scores the fast loop issues 16 v_exp + 8 v_cvt_pk + 18 MFMAs (vector issue ~160 of the 288 matrix-pipe cycles + 144 for the MFMAs'
+  // own issue slots); the safe loop 8 v_dot2c + 3 more vector instructions and a ballot on top.  Partial results of the key-split tail carry
+  // m = 0 from a fast sweep: attn_combine_kernel merges (m, l, O) triples whatever reference each one used.
+  auto sweep = [&](auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    k_next = 0; v_next = 0;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+    for (int qb = 0; qb < QB; ++qb) {
+      negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      m[qb] = 0.f; l[qb] = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (gkey < lo - (16 * kb + r)) {
-#pragma unroll
-              for (int qb = 0; qb < QB; ++qb) s[kb][qb][r] = -INFINITY;
-            }
-      }
-      if (recentre) {
-        float tm[QB];
-        tile_max(s, tm);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          const bool first = (t == 0 && SUB == 0);
-          const float delta = first ? fmaxf(tm[qb], -1e30f) : fmaxf(tm[qb], 0.f);   // S' is relative to m already: a row moves by max(0, tile max)
-          if (!first) {
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-            l[qb] *= alpha;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) o[db][qb] *= f32x4{alpha, alpha, alpha, alpha};
-          }
-          m[qb] += delta;
-          negm[qb] = f32x4{-m[qb], -m[qb], -m[qb], -m[qb]};
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) s[kb][qb] -= f32x4{delta, delta, delta, delta};
-        }
-      }
-      // P = exp2(S') rounded to bf16 first; the row sum is then one v_dot2c_f32_bf16 (pair . (1, 1) + acc) per packed register -- 8 + 1 instead of
-      // 16 vector instructions per 16 scores (133 -> 112 per tile, +1.5 % on the launch) -- and l sums exactly the P values that multiply V
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          unsigned w0 = pack_bf2(s[2 * st][qb][0], s[2 * st][qb][1]), w1 = pack_bf2(s[2 * st][qb][2], s[2 * st][qb][3]);
-          unsigned w2 = pack_bf2(s[2 * st + 1][qb][0], s[2 * st + 1][qb][1]), w3 = pack_bf2(s[2 * st + 1][qb][2], s[2 * st + 1][qb][3]);
-          asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));   // hipcc 7.2 otherwise feeds sub-register 0 of the vector to all four dot2c
-          a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w0), __builtin_bit_cast(bf16v2, 0x3f803f80u), a0, false);
-          a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w1), __builtin_bit_cast(bf16v2, 0x3f803f80u), a1, false);
-          a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w2), __builtin_bit_cast(bf16v2, 0x3f803f80u), a0, false);
-          a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w3), __builtin_bit_cast(bf16v2, 0x3f803f80u), a1, false);
-          const u32x4 w = {w0, w1, w2, w3};
-          pb[st][qb] = __builtin_bit_cast(bf16x8, w);
-        }
-        ps[qb] = a0 + a1;
-      }
-      bool blown = false;
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) blown |= !(ps[qb] <= kBig);   // also catches inf / NaN
-      if (__builtin_expect(!__any(blown), 1) || recentre) break;     // a re-centred tile has P <= 1: it cannot explode again
-      recentre = true;
+      for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
-    pv16<V_BASE + OFF, QB>(ln, pb, o);
-  };
-  auto iter = [&](int t, auto stage_c) {
-    constexpr int STG = decltype(stage_c)::value;
-    wait_pair();   // barrier #t: stage t has landed for every wave, stage t - 1's buffer is free
-    auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
-    if (!wave_active) { early_issue(); return; }
-    tile(t, std::integral_constant<int, STG * STAGE_BYTES>{}, early_issue);
+    for (int i = 0; i < D; ++i) issue_kv(i, i);
+
+    auto tile = [&](int t, auto off_c, auto hook) {
+      constexpr int OFF = decltype(off_c)::value, SUB = 0;
+      f32x4 s[4][QB];
+      float ps[QB];
+      const bool ragged = (t == nt - 1) && (skv & (SK - 1));
+      const int gkey = skv - SK + SUB * KVB + 4 * ln.g;   // slid-back last stage: first key of this lane's group in key block 0 of this tile
+      // Pass 1 is the whole story except on the first tile and (safe form) on a tile whose row sums explode: those re-centre -- exact tile
+      // maximum, m moves, O and l are rescaled by the exact factor -- and, for an exploded tile, the score MFMAs are simply run again (its K
+      // stage is still resident).
+      bool recentre = !FAST && (t == 0 && SUB == 0);
+      bf16x8 pb[2][QB];
+      for (int pass = 0;; ++pass) {
+        if constexpr (FAST) {
+          f32x4 zero[QB];                       // S = K . Q^T + 0: the C operand is the inline constant
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) zero[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          qk16<OFF, QB>(ln, qf, zero, s, hook);
+        } else if (pass == 0) qk16<OFF, QB>(ln, qf, negm, s, hook);
+        else qk16<OFF, QB>(ln, qf, negm, s, NoHook16());
+        if (ragged) {   // keys before t * 64 were consumed by the previous tile
+          asm volatile("; ragged last tile" ::: "memory");   // keeps hipcc from if-converting this into 48 selects on EVERY tile
+          const int lo = t * SK;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gkey < lo - (16 * kb + r)) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[kb][qb][r] = -INFINITY;
+              }
+        }
+        if (recentre) {
+          float tm[QB];
+          tile_max(s, tm);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const bool first = (t == 0 && SUB == 0);
+            const float delta = first ? fmaxf(tm[qb], -1e30f) : fmaxf(tm[qb], 0.f);   // S' is relative to m already: a row moves by max(0, tile max)
+            if (!first) {
+              const float alpha = __builtin_amdgcn_exp2f(-delta);
+              l[qb] *= alpha;
+#pragma unroll
+              for (int db = 0; db < 4; ++db) o[db][qb] *= f32x4{alpha, alpha, alpha, alpha};
+            }
+            m[qb] += delta;
+            negm[qb] = f32x4{-m[qb], -m[qb], -m[qb], -m[qb]};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[kb][qb] -= f32x4{delta, delta, delta, delta};
+          }
+        }
+        if constexpr (FAST) {
+          // P = exp2(S') rounded to bf16: nothing else on the vector pipe
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+              const u32x4 w = {pack_bf2(s[2 * st][qb][0], s[2 * st][qb][1]), pack_bf2(s[2 * st][qb][2], s[2 * st][qb][3]),
+                               pack_bf2(s[2 * st + 1][qb][0], s[2 * st + 1][qb][1]), pack_bf2(s[2 * st + 1][qb][2], s[2 * st + 1][qb][3])};
+              pb[st][qb] = __builtin_bit_cast(bf16x8, w);
+            }
+          }
+          break;
+        } else {
+          // P = exp2(S') rounded to bf16 first; the row sum is then one v_dot2c_f32_bf16 (pair . (1, 1) + acc) per packed register -- 8 + 1 instead of
+          // 16 vector instructions per 16 scores -- and l sums exactly the P values that multiply V
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+              unsigned w0 = pack_bf2(s[2 * st][qb][0], s[2 * st][qb][1]), w1 = pack_bf2(s[2 * st][qb][2], s[2 * st][qb][3]);
+              unsigned w2 = pack_bf2(s[2 * st + 1][qb][0], s[2 * st + 1][qb][1]), w3 = pack_bf2(s[2 * st + 1][qb][2], s[2 * st + 1][qb][3]);
+              asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));   // hipcc 7.2 otherwise feeds sub-register 0 of the vector to all four dot2c
+              a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w0), __builtin_bit_cast(bf16v2, 0x3f803f80u), a0, false);
+              a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w1), __builtin_bit_cast(bf16v2, 0x3f803f80u), a1, false);
+              a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w2), __builtin_bit_cast(bf16v2, 0x3f803f80u), a0, false);
+              a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, w3), __builtin_bit_cast(bf16v2, 0x3f803f80u), a1, false);
+              const u32x4 w = {w0, w1, w2, w3};
+              pb[st][qb] = __builtin_bit_cast(bf16x8, w);
+            }
+            ps[qb] = a0 + a1;
+          }
+          bool blown = false;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) blown |= !(ps[qb] <= kBig);   // also catches inf / NaN
+          if (__builtin_expect(!__any(blown), 1) || recentre) break;     // a re-centred tile has P <= 1: it cannot explode again
+          recentre = true;
+        }
+      }
+      if constexpr (FAST) {
+        pv16<V_BASE + OFF, QB, true>(ln, pb, o, &lacc);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
+        pv16<V_BASE + OFF, QB>(ln, pb, o);
+      }
+    };
+    auto iter = [&](int t, auto stage_c) {
+      constexpr int STG = decltype(stage_c)::value;
+      wait_pair();   // barrier #t: stage t has landed for every wave, stage t - 1's buffer is free
+      auto early_issue = [&]() { issue_kv((STG + D) % NS, t + D); };
+      if (!wave_active) { early_issue(); return; }
+      tile(t, std::integral_constant<int, STG * STAGE_BYTES>{}, early_issue);
+    };
+
+    int t = 0;
+    for (; t + NS <= nt; t += NS) {
+      iter(t, std::integral_constant<int, 0>{});
+      iter(t + 1, std::integral_constant<int, 1>{});
+      if constexpr (NS >= 3) iter(t + 2, std::integral_constant<int, 2>{});
+      if constexpr (NS >= 4) iter(t + 3, std::integral_constant<int, 3>{});
+    }
+    if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
+    if constexpr (NS >= 3) { if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; } }
+    if constexpr (NS >= 4) { if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; } }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released (or re-used by a second sweep)
   };
 
-
-  int t = 0;
-  for (; t + NS <= nt; t += NS) {
-    iter(t, std::integral_constant<int, 0>{});
-    iter(t + 1, std::integral_constant<int, 1>{});
-    if constexpr (NS >= 3) iter(t + 2, std::integral_constant<int, 2>{});
-    if constexpr (NS >= 4) iter(t + 3, std::integral_constant<int, 3>{});
+  bool fast_ok = false;
+#if MRAG_ATTN16_OPTIMISTIC
+  {
+    sweep(std::true_type{});
+    bool bad = false;
+    if (wave_active) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) bad |= !(lacc[qb][0] <= 1.2676506e30f && lacc[qb][0] >= 7.888609e-31f);   // [2^-100, 2^100]; false for inf / NaN
+    }
+    // workgroup-uniform verdict: the K / V ring is fed by all four waves, so the pass is repeated by all of them or by none.  The barrier also
+    // fences the LDS between the sweeps (every wave's tail DMAs were retired just above)
+    fast_ok = !__syncthreads_or((int)bad);
   }
-  if (t < nt) { iter(t, std::integral_constant<int, 0>{}); ++t; }
-  if constexpr (NS >= 3) { if (t < nt) { iter(t, std::integral_constant<int, 1>{}); ++t; } }
-  if constexpr (NS >= 4) { if (t < nt) { iter(t, std::integral_constant<int, 2>{}); ++t; } }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the clamped tail DMAs before the LDS is released
+#endif
+  if (!fast_ok) sweep(std::false_type{});
 
   if (!wave_active) return;
   // ---- epilogue: row sums across the 4 lane groups, normalise, fused residual, 8-byte stores (4 consecutive features of a row per lane)
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    float lt = l[qb];
-    lt += __shfl_xor(lt, 16);
-    lt += __shfl_xor(lt, 32);
+    float lt;
+    if (fast_ok) {
+      lt = lacc[qb][0];          // complete already (the ONES . P^T product sums over every key)
+    } else {
+      lt = l[qb];
+      lt += __shfl_xor(lt, 16);
+      lt += __shfl_xor(lt, 32);
+    }
     const int qrow = q0 + qb * 16 + r16;
     if (qrow >= p.Sq) continue;
     if (KVSPLIT && split_unit) {   // partial result of this key chunk; attn_combine_kernel merges the chunks

@@ -34,8 +34,12 @@ constexpr int TILE_BYTES = KVB * 128;
 constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row sum of one tile above 2^24
 
 
-#ifndef MRAG_ATTN16_KGROUP
-#define MRAG_ATTN16_KGROUP 2           // K fragment reads per group of the score MFMAs: 2 (one key block) or 4 (two key blocks: round 3)
+// K fragment reads per group of the score MFMAs: 2 (one key block: 8 VGPRs of fragments -- what lets the optimistic sweep's row-sum accumulators fit
+// the 168 VGPRs of three workgroups per CU) or 4 (two key blocks: faster where registers allow, i.e. at QB = 4).  MRAG_ATTN16_KGROUP pins one for A/B builds.
+#ifdef MRAG_ATTN16_KGROUP
+#define KGROUP_OF(QB) MRAG_ATTN16_KGROUP
+#else
+#define KGROUP_OF(QB) ((QB) == 3 ? 2 : 4)
 #endif
 #ifndef MRAG_ATTN16_OPTIMISTIC
 #define MRAG_ATTN16_OPTIMISTIC 1       // 0: every pass in the safe (checked) form -- the round-3 loop, kept buildable for A/B runs (tools/build_variant.sh)
@@ -51,7 +55,7 @@ struct Lane16 {
 // (Requesting both groups up front -- 150 -> 168 VGPRs forced -- lost 4 % when it cost the third workgroup per CU; pruned in round 3.)
 template <int OFF, int QB, typename Between>
 __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2], const f32x4 (&negm)[QB], f32x4 (&s)[4][QB], Between between) {
-#if MRAG_ATTN16_KGROUP == 2
+  if constexpr (KGROUP_OF(QB) == 2) {
   // one key block (2 fragment reads, 2 QB MFMAs) at a time: 8 VGPRs of K fragments live instead of 16 -- the room the row-sum accumulators of the
   // optimistic sweep need at 168 VGPRs (three workgroups per CU)
 #pragma unroll
@@ -74,7 +78,7 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
       s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[1]), qf[qb][1], s[kb][qb], 0, 0, 0);
     }
   }
-#else
+  } else {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {   // key blocks (0, 1), then (2, 3): 4 fragment reads, 4 QB MFMAs each
     u32x4 kf[4];                           // [2 * kbl + ks]
@@ -98,7 +102,7 @@ __device__ __forceinline__ void qk16(const Lane16& ln, const bf16x8 (&qf)[QB][2]
         s[2 * half + kbl][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[2 * kbl + 1]), qf[qb][1], s[2 * half + kbl][qb], 0, 0, 0);
       }
   }
-#endif
+  }
 }
 
 // LSUM: the row sums ride the matrix pipe too -- l^T[., q] += ONES . P^T, one more MFMA per 32-key step and query block whose A operand is the
@@ -144,7 +148,7 @@ struct NoHook16 {
 };
 
 template <int QB, int NW, int NS, bool KVSPLIT>
-__global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : 4) void attn16_kernel(const AttnP p) {
+__global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn16_kernel(const AttnP p) {
   constexpr int ROWS = NW * QB * 16;
   constexpr int SK = KVB, STAGE_BYTES = TILE_BYTES, V_BASE = NS * STAGE_BYTES;      // an LDS stage = one 64-key compute tile; one barrier per stage
   constexpr int PPW = 8 / NW;                                                       // 1-KiB DMA pieces per wave per K (and V) stage
@@ -510,17 +514,18 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
   return mrag_launch_attn_combine(s, p);
 }
 
-// Shipped configuration (interleaved A/B on MI355X, tools/attn_ab.py, profiles/r2_attn_ab_variants.txt): 48 query rows per wave (QB = 3),
-// 4-wave workgroups of 192 rows, THREE per CU (168 VGPRs, 3 waves per SIMD, 48 KB of LDS each).  Against 32 rows per wave in 8-wave
-// workgroups (two per CU, 4 waves per SIMD) it reads 2/3 of the K / V fragment bytes per FLOP and its barriers couple 4 waves instead of 8:
-// 6.54-6.62 vs 6.82-6.83 ms at the BASELINE shape, 2.87-2.89 vs 2.95-3.03 ms at the DynamiCrafter level-0 shape.  Retired by measurement and
-// pruned in round 3: 64 rows per wave (2 waves per SIMD: -5..7 %), fragment prefetching at 150 VGPRs (-4 %), 128-key LDS stages (-1 %).
-int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning) {
+// Workgroup shapes (interleaved A/B on MI355X; round 2: profiles/r2_attn_ab_variants.txt, round 4 with the optimistic sweep: profiles/r4_attn_*_ab.txt):
+//   QB = 3 (shipped): 48 query rows per wave, 4-wave workgroups of 192 rows, THREE per CU (168 VGPRs, 3 waves per SIMD, 48 KB of LDS each);
+//   QB = 4 (-DMRAG_ATTN16_QB=4): 64 rows per wave, 256-row workgroups, TWO per CU (214 VGPRs): 3/4 of the K / V fragment bytes and barriers per FLOP.
+//           5-7 % behind with the checked loop of round 3; with the optimistic sweep 2.6 % ahead in a cold microbenchmark and 1.5 % behind inside
+//           the denoise step (attn_common.h) -- measured in the step, QB = 3 stays.
+// Retired by measurement and pruned: 32 rows per wave in 8-wave workgroups, fragment prefetching at 150 VGPRs (-4 %), 128-key LDS stages (-1 %).
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int qb) {
   if (p.mask || p.Sq <= 128 || p.Skv < 4 * KVB) return MRAG_ENOTSUP;
   if ((long long)p.Skv * p.k_ss * 2 >= 0xffffffffLL || (long long)p.Skv * p.v_ss * 2 >= 0xffffffffLL) return MRAG_ENOTSUP;   // walked 32-bit DMA offsets
   if (pl) {
-    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= 192) return MRAG_ENOTSUP;
-    return launch16_split<3, 4, 3>(s, p, pl, workspace);
+    if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= mrag_attn16_rows(qb)) return MRAG_ENOTSUP;
+    return qb == 4 ? launch16_split<4, 4, 3>(s, p, pl, workspace) : launch16_split<3, 4, 3>(s, p, pl, workspace);
   }
-  return launch16_plain<3, 4, 3>(s, p);
+  return qb == 4 ? launch16_plain<4, 4, 3>(s, p) : launch16_plain<3, 4, 3>(s, p);
 }

@@ -23,8 +23,22 @@ struct SplitPlan {
 };
 SplitPlan mrag_plan_kv_split(int B, int H, int Sq, int Skv, int tile_rows, int slots);
 int mrag_launch_attn_combine(hipStream_t s, const AttnP& p);
+// attn16 workgroup shape: query blocks of 16 rows per wave (4 waves per workgroup).  3 -> 192-row workgroups, three per CU (168 VGPRs): shipped;
+// 4 -> 256-row workgroups, two per CU (214 VGPRs): fewer K / V fragment bytes and barriers per FLOP.  With the optimistic sweep, QB = 4 is 2.6 % AHEAD
+// at S = 17 776 in a cold interleaved microbenchmark (6.05 vs 6.22 ms, profiles/r4_attn_qb4_ab.txt) and 1.5 % BEHIND inside the denoise step, where the
+// chip sits in its sustained power state (6.38 vs 6.28 ms per launch, 562 vs 560 ms per step on one box: profiles/r4_attn_step_ab.txt) -- the step is
+// what ships, so 3 everywhere.  -DMRAG_ATTN16_QB=4 builds the other shape (tools/build_variant.sh) for A/B runs.
+inline int mrag_attn16_qb(int /*Sq*/) {
+#ifdef MRAG_ATTN16_QB
+  return MRAG_ATTN16_QB;
+#else
+  return 3;
+#endif
+}
+inline int mrag_attn16_rows(int qb) { return 64 * qb; }
+inline int mrag_attn16_slots(int qb) { return (qb == 3 ? 3 : 2) * 256; }
 // attn16.hip: long unmasked sequences (Sq > 128, Skv >= 256) on v_mfma_f32_16x16x32_bf16; returns MRAG_ENOTSUP for shapes it does not take
-int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int tuning);
+int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int qb);
 
 
 // v_max3_f32 through asm: plain fmaxf() on MFMA outputs makes hipcc emit a canonicalising v_max per operand

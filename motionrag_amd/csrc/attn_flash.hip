@@ -752,7 +752,7 @@ int mrag_launch_attn_combine(hipStream_t s, const AttnP& p) {
 
 extern "C" int64_t mrag_attn_workspace_bytes(int32_t B, int32_t H, int32_t Sq, int32_t Skv) {
   if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return 0;
-  const size_t a = mrag_plan_kv_split(B, H, Sq, Skv, 256, 512).bytes, b = mrag_plan_kv_split(B, H, Sq, Skv, 192, 768).bytes;
+  const size_t a = mrag_plan_kv_split(B, H, Sq, Skv, 256, 512).bytes, b = mrag_plan_kv_split(B, H, Sq, Skv, mrag_attn16_rows(mrag_attn16_qb(Sq)), mrag_attn16_slots(mrag_attn16_qb(Sq))).bytes;
   return (int64_t)(a > b ? a : b);      // either kernel family's tail plan fits
 }
 
@@ -981,10 +981,10 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     SplitPlan pl;
     bool split = false;
     if (may_split) {
-      pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, 192, 768);
+      pl = mrag_plan_kv_split(a->B, a->H, a->Sq, a->Skv, mrag_attn16_rows(mrag_attn16_qb(a->Sq)), mrag_attn16_slots(mrag_attn16_qb(a->Sq)));
       split = pl.splits > 1 && a->workspace_bytes >= (int64_t)pl.bytes;
     }
-    const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace, a->tuning);
+    const int rc = mrag_launch_attn16(s, p, split ? &pl : nullptr, a->workspace, mrag_attn16_qb(a->Sq));
     if (rc != MRAG_ENOTSUP) return rc;
   }
   if (may_split) {

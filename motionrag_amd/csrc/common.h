@@ -51,18 +51,49 @@ __device__ __forceinline__ f32x2 gelu_tanh_f2(const f32x2 x) {
 }
 // exact-erf GELU.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): one v_rcp + one v_exp + 7 FMAs
 // instead of the ~40-instruction branchy libm erff -- in a short-K GEMM (K = 320 GEGLU projections) the libm call was
-// ~20k of a workgroup's ~43k cycles.
+// ~20k of a workgroup's ~43k cycles.  Every multiply-add is written as an explicit fma (and nothing else is contractable), so the scalar and
+// the packed form below perform the same operations per value whatever -ffp-contract says: identical bits.
 __device__ __forceinline__ float erf_as_f(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE reciprocal sequence
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float r = 1.0f - pl * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE reciprocal sequence
+  float pl = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  pl = __builtin_fmaf(pl, t, 1.421413741f);
+  pl = __builtin_fmaf(pl, t, -0.284496736f);
+  pl = __builtin_fmaf(pl, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f((ax * -1.4426950408889634f) * ax);
+  const float r = __builtin_fmaf(-(pl * t), e, 1.0f);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return (0.5f * x) * (1.0f + erf_as_f(x * 0.7071067811865476f)); }
+// the same function on two values with packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add): 12 packed + 8 single instructions for TWO values
+// (10 issue slots per value against 17) -- the GEGLU epilogue of the UNets' K = 320 ... 1280 projections is as long as their K loop
+__device__ __forceinline__ f32x2 gelu_erf_f2(const f32x2 x) {
+  const f32x2 x0 = x * 0.7071067811865476f;
+  const f32x2 ax = {fabsf(x0[0]), fabsf(x0[1])};
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f, 0.3275911f}, one);
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 pl = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{1.421413741f, 1.421413741f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{-0.284496736f, -0.284496736f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 z = (ax * -1.4426950408889634f) * ax;
+  const f32x2 e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+  const f32x2 r = __builtin_elementwise_fma(-(pl * t), e, one);
+  const f32x2 erf = {copysignf(r[0], x0[0]), copysignf(r[1], x0[1])};
+  return (x * 0.5f) * (erf + 1.0f);
+}
+// GEGLU on four (value, gate) pairs of one lane: v <- bf16(v) * act(bf16(g)) (the reference rounds both halves of proj(x) to bf16 before the product:
+// nn.Linear output dtype); TANH selects the tanh gate (T5's gated-gelu), else the exact-erf one (lvdm attention.py:448-455 / diffusers GEGLU)
+template <bool TANH>
+__device__ __forceinline__ void geglu4(float (&v)[4], const float (&g)[4]) {
+  const unsigned gw0 = pack_bf2(g[0], g[1]), gw1 = pack_bf2(g[2], g[3]), vw0 = pack_bf2(v[0], v[1]), vw1 = pack_bf2(v[2], v[3]);
+  const f32x2 g01 = {__uint_as_float(gw0 << 16), __uint_as_float(gw0 & 0xffff0000u)}, g23 = {__uint_as_float(gw1 << 16), __uint_as_float(gw1 & 0xffff0000u)};
+  const f32x2 v01 = {__uint_as_float(vw0 << 16), __uint_as_float(vw0 & 0xffff0000u)}, v23 = {__uint_as_float(vw1 << 16), __uint_as_float(vw1 & 0xffff0000u)};
+  const f32x2 a01 = TANH ? gelu_tanh_f2(g01) : gelu_erf_f2(g01), a23 = TANH ? gelu_tanh_f2(g23) : gelu_erf_f2(g23);
+  const f32x2 o01 = v01 * a01, o23 = v23 * a23;
+  v[0] = o01[0]; v[1] = o01[1]; v[2] = o23[0]; v[3] = o23[1];
+}
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // async global -> LDS copy of 16 bytes per lane; LDS destination is

@@ -735,8 +735,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
               g[0] += __uint_as_float(bg[0] << 16); g[1] += __uint_as_float(bg[0] & 0xffff0000u);
               g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
+            geglu4<EPI == EPI_GEGLU_TANH>(v, g);
             u32x2 out;
             out[0] = pack_bf2(v[0], v[1]);
             out[1] = pack_bf2(v[2], v[3]);
@@ -774,8 +773,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
           g[2] += __uint_as_float(bg[1] << 16); g[3] += __uint_as_float(bg[1] & 0xffff0000u);
         }
         // the reference rounds both halves of proj(x) to bf16 before the product (nn.Linear output dtype)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
+        geglu4<EPI == EPI_GEGLU_TANH>(v, g);
         u32x2 out;
         out[0] = pack_bf2(v[0], v[1]);
         out[1] = pack_bf2(v[2], v[3]);
@@ -1086,8 +1084,7 @@ __device__ __forceinline__ void epilogue_w4_geglu(const GemmP& p, char* smem, f3
       v[2] += __uint_as_float(bv[jj][1] << 16); v[3] += __uint_as_float(bv[jj][1] & 0xffff0000u);
       g[0] += __uint_as_float(bg[jj][0] << 16); g[1] += __uint_as_float(bg[jj][0] & 0xffff0000u);
       g[2] += __uint_as_float(bg[jj][1] << 16); g[3] += __uint_as_float(bg[jj][1] & 0xffff0000u);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = bf_round(v[e]) * (EPI == EPI_GEGLU_TANH ? gelu_tanh_f(bf_round(g[e])) : gelu_erf_f(bf_round(g[e])));
+      geglu4<EPI == EPI_GEGLU_TANH>(v, g);
       *(u32x2*)(wput + (i & 1) * 2048 + (((2 * jj + xput) ^ sw) * 16)) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     }
   };

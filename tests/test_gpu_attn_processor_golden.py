@@ -105,6 +105,7 @@ class _CT:
         return torch.cat([torch.zeros_like(y), y]) if do_classifier_free_guidance else y
 
 
+@torch.no_grad()
 def test_adapter_pipelines_glue_against_the_reference_classes(hip, golden_dir):
     """`prepare_action_embeddings` / `_prepare_rotary_positional_embeddings` (cogvideox/pipeline.py:46-78,117-130) and the SVD pipelines'
     `prepare_action_embeddings` / `_encode_image` / stage-2 image hop (svd/pipelines/pipeline.py:99-119,154-158) of the product classes against the

@@ -256,8 +256,10 @@ int mrag_add_bf16(void* stream, const void* a, const void* b, void* y, int64_t n
 /* y[r, :] = x[r, :] + table[(r / div) % period, :] -- a per-frame / per-sample vector broadcast over a frame's pixels.
  * SVD (third-party diffusers 0.32.2 TransformerSpatioTemporalModel, reached from src/projects/svd/module.py:38-47):
  * `hidden_states_mix + emb[:, None, :]` (frame-index embedding) and TemporalResnetBlock's `+ temb` per frame;
- * with div = 1 it reproduces the `time_context` row order of the temporal cross-attention (row % batch).           */
-int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period);
+ * with div = 1 it reproduces the `time_context` row order of the temporal cross-attention (row % batch).
+ * `table_stride`: elements between table rows (0 = D; a multiple of 8): the table may be a column slice of a wider matrix -- the per-frame
+ * projections of ALL residual blocks come out of one batched GEMM (svd_unet.TembBank).                               */
+int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period, int64_t table_stride);
 /* out = a x + b y (fp32 inside, one rounding): diffusers AlphaBlender `alpha * x_spatial + (1 - alpha) * x_temporal`
  * of SpatioTemporalResBlock / TransformerSpatioTemporalModel (SVD UNet sites the reference adapts at
  * src/projects/svd/module.py:145-165).                                                                          */

@@ -219,7 +219,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_conv_bf16.argtypes = [c_void_p, POINTER(ConvArgs)]
     L.mrag_ip_attn_folded_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
                                            c_int64, c_float, c_float]
-    L.mrag_add_bcast_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64]
+    L.mrag_add_bcast_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64]
     L.mrag_axpby_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float]
     L.mrag_cfg_euler_step_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_float, c_float]
     L.mrag_patchify_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 7

@@ -166,7 +166,7 @@ __global__ void cfg_dpm_kernel(const bf16_t* vp, bf16_t* x, bf16_t* x0_old, cons
 }
 
 // y[r, :] = x[r, :] + table[(r / div) % period, :]  (per-frame / per-sample vectors broadcast over the pixels of a frame)
-__global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long div, long long period) {
+__global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y, long long rows, long long D8, long long div, long long period, long long tstride8) {
   const long long total = rows * D8;
   // (row, column vector) advance incrementally: one 64-bit division per thread instead of three per 16-byte vector
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -177,7 +177,7 @@ __global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* table, bf16_t* y
   for (; i < total; i += stride) {
     float u[8], v[8];
     unpack8(*(const u32x4*)(x + i * 8), u);
-    unpack8(*(const u32x4*)(table + (bidx * D8 + c) * 8), v);
+    unpack8(*(const u32x4*)(table + (bidx * tstride8 + c) * 8), v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) u[e] += v[e];
     *(u32x4*)(y + i * 8) = pack8(u);
@@ -380,11 +380,13 @@ extern "C" int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* la
   return MRAG_OK;
 }
 
-extern "C" int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period) {
+extern "C" int mrag_add_bcast_bf16(void* stream, const void* x, const void* table, void* y, int64_t rows, int64_t D, int64_t div, int64_t period, int64_t table_stride) {
   if (!x || !table || !y || rows <= 0 || D <= 0 || div <= 0 || period <= 0 || D % 8 != 0) return MRAG_EINVAL;
+  if (table_stride == 0) table_stride = D;
+  if (table_stride < D || table_stride % 8 != 0) return MRAG_EINVAL;
   if (((uintptr_t)x | (uintptr_t)table | (uintptr_t)y) & 15) return MRAG_EINVAL;
   MRAG_LAUNCH(add_bcast_kernel, dim3(grid_for(rows * D / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)table, (bf16_t*)y,
-              (long long)rows, (long long)(D / 8), (long long)div, (long long)period);
+              (long long)rows, (long long)(D / 8), (long long)div, (long long)period, (long long)(table_stride / 8));
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

@@ -56,6 +56,36 @@ class _Cache:
 _CACHE = _Cache()
 
 
+class TembBank:
+    """SiLU(emb) [N, E] together with EVERY residual block's projection of it.  Each ResBlock applies its own `Linear(emb_channels, C_out)` to the
+    same SiLU(emb) (openaimodel3d.py:222; diffusers `time_emb_proj`): 25-44 GEMMs of 28-32 rows per step, each a 20 us launch on 3-10 workgroups.
+    They do not depend on the activations, so the bank runs them as ONE GEMM against the row-concatenated weights at the start of the step and
+    hands out column slices `[N, C_out]` (row stride = the concatenated width).  Same kernel (128 x 128 tiles), same K order per output
+    element as the separate launches: identical bits."""
+
+    def __init__(self, silu_emb: torch.Tensor, owner: nn.Module, linears):
+        self.silu = silu_emb
+        refs = tuple(t for lin in linears for t in (lin.weight, lin.bias))
+        w, b, offs = _CACHE.get(("tembbank", id(owner)), refs, lambda: (
+            torch.cat([lin.weight.detach() for lin in linears], dim=0).contiguous(),
+            torch.cat([(lin.bias.detach() if lin.bias is not None else torch.zeros(lin.out_features, dtype=lin.weight.dtype, device=lin.weight.device))
+                       for lin in linears], dim=0).contiguous(),
+            {id(lin): (o, lin.out_features) for lin, o in zip(linears, np.cumsum([0] + [lin.out_features for lin in linears[:-1]]).tolist())}))
+        self._all = ops.linear(silu_emb, w, b) if linears else None
+        self._offs = offs
+
+    def proj(self, lin: nn.Linear) -> torch.Tensor:
+        ent = self._offs.get(id(lin))
+        if ent is None or ent[0] % 8:                      # a block outside the bank (or an unaligned slice): its own launch
+            return ops.linear(self.silu, lin.weight, lin.bias)
+        return self._all[:, ent[0]:ent[0] + ent[1]]
+
+
+def temb_proj(silu_emb, lin: nn.Linear) -> torch.Tensor:
+    """`lin(SiLU(emb))`: a slice of the step's TembBank, or the plain projection when a block is driven with a bare tensor (unit tests)"""
+    return silu_emb.proj(lin) if isinstance(silu_emb, TembBank) else ops.linear(silu_emb, lin.weight, lin.bias)
+
+
 def _tanh_scalar(p: torch.Tensor) -> float:
     """tanh of a learnable scalar gate (attention.py:200-202, 216-218) as a host float, read back ONCE per weight version: a `.item()` per
     attention call is a host sync per layer and cannot be captured in a HIP graph"""
@@ -363,7 +393,7 @@ class ResBlock(nn.Module):
         gi, go = self.in_layers[0], self.out_layers[0]
         h = ops.groupnorm(x.view(N, H * W, C), gi.weight, gi.bias, 32, gi.eps, silu=True).view(N, H, W, C)
         h = conv3x3(h, self.in_layers[2])
-        emb_out = ops.linear(silu_emb, self.emb_layers[1].weight, self.emb_layers[1].bias)                     # :222
+        emb_out = temb_proj(silu_emb, self.emb_layers[1])                                                      # :222 (one batched GEMM per step: TembBank)
         h = ops.groupnorm(h.view(N, H * W, -1), go.weight, go.bias, 32, go.eps, silu=True, emb=emb_out).view(N, H, W, -1)   # h + emb_out -> GN -> SiLU
         if isinstance(self.skip_connection, nn.Identity):
             skip = x
@@ -506,6 +536,9 @@ class UNetModel(nn.Module):
                 fs = torch.tensor([self.default_fs] * b, dtype=torch.long, device=dev)
             emb = ops.add(emb, mlp(self.fps_embedding, ops.timestep_embedding(fs.to(dev, torch.float32), self.model_channels)))
         silu_emb = ops.silu(emb).repeat_interleave(t, dim=0).contiguous()                                               # every ResBlock uses SiLU(emb)
+        if getattr(self, "_temb_linears", None) is None:
+            self._temb_linears = [m.emb_layers[1] for m in self.modules() if isinstance(m, ResBlock)]
+        silu_emb = TembBank(silu_emb, self, self._temb_linears)
         h = x.to(torch.bfloat16).permute(0, 2, 3, 4, 1).reshape(b * t, hh, ww, c).contiguous()                          # b c t h w -> (b t) h w c
         hs = []
         for i, module in enumerate(self.input_blocks):

@@ -385,14 +385,15 @@ def add_rows(x: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] =
 
 
 def add_bcast(x: torch.Tensor, table: torch.Tensor, div: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [rows, D] (any leading shape) + table[(row // div) % len(table)]: a per-frame vector broadcast over `div` pixel rows."""
+    """x [rows, D] (any leading shape) + table[(row // div) % len(table)]: a per-frame vector broadcast over `div` pixel rows.  `table` may be a
+    column slice of a wider matrix (row stride a multiple of 8 elements, 16-byte aligned)."""
     _dev(x, name="x"); _dev(table, name="table")
-    if not x.is_contiguous() or not table.is_contiguous() or table.dim() != 2 or table.shape[1] != x.shape[-1]:
-        raise ValueError("add_bcast: x [..., D] and table [L, D], both contiguous")
+    if not x.is_contiguous() or table.dim() != 2 or table.shape[1] != x.shape[-1] or table.stride(1) != 1 or table.stride(0) % 8 or table.data_ptr() % 16:
+        raise ValueError("add_bcast: contiguous x [..., D] and table [L, D] with contiguous rows (row stride % 8 == 0, 16-byte aligned)")
     if out is None:
         out = torch.empty_like(x)
     D = x.shape[-1]
-    check(_lib.lib().mrag_add_bcast_bf16(_stream(), _p(x), _p(table), _p(out), x.numel() // D, D, int(div), table.shape[0]), "mrag_add_bcast_bf16")
+    check(_lib.lib().mrag_add_bcast_bf16(_stream(), _p(x), _p(table), _p(out), x.numel() // D, D, int(div), table.shape[0], table.stride(0)), "mrag_add_bcast_bf16")
     return out
 
 

@@ -22,7 +22,7 @@ from torch import nn
 
 from . import ops
 from .attn_processor import Attention
-from .dynamicrafter import _CACHE, _cat0, conv3x3, conv_t3
+from .dynamicrafter import _CACHE, TembBank, _cat0, conv3x3, conv_t3, temb_proj
 
 
 def _ln(n: nn.LayerNorm, x):
@@ -71,7 +71,7 @@ class ResnetBlock2D(nn.Module):
         N, H, W, C = x.shape
         h = ops.groupnorm(x.view(N, H * W, C), self.norm1.weight, self.norm1.bias, 32, self.norm1.eps, silu=True).view(N, H, W, C)
         h = conv3x3(h, self.conv1)
-        t = ops.linear(silu_temb, self.time_emb_proj.weight, self.time_emb_proj.bias)
+        t = temb_proj(silu_temb, self.time_emb_proj)                               # a slice of the step's one batched projection (TembBank)
         co = h.shape[-1]
         h = ops.groupnorm(h.view(N, H * W, co), self.norm2.weight, self.norm2.bias, 32, self.norm2.eps, silu=True, emb=t).view(N, H, W, co)
         if self.conv_shortcut is not None:
@@ -98,7 +98,7 @@ class TemporalResnetBlock(nn.Module):
         f = N // b
         h = ops.groupnorm(x.view(b, f * HW, C), self.norm1.weight, self.norm1.bias, 32, self.norm1.eps, silu=True).view(N, HW, C)
         h = conv_t3(h, self.conv1, b, f)
-        t = ops.linear(silu_temb, self.time_emb_proj.weight, self.time_emb_proj.bias)            # [(b f), C] -> one vector per frame
+        t = temb_proj(silu_temb, self.time_emb_proj)                                             # [(b f), C] -> one vector per frame
         h = ops.add_bcast(h, t, HW)
         h = ops.groupnorm(h.view(b, f * HW, C), self.norm2.weight, self.norm2.bias, 32, self.norm2.eps, silu=True).view(N, HW, C)
         return conv_t3(h, self.conv2, b, f, resid=x, acc_scale=branch_scale)
@@ -424,6 +424,9 @@ class UNetSpatioTemporalConditionModel(nn.Module):
         aug = self.add_embedding(ops.timestep_embedding(tid, self.addition_time_embed_dim).view(B, -1))
         emb = ops.add(emb, aug)
         silu_temb = ops.silu(emb).repeat_interleave(Fr, dim=0)                      # every resnet starts from SiLU(temb)
+        if getattr(self, "_temb_linears", None) is None:
+            self._temb_linears = [m.time_emb_proj for m in self.modules() if isinstance(m, (ResnetBlock2D, TemporalResnetBlock))]
+        silu_temb = TembBank(silu_temb.contiguous(), self, self._temb_linears)
         ehs = encoder_hidden_states.repeat_interleave(Fr, dim=0)                    # TupleTensor forwards this to both members (pipeline.py:39-40)
         ehs = ehs.to(torch.bfloat16)
         x = sample.to(torch.bfloat16).permute(0, 1, 3, 4, 2).reshape(B * Fr, H, W, C).contiguous()

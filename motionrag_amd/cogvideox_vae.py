@@ -361,6 +361,8 @@ class AutoencoderKLCogVideoX(nn.Module):
         self.tile_latent_min_height, self.tile_latent_min_width = int(self.tile_sample_min_height / down), int(self.tile_sample_min_width / down)
         self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
         self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
+        if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+            self.prepare_streams()            # weights already on the GPU: probe the tile streams at set-up, not inside the first decode
 
     def disable_tiling(self) -> None:
         self.use_tiling = False
@@ -388,6 +390,18 @@ class AutoencoderKLCogVideoX(nn.Module):
             elif isinstance(mod, CogVideoXResnetBlock3D) and hasattr(mod, "conv_shortcut"):
                 _w1(mod.conv_shortcut)
 
+    def prepare_streams(self, device=None) -> None:
+        """Probe the side-stream pool of the tiled decode / encode NOW (about 30 timed spin-kernel pairs with host synchronisation, once per process and
+        device) instead of inside the first tiled call: call it at model set-up, outside any timed region and before a HIP-graph capture.
+        `enable_tiling()` calls it when the weights already sit on a GPU.  The candidates come from torch's per-device stream pool (32 streams that exist
+        for the life of the process whether or not they are used), so the ones not chosen cost nothing once the probe returns."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            return
+        key = (str(dev), max(1, self.tile_streams))
+        if self.tile_streams > 1 and key not in _STREAMS:
+            _STREAMS[key] = concurrent_streams(dev, self.tile_streams)
+
     def _tiled(self, net, x: torch.Tensor, batch: int, tile: Tuple[int, int], overlap: Tuple[int, int], blend: Tuple[int, int], limit: Tuple[int, int]) -> torch.Tensor:
         """tiles are independent until the seams: they are issued round-robin over `tile_streams` HIP streams, so that the coarse levels' launches of one tile
         (a 30 x 45 latent tile of two frames is 2 700 GEMM rows: a third of the chip) overlap another tile's; the blend waits for all of them"""
@@ -403,6 +417,9 @@ class AutoencoderKLCogVideoX(nn.Module):
             self._warm(net)
             key = (str(x.device), n)
             if key not in _STREAMS:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("AutoencoderKLCogVideoX: the tile streams are probed with timed spin kernels and host synchronisation, which cannot run "
+                                       "inside a HIP-graph capture -- call vae.prepare_streams() (or run one tiled decode) before capturing")
                 _STREAMS[key] = concurrent_streams(x.device, n)
             for k, (i, j) in enumerate(origins):
                 side = _STREAMS[key][k % n]

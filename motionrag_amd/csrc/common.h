@@ -49,39 +49,40 @@ __device__ __forceinline__ f32x2 gelu_tanh_f2(const f32x2 x) {
   const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
   return x * r;
 }
-// exact-erf GELU.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): one v_rcp + one v_exp + 7 FMAs
-// instead of the ~40-instruction branchy libm erff -- in a short-K GEMM (K = 320 GEGLU projections) the libm call was
-// ~20k of a workgroup's ~43k cycles.  Every multiply-add is written as an explicit fma (and nothing else is contractable), so the scalar and
-// the packed form below perform the same operations per value whatever -ffp-contract says: identical bits.
-__device__ __forceinline__ float erf_as_f(float x) {
+// exact-erf GELU.  Phi's upper tail by Abramowitz & Stegun 7.1.26, Q(a) = 0.5 erfc(a / sqrt 2) = 0.5 t P(t) exp(-a^2 / 2), t = 1 / (1 + p a / sqrt 2)
+// (|error| <= 0.75e-7, far below a bf16 ulp), used symmetrically:  gelu(x) = x Phi(x) = max(x, 0) - |x| Q(|x|)  -- no copysign, no 1 + erf, no
+// 0.5 x: one v_rcp + one v_exp + 6 FMAs + 5 multiplies / max (13 vector instructions; the 1 - erf form took 16; the branchy libm erff ~40).  In a
+// short-K GEMM (the UNets' K = 320 GEGLU projections) this epilogue is as long as the K loop.  |x| rides as a source modifier.
+#ifndef MRAG_GELU_PACKED
+#define MRAG_GELU_PACKED 0     // 1: the same operations on value PAIRS with v_pk_*_f32 (A/B builds; measured no faster: packed fp32 issues at half rate here)
+#endif
+__device__ __forceinline__ float gelu_erf_f(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE reciprocal sequence
-  float pl = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-  pl = __builtin_fmaf(pl, t, 1.421413741f);
-  pl = __builtin_fmaf(pl, t, -0.284496736f);
-  pl = __builtin_fmaf(pl, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f((ax * -1.4426950408889634f) * ax);
-  const float r = __builtin_fmaf(-(pl * t), e, 1.0f);
-  return copysignf(r, x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.7071067811865476f, 1.0f));   // v_rcp_f32 (1 ulp), not the IEEE reciprocal sequence
+  float pl = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);                                // 0.5 P(t): the 1/2 of Q folded into the coefficients
+  pl = __builtin_fmaf(pl, t, 0.5f * 1.421413741f);
+  pl = __builtin_fmaf(pl, t, 0.5f * -0.284496736f);
+  pl = __builtin_fmaf(pl, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f((ax * -0.7213475204444817f) * ax);                               // exp(-x^2 / 2)
+  const float q = ((pl * t) * e) * ax;                                                                      // |x| Q(|x|)
+  return fmaxf(x, 0.0f) - q;
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return (0.5f * x) * (1.0f + erf_as_f(x * 0.7071067811865476f)); }
-// the same function on two values with packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add): 12 packed + 8 single instructions for TWO values
-// (10 issue slots per value against 17) -- the GEGLU epilogue of the UNets' K = 320 ... 1280 projections is as long as their K loop
 __device__ __forceinline__ f32x2 gelu_erf_f2(const f32x2 x) {
-  const f32x2 x0 = x * 0.7071067811865476f;
-  const f32x2 ax = {fabsf(x0[0]), fabsf(x0[1])};
-  const f32x2 one = {1.0f, 1.0f};
-  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f, 0.3275911f}, one);
+#if MRAG_GELU_PACKED
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f * 0.7071067811865476f, 0.3275911f * 0.7071067811865476f}, f32x2{1.0f, 1.0f});
   const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  f32x2 pl = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-  pl = __builtin_elementwise_fma(pl, t, f32x2{1.421413741f, 1.421413741f});
-  pl = __builtin_elementwise_fma(pl, t, f32x2{-0.284496736f, -0.284496736f});
-  pl = __builtin_elementwise_fma(pl, t, f32x2{0.254829592f, 0.254829592f});
-  const f32x2 z = (ax * -1.4426950408889634f) * ax;
+  f32x2 pl = __builtin_elementwise_fma(t, f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  const f32x2 z = (ax * -0.7213475204444817f) * ax;
   const f32x2 e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
-  const f32x2 r = __builtin_elementwise_fma(-(pl * t), e, one);
-  const f32x2 erf = {copysignf(r[0], x0[0]), copysignf(r[1], x0[1])};
-  return (x * 0.5f) * (erf + 1.0f);
+  const f32x2 q = ((pl * t) * e) * ax;
+  return f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)} - q;
+#else
+  return f32x2{gelu_erf_f(x[0]), gelu_erf_f(x[1])};
+#endif
 }
 // GEGLU on four (value, gate) pairs of one lane: v <- bf16(v) * act(bf16(g)) (the reference rounds both halves of proj(x) to bf16 before the product:
 // nn.Linear output dtype); TANH selects the tanh gate (T5's gated-gelu), else the exact-erf one (lvdm attention.py:448-455 / diffusers GEGLU)

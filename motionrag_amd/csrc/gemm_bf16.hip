@@ -1296,6 +1296,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 
 // the persistent four-wave launch: one workgroup per CU, 128 KB of LDS
 inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
+  // the K-tile stream walks A and W with 32-bit byte offsets inside a 256-row panel: (row * ld + chunk) * 2 with row <= 255 must stay below 4 GiB
+  // (a view with a huge leading dimension goes to the 8-wave kernel, whose row pointers are 64-bit)
+  if (256LL * (p0.lda > p0.ldw ? p0.lda : p0.ldw) * 2 >= (1LL << 32)) return MRAG_ENOTSUP;
   GemmP p = p0;
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);

@@ -72,6 +72,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if out is None:
         out = torch.empty(*x.shape[:-1], N // 2 if epilogue == EPI_GEGLU else N, dtype=torch.bfloat16, device=x.device)
     o2 = _rows(out)
+    if epilogue == EPI_RESID and acc_scale == 0.0:
+        # resid + 0 * (...) is the residual itself.  The C struct keeps 0 as "unset = 1" (zero-initialised callers), so an exact zero -- a saturated
+        # AlphaBlender, svd_unet: 1 - sigmoid(mix_factor) -- never reaches it: the product is skipped, not silently scaled by 1
+        o2.copy_(_rows(_dev(resid, name="resid")))
+        return out
     a = GemmArgs()
     a.A, a.W, a.bias, a.C = _p(x2), _p(weight), _p(bias), _p(o2)
     a.M, a.N, a.K = M, N, K
@@ -692,6 +697,9 @@ def conv_implicit(x: torch.Tensor, wk: torch.Tensor, bias: Optional[torch.Tensor
         _dev(resid, name="resid")
         if resid.numel() != out.numel() or not resid.is_contiguous():
             raise ValueError("conv_implicit: resid must be contiguous with the output's shape")
+        if acc_scale == 0.0:                  # see ops.linear: an exact zero means "the residual alone", the C struct's 0 means "unset = 1"
+            out.copy_(resid.view(out.shape))
+            return out
         a.resid, a.epilogue, a.acc_scale = _p(resid), EPI_RESID, acc_scale
     check(_lib.lib().mrag_conv_bf16(_stream(), ctypes.byref(a)), "mrag_conv_bf16")
     return out

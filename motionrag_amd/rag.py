@@ -79,8 +79,17 @@ def _read_meta(tdir: str):
 
 def add_to_db(annotations: List[dict], embeddings: Optional[np.ndarray] = None, embedder: Optional[Callable] = None,
               text_name: str = "llm_caption", db_path: str = "../data/rag.db") -> None:
-    """tools/build_rag_database.py:16-52: append rows (+ their text embeddings) to table `text_name`."""
+    """tools/build_rag_database.py:16-52: append rows (+ their text embeddings) to table `text_name`.  Needs pyarrow >= 14 (as RAGDatabase does).
+    Append order: vectors.npy is replaced first, meta.arrow second (two atomic renames); a reader that opens the table between them -- or after a
+    crash there -- sees more vectors than rows and opens the table as it was before the append (RAGDatabase.__init__)."""
     import pyarrow as pa
+    tdir0 = os.path.join(db_path, text_name)
+    if os.path.exists(os.path.join(tdir0, "vectors.npy")) and os.path.exists(os.path.join(tdir0, "meta.arrow")):
+        n_vec, n_meta = np.load(os.path.join(tdir0, "vectors.npy"), mmap_mode="r").shape[0], _read_meta(tdir0).num_rows
+        if n_vec > n_meta:                                  # an interrupted append: drop its orphan vectors before appending again
+            keep = np.ascontiguousarray(np.load(os.path.join(tdir0, "vectors.npy"), mmap_mode="r")[:n_meta])
+            np.save(os.path.join(tdir0, "vectors.npy.repair.npy"), keep)
+            os.replace(os.path.join(tdir0, "vectors.npy.repair.npy"), os.path.join(tdir0, "vectors.npy"))
     tdir = os.path.join(db_path, text_name)
     os.makedirs(tdir, exist_ok=True)
     if embeddings is None:
@@ -128,6 +137,13 @@ class RAGDatabase:
         tdir = os.path.join(db_path, table_name)
         self.vectors_host = np.load(os.path.join(tdir, "vectors.npy"), mmap_mode="c")      # a copy-on-write view of the file (never written): pages stream through on upload
         self.meta = _read_meta(tdir)
+        if self.vectors_host.shape[0] > self.meta.num_rows:
+            # add_to_db appends by replacing vectors.npy and THEN meta.arrow: a crash (or an open) between the two renames leaves the new vectors
+            # without their rows.  The table is append-only, so its first `num_rows` vectors are exactly the table before that append: open that.
+            import warnings
+            warnings.warn(f"{tdir}: {self.vectors_host.shape[0]} vectors but {self.meta.num_rows} metadata rows -- an interrupted add_to_db; "
+                          f"opening the {self.meta.num_rows} complete rows (re-run the append)")
+            self.vectors_host = self.vectors_host[:self.meta.num_rows]
         self._init_device(device, metric, embedder)
 
     @classmethod

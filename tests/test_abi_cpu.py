@@ -226,3 +226,17 @@ def test_dpm_scheduler_multipliers_match_the_restated_step():
             got = m1 * x - m2 * (m3 * x0 - m4 * mine_old if second else x0) + mn * draws[-1]
             assert torch.isfinite(got).all() and torch.allclose(got, want, rtol=1e-4, atol=1e-5)
             x, mine_old, xo, x0_old = got, x0, want, want_x0
+
+
+def test_add_to_db_recovers_from_an_interrupted_append(tmp_path):
+    """add_to_db replaces vectors.npy, then meta.arrow: a crash between the two renames leaves orphan vectors.  The next append drops them first
+    (the table is append-only, so its first `num_rows` vectors are the table before the interrupted append); host logic only, no GPU."""
+    import numpy as np
+    from motionrag_amd import rag
+    rows = [{"text": "a", "id": i, "uid": f"x/{i}", "dataset": "x", "video": f"v{i}", "start_sec": 0.0, "end_sec": 1.0} for i in range(5)]
+    rag.add_to_db(rows[:3], np.ones((3, 8), np.float32), text_name="t", db_path=str(tmp_path))
+    vp = tmp_path / "t" / "vectors.npy"
+    np.save(vp, np.concatenate([np.load(vp), 2 * np.ones((2, 8), np.float32)]))          # the state after a crash: 5 vectors, 3 rows
+    rag.add_to_db(rows[3:], 3 * np.ones((2, 8), np.float32), text_name="t", db_path=str(tmp_path))
+    assert np.load(vp)[:, 0].tolist() == [1.0, 1.0, 1.0, 3.0, 3.0]
+    assert rag._read_meta(str(tmp_path / "t")).column("id").to_pylist() == [0, 1, 2, 3, 4]

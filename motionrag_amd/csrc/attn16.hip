@@ -41,6 +41,23 @@ constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row
 #else
 #define KGROUP_OF(QB) ((QB) == 3 ? 2 : 4)
 #endif
+#ifndef MRAG_ATTN16_VPREFETCH
+#define MRAG_ATTN16_VPREFETCH 0
+#endif
+// Wave priority by phase (fast sweep): three workgroups per CU put three waves on every SIMD, each cycling through score MFMAs -> a vector-only block
+// (48 v_exp + 24 v_cvt_pk, ~480 issue cycles) -> P.V MFMAs.  With equal priorities the oldest wave wins the issue port, whatever it is doing; with
+// s_setprio (QK, EXP, PV) = (1, 0, 2) a wave in its exp block yields to waves that have MFMAs to issue, so the matrix pipe is fed first and the
+// exponentials fill the MFMAs' shadow.  Same-box interleaved, inside the denoise step (profiles/r4_attn_step_ab4.txt): 6.38 -> 6.04 ms per launch,
+// 565.6 -> 551.9 ms per step; (1,0,2) = (2,0,3) = (1,0,3) = (2,1,3); exp at the QK level (1,1,2) keeps only a fifth of the gain; exp ABOVE the MFMA
+// phases loses 7 %.  -DMRAG_ATTN16_SETPRIO=0 builds the loop without priorities.
+#ifndef MRAG_ATTN16_SETPRIO
+#define MRAG_ATTN16_SETPRIO 1
+#endif
+#ifndef MRAG_ATTN16_PRIO_QK
+#define MRAG_ATTN16_PRIO_QK 1
+#define MRAG_ATTN16_PRIO_EXP 0
+#define MRAG_ATTN16_PRIO_PV 2
+#endif
 #ifndef MRAG_ATTN16_OPTIMISTIC
 #define MRAG_ATTN16_OPTIMISTIC 1       // 0: every pass in the safe (checked) form -- the round-3 loop, kept buildable for A/B runs (tools/build_variant.sh)
 #endif
@@ -141,6 +158,47 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
       for (int qb = 0; qb < QB; ++qb) (*lacc)[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[st][qb], (*lacc)[qb], 0, 0, 0);
     }
   }
+}
+
+// experiment (-DMRAG_ATTN16_VPREFETCH=1): the first 32-key step's V^T fragments requested BEFORE the exp2 / pack block, so their LDS latency hides under
+// it (16 more live VGPRs through that block)
+template <int VOFF>
+__device__ __forceinline__ void pv16_request0(const Lane16& ln, u32x2 (&lo)[4], u32x2 (&hi)[4]) {
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF), "n"(VOFF + 2048) : "memory");
+}
+template <int VOFF, int QB>
+__device__ __forceinline__ void pv16_pref(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB], f32x4 (&lacc)[QB], u32x2 (&lo0)[4], u32x2 (&hi0)[4]) {
+  const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo0[0]), "+v"(lo0[1]), "+v"(lo0[2]), "+v"(lo0[3]), "+v"(hi0[0]), "+v"(hi0[1]), "+v"(hi0[2]), "+v"(hi0[3]) :: "memory");
+  u32x2 lo[4], hi[4];
+  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF + 4096), "n"(VOFF + 6144) : "memory");
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const u32x4 w = {lo0[db][0], lo0[db][1], hi0[db][0], hi0[db][1]};
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[0][qb], o[db][qb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[0][qb], lacc[qb], 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]) :: "memory");
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[1][qb], o[db][qb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[1][qb], lacc[qb], 0, 0, 0);
 }
 
 struct NoHook16 {
@@ -310,6 +368,9 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
       // stage is still resident).
       bool recentre = !FAST && (t == 0 && SUB == 0);
       bf16x8 pb[2][QB];
+#if MRAG_ATTN16_VPREFETCH
+      u32x2 vlo0[4], vhi0[4];
+#endif
       for (int pass = 0;; ++pass) {
         if constexpr (FAST) {
           f32x4 zero[QB];                       // S = K . Q^T + 0: the C operand is the inline constant
@@ -350,6 +411,12 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
           }
         }
         if constexpr (FAST) {
+#if MRAG_ATTN16_VPREFETCH
+          pv16_request0<V_BASE + OFF>(ln, vlo0, vhi0);
+#endif
+#if MRAG_ATTN16_SETPRIO
+          __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_EXP);
+#endif
           // P = exp2(S') rounded to bf16: nothing else on the vector pipe
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
@@ -397,7 +464,17 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
         }
       }
       if constexpr (FAST) {
+#if MRAG_ATTN16_SETPRIO
+        __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_PV);
+#endif
+#if MRAG_ATTN16_VPREFETCH
+        pv16_pref<V_BASE + OFF, QB>(ln, pb, o, lacc, vlo0, vhi0);
+#else
         pv16<V_BASE + OFF, QB, true>(ln, pb, o, &lacc);
+#endif
+#if MRAG_ATTN16_SETPRIO
+        __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_QK);
+#endif
       } else {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];

@@ -2,26 +2,27 @@
 // src/projects/condition/attn_processor.py:233-235; the spatial self-attention of the UNets, lvdm/modules/attention.py:189) on
 // v_mfma_f32_16x16x32_bf16.
 //
-// Why a second kernel family.  attn_flash.hip (v_mfma_f32_32x32x16_bf16, a lane owns a query row) is bound on this chip by power, not
-// by issue slots: its loop holds ~1.9 of 2.4 GHz.  Two things lower the energy per FLOP here:
+// Why a second kernel family.  attn_flash.hip (v_mfma_f32_32x32x16_bf16, a lane owns a query row) is bound on this chip by power and by vector
+// issue slots.  Here:
 //   * the 16x16x32 shape -- the guide measures 1.12-1.15x the FLOP/s of 32x32x16 in power-limited loops at equal cycles per FLOP
-//     (MI355X_MICROARCH.md, DVFS give-back item 7) -- and its 4-register C operand carries the running max into the score MFMAs for free
-//     (S' = K.Q^T - m leaves the chain; the 32x32 kernel spends 2 extra MFMAs per tile on that);
-//   * a LAZY running max: no per-tile row maximum at all.  The first tile of a row fixes m; afterwards P = exp2(S') is formed directly
-//     and only a tile whose row sum explodes (> 2^24: a score beat the stale max by > ~20 log2 units -- never on real activations)
-//     re-runs its score MFMAs, moves m and rescales O / l.  That removes the v_max3 chains, the half-wave swap and the threshold test
-//     (~22 of ~130 vector instructions per tile) from a loop whose vector pipe is the busier one.
+//     (MI355X_MICROARCH.md, DVFS give-back item 7);
+//   * (round 4) the OPTIMISTIC sweep: no running maximum at all -- P = exp2(S) straight from the score MFMAs, row sums on the matrix pipe
+//     (l^T += ONES . P^T), one range check per sweep; a workgroup whose check fails repeats the pass in the SAFE form (rounds 2-3: the first
+//     tile's maximum carried into the score MFMAs as their C operand, per-tile partial sums, exact re-centring of a tile whose sum explodes).
+//     The fast loop issues per 16 x 64 scores exactly 16 v_exp + 8 v_cvt_pk + 18 MFMAs; see the comment above `sweep` in the kernel;
+//   * (round 4) wave priorities by phase (s_setprio: score MFMAs 1, exp block 0, P.V MFMAs 2) so that the three waves of a SIMD feed the
+//     matrix pipe first and exponentiate in its shadow.
 //
 // Layout (QB = 16-query blocks per wave, 2 -> 32 rows per wave, 256 per 8-wave workgroup):
 //   S^T[key, q] = K . Q^T   A = K fragment  (row = key l & 15, k = d 32 ks + 8 (l >> 4) + j)   <- ds_read_b128 of the XOR-swizzled K tile
 //                           B = Q^T fragment (col = q   l & 15, same k)                          <- registers, pre-multiplied by scale * log2 e
-//                           C = (-m, -m, -m, -m) of the lane's query
+//                           C = 0 (fast sweep) | (-m, -m, -m, -m) of the lane's query (safe sweep)
 //     D: lane (q = l & 15, g = l >> 4) holds keys 16 kb + 4 g + r  (r = register 0..3)
 //   O^T[d, q] = V^T . P^T   A = V^T fragment (row = d 16 db + (l & 15), k-slot 8 g + j)         <- 2 x ds_read_b64_tr_b16 (keys 4 g.., 16 + 4 g..)
 //                           B = P^T fragment: k-slot 8 g + j = key 32 s + 4 g + j (j < 4) | 32 s + 16 + 4 g + j - 4 -- exactly the packed
 //                               accumulators of key blocks 2 s and 2 s + 1: P never leaves registers and needs no cross-lane move
 //     D: lane (q, g) holds d = 16 db + 4 g + r -> 8-byte stores.
-// K / V tiles of 64 keys ride the same 4-stage LDS-DMA ring as attn_flash.hip (scalar-base global_load_lds, counted vmcnt, raw s_barrier);
+// K / V tiles of 64 keys ride a 3-stage LDS-DMA ring like attn_flash.hip's (scalar-base global_load_lds, counted vmcnt, raw s_barrier);
 // V's 32-byte chunks are XOR-swizzled by (key >> 1) & 3 on the DMA source so the transposed reads are conflict-free.
 #include "attn_common.h"
 #include "../../include/mrag_hip.h"
@@ -40,9 +41,6 @@ constexpr float kBig = 16777216.0f;    // lazy-max trigger: a lane's partial row
 #define KGROUP_OF(QB) MRAG_ATTN16_KGROUP
 #else
 #define KGROUP_OF(QB) ((QB) == 3 ? 2 : 4)
-#endif
-#ifndef MRAG_ATTN16_VPREFETCH
-#define MRAG_ATTN16_VPREFETCH 0
 #endif
 // Wave priority by phase (fast sweep): three workgroups per CU put three waves on every SIMD, each cycling through score MFMAs -> a vector-only block
 // (48 v_exp + 24 v_cvt_pk, ~480 issue cycles) -> P.V MFMAs.  With equal priorities the oldest wave wins the issue port, whatever it is doing; with
@@ -158,47 +156,6 @@ __device__ __forceinline__ void pv16(const Lane16& ln, const bf16x8 (&pb)[2][QB]
       for (int qb = 0; qb < QB; ++qb) (*lacc)[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[st][qb], (*lacc)[qb], 0, 0, 0);
     }
   }
-}
-
-// experiment (-DMRAG_ATTN16_VPREFETCH=1): the first 32-key step's V^T fragments requested BEFORE the exp2 / pack block, so their LDS latency hides under
-// it (16 more live VGPRs through that block)
-template <int VOFF>
-__device__ __forceinline__ void pv16_request0(const Lane16& ln, u32x2 (&lo)[4], u32x2 (&hi)[4]) {
-  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
-               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF), "n"(VOFF + 2048) : "memory");
-}
-template <int VOFF, int QB>
-__device__ __forceinline__ void pv16_pref(const Lane16& ln, const bf16x8 (&pb)[2][QB], f32x4 (&o)[4][QB], f32x4 (&lacc)[QB], u32x2 (&lo0)[4], u32x2 (&hi0)[4]) {
-  const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo0[0]), "+v"(lo0[1]), "+v"(lo0[2]), "+v"(lo0[3]), "+v"(hi0[0]), "+v"(hi0[1]), "+v"(hi0[2]), "+v"(hi0[3]) :: "memory");
-  u32x2 lo[4], hi[4];
-  asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %1, %9 offset:%12\n\tds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
-               "ds_read_b64_tr_b16 %3, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
-               : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-               : "v"(ln.va[0]), "v"(ln.va[1]), "v"(ln.va[2]), "v"(ln.va[3]), "n"(VOFF + 4096), "n"(VOFF + 6144) : "memory");
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    const u32x4 w = {lo0[db][0], lo0[db][1], hi0[db][0], hi0[db][1]};
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[0][qb], o[db][qb], 0, 0, 0);
-  }
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[0][qb], lacc[qb], 0, 0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]) :: "memory");
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    const u32x4 w = {lo[db][0], lo[db][1], hi[db][0], hi[db][1]};
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), pb[1][qb], o[db][qb], 0, 0, 0);
-  }
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), pb[1][qb], lacc[qb], 0, 0, 0);
 }
 
 struct NoHook16 {
@@ -368,9 +325,6 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
       // stage is still resident).
       bool recentre = !FAST && (t == 0 && SUB == 0);
       bf16x8 pb[2][QB];
-#if MRAG_ATTN16_VPREFETCH
-      u32x2 vlo0[4], vhi0[4];
-#endif
       for (int pass = 0;; ++pass) {
         if constexpr (FAST) {
           f32x4 zero[QB];                       // S = K . Q^T + 0: the C operand is the inline constant
@@ -411,9 +365,6 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
           }
         }
         if constexpr (FAST) {
-#if MRAG_ATTN16_VPREFETCH
-          pv16_request0<V_BASE + OFF>(ln, vlo0, vhi0);
-#endif
 #if MRAG_ATTN16_SETPRIO
           __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_EXP);
 #endif
@@ -467,11 +418,7 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
 #if MRAG_ATTN16_SETPRIO
         __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_PV);
 #endif
-#if MRAG_ATTN16_VPREFETCH
-        pv16_pref<V_BASE + OFF, QB>(ln, pb, o, lacc, vlo0, vhi0);
-#else
         pv16<V_BASE + OFF, QB, true>(ln, pb, o, &lacc);
-#endif
 #if MRAG_ATTN16_SETPRIO
         __builtin_amdgcn_s_setprio(MRAG_ATTN16_PRIO_QK);
 #endif

@@ -368,10 +368,26 @@ class ActionTransformer(nn.Module):
 
     @torch.no_grad()
     def predict(self, batch, do_classifier_free_guidance: bool = False) -> torch.Tensor:
-        action_emb = self.batch_forward(batch, return_loss=False)[:, -1]
+        """module.py:325-331.  Same outputs with one vision pass instead of two and a half: the reference encodes the k reference clips AND the target
+        clip (whose motion tokens `forward` then drops, :298 `vision_emb[:, :-1]` -- SURVEY App. D.9) and, for classifier-free guidance, runs the
+        vision encoder + Resampler a second time on one all-zero clip (:327).  Clips are independent rows of both, so here the k references and
+        the zero clip go through them as ONE batch and the target clip's dead pass is skipped: a third fewer launches per clip."""
+        ref_videos = batch["ref_videos"].flip(1)                                   # reverse the similarity  :319
+        b, k = ref_videos.shape[:2]
+        ref_images = torch.cat([ref_videos[:, :, 0], batch["video"][:, None, 0]], dim=1)          # first frames incl. the target image  :320-321
+        vis_in = torch.cat([ref_videos, torch.zeros_like(ref_videos[:, 0:1])], dim=1) if do_classifier_free_guidance else ref_videos
+        vision_all = self.encode_vision(vis_in)                                     # [b, k (+ 1), l, c]
+        condition_emb = self.encode_condition(ref_images)
+        frame_tokens, d = vision_all.shape[-2:]
+        sos = _bf16(self.sos_token.detach()).expand(b, -1, -1)
+        x = torch.cat([sos, vision_all[:, :k].reshape(b, k * frame_tokens, d)], dim=1).contiguous()               # :298
+        if self.vision_pe is not None:
+            x = self.vision_pe(x)
+        x = ops.add(x, condition_emb.contiguous())
+        y = self.transformer(x, self.get_mask(k + 1, frame_tokens))
+        action_emb = y.view(b, k + 1, frame_tokens, d)[:, -1]
         if do_classifier_free_guidance:
-            uncond = self.encode_vision(torch.zeros_like(batch["ref_videos"][:, 0:1]))[:, 0]
-            action_emb = torch.cat([uncond, action_emb], dim=0)                    # uncond FIRST  :329
+            action_emb = torch.cat([vision_all[:, k], action_emb], dim=0)          # uncond FIRST  :329
         return action_emb
 
 

@@ -407,6 +407,38 @@ def test_attention16_lazy_max_recentre_and_legacy_agreement(hip):
     close(got, old.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=4e-2)           # the two kernel families agree to a bf16 ulp or two
 
 
+def test_attention16_optimistic_sweep_ranges(hip):
+    """attn16's fast sweep forms P = exp2(S) with NO running maximum and checks each row sum once per sweep against [2^-100, 2^100]; a workgroup
+    with a row outside repeats the pass in the checked form.  Softmax is invariant under a per-row offset of the logits, so three copies of one
+    problem with the logits shifted by a per-query constant must give the same output as the unshifted fp32 reference:
+      +-40 nats (+-58 log2 units: inside the fast sweep's range -- the scale-invariance claim itself),
+      +90 nats (exp2 overflows: inf row sums) and -90 nats (every P underflows: zero row sums) -- the checked re-run,
+    the shift riding on a dedicated feature (q[63] = c, k[63] = 8: c per logit after the 1/8 scale), exact in bf16.  Also a launch in which only
+    ONE row of one workgroup is out of range, and the key-split tail (Sq % 192 != 0 with a workspace) in both regimes."""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, H, Sq, Skv = 1, 2, 500, 1344
+    q, k, v = (torch.randn(B, S, H, 64, generator=g) for S in (Sq, Skv, Skv))
+    q[..., 63] = 0.0
+    k[..., 63] = 8.0
+    q, k, v = bf(q), bf(k), bf(v)
+    want = sdpa_ref(q, k, v)                                  # q[63] = 0: the shift feature does not enter the reference
+    base = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    close(base, want, scale=0.3)
+    for shift in (40.0, -40.0, 90.0, -90.0):
+        qs = q.clone()
+        qs[..., 63] = shift                                   # every logit of every row moves by `shift` nats (bf16-exact: 40, 90 and 8 are representable)
+        got = ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV))
+        # Q' = bf16(Q * scale * log2 e) rounds the shift feature too: the rounding is common to all keys of a row, so it cancels in the softmax
+        close(got, want, scale=0.3)
+        close(got, base.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=3e-2)
+    qs = q.clone()
+    qs[:, 137, 1, 63] = 95.0                                  # one row of one (b, h): its workgroup takes the checked re-run, the others stay fast
+    qs[:, 499, 0, 63] = -95.0                                 # a row of the ragged last query tile (the key-split units when a workspace is given)
+    got = ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV))
+    close(got, want, scale=0.3)
+
+
 def test_attention_large_sequence_properties(hip):
     """BASELINE-size sequence (S = 17 776, the CogVideoX joint length), checked through size-independent properties:
     (1) with V = ones the output is exactly 1 (softmax rows sum to one); (2) permuting the keys/values does not change

@@ -366,6 +366,14 @@ class ActionTransformer(nn.Module):
         ref_images = videos[:, :, 0]
         return self.forward(videos, ref_images, return_loss, ignore_ref_loss)
 
+    parallel_branches = True       # run the condition branch of `predict` on a side stream (False: everything on the current stream)
+
+    def _side_stream(self, device):
+        ent = getattr(self, "_side", None)
+        if ent is None or ent[0] != str(device):
+            ent = self._side = (str(device), torch.cuda.Stream(device=device))
+        return ent[1]
+
     @torch.no_grad()
     def predict(self, batch, do_classifier_free_guidance: bool = False) -> torch.Tensor:
         """module.py:325-331.  Same outputs with one vision pass instead of two and a half: the reference encodes the k reference clips AND the target
@@ -376,8 +384,21 @@ class ActionTransformer(nn.Module):
         b, k = ref_videos.shape[:2]
         ref_images = torch.cat([ref_videos[:, :, 0], batch["video"][:, None, 0]], dim=1)          # first frames incl. the target image  :320-321
         vis_in = torch.cat([ref_videos, torch.zeros_like(ref_videos[:, 0:1])], dim=1) if do_classifier_free_guidance else ref_videos
-        vision_all = self.encode_vision(vis_in)                                     # [b, k (+ 1), l, c]
-        condition_emb = self.encode_condition(ref_images)
+        # the motion branch (video encoder + Resampler) and the condition branch (image encoder + Resampler + PE) share nothing until the encoder's input:
+        # both are chains of small launches (24-96 workgroups each on 256 CUs), so the condition branch runs on a side stream beside the other
+        cur = torch.cuda.current_stream(ref_videos.device)
+        side = self._side_stream(ref_videos.device) if self.parallel_branches else None
+        if side is not None:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                condition_emb = self.encode_condition(ref_images).contiguous()
+            vision_all = self.encode_vision(vis_in)                                 # [b, k (+ 1), l, c]
+            cur.wait_stream(side)
+            condition_emb.record_stream(cur)
+            ref_images.record_stream(side)
+        else:
+            vision_all = self.encode_vision(vis_in)
+            condition_emb = self.encode_condition(ref_images)
         frame_tokens, d = vision_all.shape[-2:]
         sos = _bf16(self.sos_token.detach()).expand(b, -1, -1)
         x = torch.cat([sos, vision_all[:, :k].reshape(b, k * frame_tokens, d)], dim=1).contiguous()               # :298

@@ -18,3 +18,13 @@ _, cam, _ = bench.build_models(dev, 1, 13)
 batch = {"ref_videos": torch.zeros(1, 9, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev), "video": torch.zeros(1, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev)}
 dt = timeit(lambda: cam.predict(batch, do_classifier_free_guidance=True), iters=int(os.environ.get("ITERS", "20")), warm=3)
 print(f"CAMA predict: {dt*1e3:.3f} ms per clip")
+if os.environ.get("CAMA_AB"):          # side-stream condition branch on / off, eager and as one HIP graph, interleaved
+    from motionrag_amd.cama import GraphedPredict
+    for rnd in range(3):
+        for par in (True, False):
+            cam.parallel_branches = par
+            e = timeit(lambda: cam.predict(batch, do_classifier_free_guidance=True), iters=20, warm=3)
+            gp = GraphedPredict(cam, do_classifier_free_guidance=True)
+            gp(batch)
+            g = timeit(lambda: gp(batch), iters=20, warm=3)
+            print(f"parallel_branches={par}: eager {e*1e3:.3f} ms, one HIP graph {g*1e3:.3f} ms", flush=True)

@@ -74,6 +74,13 @@ def test_cama_predict_against_reference_golden(hip, golden_dir):
     assert model.vision_proj.cross_attention_dim == 1024                     # read by cogvideox/module.py:260
     ev = model.encode_vision(torch.zeros_like(batch["ref_videos"][:, 0:1]))
     close_exactish(ev[:, 0], out[:2], rtol=1e-6, atol_frac=1e-6)                      # uncond half == encode_vision(zeros)[:, 0]
+    # predict's restructuring (one batched vision pass + the condition branch on a side stream, round 4) against the reference's literal order of
+    # operations: batch_forward (k references + the target clip through the vision path, module.py:317-323) + the separate zero-clip pass (:327)
+    literal = torch.cat([ev[:, 0], model.batch_forward(batch, return_loss=False)[:, -1]], dim=0)
+    assert torch.equal(out, literal), "batched / two-stream predict differs from the literal two-pass form"
+    model.parallel_branches = False
+    assert torch.equal(model.predict(batch, do_classifier_free_guidance=True), out)
+    assert torch.equal(model.predict(batch, do_classifier_free_guidance=False), out[2:])
 
 
 def test_condition_fusion_against_reference_golden(hip, golden_dir):

@@ -549,7 +549,9 @@ int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* worksp
   if ((long long)p.Skv * p.k_ss * 2 >= 0xffffffffLL || (long long)p.Skv * p.v_ss * 2 >= 0xffffffffLL) return MRAG_ENOTSUP;   // walked 32-bit DMA offsets
   if (pl) {
     if (pl->chunk_keys % KVB != 0 || pl->rem_rows >= mrag_attn16_rows(qb)) return MRAG_ENOTSUP;
+    if (qb == 2) return launch16_split<2, 4, 2>(s, p, pl, workspace);        // A/B shape: 32 rows per wave, FOUR workgroups per CU, two-stage ring (32 KB of LDS each)
     return qb == 4 ? launch16_split<4, 4, 3>(s, p, pl, workspace) : launch16_split<3, 4, 3>(s, p, pl, workspace);
   }
+  if (qb == 2) return launch16_plain<2, 4, 2>(s, p);
   return qb == 4 ? launch16_plain<4, 4, 3>(s, p) : launch16_plain<3, 4, 3>(s, p);
 }

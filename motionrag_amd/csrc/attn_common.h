@@ -36,7 +36,7 @@ inline int mrag_attn16_qb(int /*Sq*/) {
 #endif
 }
 inline int mrag_attn16_rows(int qb) { return 64 * qb; }
-inline int mrag_attn16_slots(int qb) { return (qb == 3 ? 3 : 2) * 256; }
+inline int mrag_attn16_slots(int qb) { return (qb == 3 ? 3 : (qb == 2 ? 4 : 2)) * 256; }
 // attn16.hip: long unmasked sequences (Sq > 128, Skv >= 256) on v_mfma_f32_16x16x32_bf16; returns MRAG_ENOTSUP for shapes it does not take
 int mrag_launch_attn16(hipStream_t s, AttnP p, const SplitPlan* pl, void* workspace, int qb);
 

@@ -21,7 +21,7 @@ for (M, N, K) in SHAPES:
     assert L.mrag_debug_set_gemm_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
     a = GemmArgs()
     a.A, a.W, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldw, a.ldc = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr(), M, N, K, K, K, N
-    a.tuning = 3 << 4
+    a.tuning = int(os.environ.get("CFG", "3")) << 4
     if EPI in ("gate", "resid"):
         r = torch.randn(M, N, device="cuda").to(torch.bfloat16)
         g0, g1 = (torch.randn(4, N, device="cuda").to(torch.bfloat16) for _ in range(2))

@@ -361,7 +361,14 @@ inline bool small_db(long long n_rows, int nq) { return nq <= 4 && n_rows < 256L
 void plan(long long n_rows, int nq, int* slices, int* rows_per_slice) {
   const int QT = pick_qt(nq);
   const int ntq = (nq + QT - 1) / QT;
-  const int MAX_SLICES = 2048;
+  // workgroups along the database.  A single query (QT = 1) streams best with 512: two workgroups per CU, ~2 000 rows each at 10^6 rows, and only
+  // 2 048 per-wave lists for the last arriver to merge -- 523 us = 5.88 TB/s at 10^6 rows against 627 us with 2 048 slices, 6.60 against 6.23 TB/s
+  // at 4 x 10^6 (256: 4.1 TB/s, 384: 5.2, 768: 5.8; round 4, tools/topk_slices_probe.py).  Query tiles keep 2 048 (1 024 costs them 15 %).
+#ifdef MRAG_TOPK_MAX_SLICES
+  const int MAX_SLICES = MRAG_TOPK_MAX_SLICES;
+#else
+  const int MAX_SLICES = QT == 1 ? 512 : 2048;
+#endif
   const int ROWS = small_db(n_rows, nq) ? 64 : 256;     // rows per workgroup pass (4 waves x 16 or 64 rows; 8 rows per wave measured slower:
                                                         // 34.0 vs 27.5 us at 10 k rows -- the 1 256-list merge of the last arriver then dominates)
   long long tiles = (n_rows + ROWS - 1) / ROWS;

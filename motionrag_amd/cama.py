@@ -386,8 +386,9 @@ class ActionTransformer(nn.Module):
         vis_in = torch.cat([ref_videos, torch.zeros_like(ref_videos[:, 0:1])], dim=1) if do_classifier_free_guidance else ref_videos
         # the motion branch (video encoder + Resampler) and the condition branch (image encoder + Resampler + PE) share nothing until the encoder's input:
         # both are chains of small launches (24-96 workgroups each on 256 CUs), so the condition branch runs on a side stream beside the other
-        cur = torch.cuda.current_stream(ref_videos.device)
-        side = self._side_stream(ref_videos.device) if self.parallel_branches else None
+        on_gpu = ref_videos.is_cuda                                                # (CPU tensors fall through to the ops' HipOnly error)
+        cur = torch.cuda.current_stream(ref_videos.device) if on_gpu else None
+        side = self._side_stream(ref_videos.device) if (self.parallel_branches and on_gpu) else None
         if side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side):

@@ -1466,7 +1466,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   if (const int cfg = (a->tuning >> 4) & 0xf) {   // developer knob (tools/microbench.py); 0 = the shipped choice below
     if (cfg == 1 && t256 >= 192) return launch_cfg<4, 4, 4, 4>(s, p, epi);   // 256x256, 16 waves (4 per SIMD)
     if (cfg == 2) return launch_cfg<2, 2, 4, 4>(s, p, epi);                  // 128x128, 4 waves, 2 workgroups per CU
-    if (cfg == 4) {                                                          // the persistent kernel whatever the tile count (small-M experiments)
+    if (cfg == 4) {                                                          // the persistent kernel whatever the tile count (small-M experiments: T5 11.3 -> 13.6 ms; 256x128 8-wave tiles: 12.9 ms -- the 128x128 tile stays)
       const int rc = launch_w4(s, p, epi);
       if (rc != MRAG_ENOTSUP) return rc;
     }

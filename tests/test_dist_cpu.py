@@ -52,6 +52,51 @@ def test_gather_latents_world1_is_identity():
     assert gather_latents(x, 1) is x
 
 
+def _one_rank_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from motionrag_amd.dist import SequenceParallel, gather_latents
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.arange(12, dtype=torch.float32).view(2, 2, 3).to(torch.bfloat16)
+        forced = gather_latents(x, 1, force=True)                 # a launcher-started one-rank group: the collective runs all the same (bench.py)
+        rows = SequenceParallel(0, 1).all_gather_rows_async(x.contiguous()).wait()
+        ret[0] = (forced is not x, forced.float().tolist() == x.float().tolist(), rows.float().tolist() == x.float().tolist(), SequenceParallel(0, 1).shard(17776))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_one_rank_process_group_runs_the_collectives():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (tests/test_gpu_multiproc.py runs it over RCCL): with a one-rank process group the
+    end-of-loop gather (`force=True`) and the K / V row gather go THROUGH the backend and return the rank's own data; without a group `force` is inert"""
+    from motionrag_amd.dist import gather_latents
+    x = torch.randn(2, 3)
+    assert gather_latents(x, 1, force=True) is x                  # no process group: identity
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_one_rank_worker, args=(1, 31500 + os.getpid() % 2000, ret), nprocs=1, join=True)
+    assert ret[0] == (True, True, True, (0, 17776))
+
+
+def test_bench_detects_an_attached_profiler(monkeypatch):
+    """bench.py skips the shipped-configuration clip (a second shape of the dominant kernel) when rocprofv3's preload is present, so that
+    `rocprofv3 --stats -- python3 bench.py` averages that kernel over ONE shape"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mrag_bench_cpu", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in [k for k in os.environ if k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_"))]:
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    assert not bench.profiler_attached()
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.profiler_attached()
+    monkeypatch.setenv("LD_PRELOAD", "")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x.so")
+    assert bench.profiler_attached()
+
+
 def _sp_worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     from motionrag_amd.dist import SequenceParallel

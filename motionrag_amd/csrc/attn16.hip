@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, QB == 3 ? 3 : (QB == 4 ? 2 : 4)) void attn
       u32x2 out;
       out[0] = pack_bf2(v[0], v[1]);
       out[1] = pack_bf2(v[2], v[3]);
-      *(u32x2*)(p.O + off) = out;
+      *(u32x2*)(p.O + off) = out;          // (non-temporal Q loads / O stores measured: fabric reads 1.13 -> 0.98 GiB but writes 0.27 -> 0.60 GiB per launch and +0.5 % time: not kept, profiles/r4_attn_step_ab8.txt)
     }
   }
 }

@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=42, help="debug only: the judged workload is 42")
     ap.add_argument("--frames", type=int, default=49, help="debug only: the judged workload is 49")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the measured ceilings (sustained MFMA probe, device copy, library GEMMs; ~5 s) printed as roofline.ceilings")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured 50-step end-to-end clip (about 35 s; N = 1 only)")
     ap.add_argument("--no-shipped-config", action="store_true", help="skip the clip of the reference's SHIPPED evaluation configuration (17 frames, 25 DPM steps, guidance 3; ~6 s), "
                     "which the default run measures after the timed region.  It launches the dominant attention kernel at a second shape (S = 6 976), so it is ALSO skipped "
@@ -149,9 +150,72 @@ def cpu_baseline_sample():
 
 
 def profiler_attached() -> bool:
-    """rocprofv3 / rocprof run the program with their tool library preloaded and ROCP* / ROCPROF* variables set"""
-    pre = os.environ.get("LD_PRELOAD", "")
-    return "rocprof" in pre or "roctracer" in pre or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+    """rocprofv3 runs the program with its TOOL LIBRARY injected (LD_PRELOAD / ROCP_TOOL_LIBRARIES = .../librocprofiler-sdk-tool.so).  Only that is a
+    profiler: a container that merely exports some ROCPROF_* variable does not change what the default run measures."""
+    return any("rocprofiler-sdk-tool" in os.environ.get(k, "") or "librocprofv3" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES"))
+
+
+def measured_ceilings(dev, seconds: float = 1.0):
+    """What THIS box sustains, measured after the timed region (same power state), printed beside the nominal peaks as `roofline.ceilings`:
+      mfma_bf16_sustained_tflops  the library's register-resident 16x16x32 MFMA loop on random operand bits (csrc/probe.hip; no memory traffic)
+      d2d_copy_TBps               a device-to-device copy of 1 GiB, bytes read + bytes written per second
+      library_gemm_tflops         torch.mm (hipBLASLt / rocBLAS: a measured LIBRARY ceiling, NOT the product path) at the DiT's four GEMM shapes
+    None for a leg that failed; never fatal for the headline line."""
+    import ctypes
+    from motionrag_amd import _lib
+    out = {"mfma_bf16_sustained_tflops": None, "d2d_copy_TBps": None, "library_gemm_tflops": None}
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    try:
+        L = _lib.lib()
+        g = torch.Generator(device="cpu").manual_seed(99)
+        operands = torch.randn(1 << 20, generator=g).to(dev, torch.bfloat16)                # random bits: the data-dependent power of a real activation
+        sink = torch.empty(256 * 512, dtype=torch.float32, device=dev)
+        iters = 20000
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        launch = lambda: _lib.check(L.mrag_probe_mfma_bf16(st, ctypes.c_void_p(operands.data_ptr()), operands.numel() * 2, ctypes.c_void_p(sink.data_ptr()), iters),  # noqa: E731
+                                    "mrag_probe_mfma_bf16")
+        one = timed(launch, 2)
+        reps = max(2, int(seconds / max(one, 1e-4)))
+        dt = timed(launch, reps)                                                             # >= `seconds` of back-to-back launches: the sustained state, not a cold burst
+        out["mfma_bf16_sustained_tflops"] = round(L.mrag_probe_mfma_flops(iters) / dt / 1e12, 1)
+        out["mfma_probe"] = f"{reps} launches x {iters} iterations x 32 v_mfma_f32_16x16x32_bf16 per wave, 8 waves per CU, random operand bits"
+    except Exception as e:                           # noqa: BLE001
+        out["mfma_probe"] = f"failed: {type(e).__name__}: {e}"[:200]
+    try:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+        dst = torch.empty_like(src)
+        dt = timed(lambda: dst.copy_(src), 10)
+        out["d2d_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)
+        del src, dst
+    except Exception as e:                           # noqa: BLE001
+        out["d2d_copy"] = f"failed: {type(e).__name__}: {e}"[:200]
+    try:
+        lib = {}
+        g = torch.Generator(device="cpu").manual_seed(98)
+        for name, (M, N, K) in {"qkv_35552x9216x3072": (35552, 9216, 3072), "to_out_35552x3072x3072": (35552, 3072, 3072),
+                                "ff1_35552x12288x3072": (35552, 12288, 3072), "ff2_35552x3072x12288": (35552, 3072, 12288)}.items():
+            a = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)
+            w = torch.randn(K, N, generator=g).to(dev, torch.bfloat16)
+            c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            dt = timed(lambda: torch.mm(a, w, out=c), 10)
+            lib[name] = round(2.0 * M * N * K / dt / 1e12, 1)
+            del a, w, c
+        out["library_gemm_tflops"] = lib
+        out["library_gemm_note"] = "torch.mm (hipBLASLt / rocBLAS), plain bf16 GEMM without bias or epilogue: a measured library ceiling, not the product path"
+    except Exception as e:                           # noqa: BLE001
+        out["library_gemm_note"] = f"failed: {type(e).__name__}: {e}"[:200]
+    torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(args):
@@ -286,6 +350,8 @@ def main():
     elapsed = time.perf_counter() - t0
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     assert torch.isfinite(gathered.float()).all(), "non-finite latents"
+    # the box's measured ceilings, right after the timed region (the part is in the step's power state), rank 0 at N = 1 only
+    ceilings = measured_ceilings(dev) if (world == 1 and not args.no_ceilings) else None
 
     # BASELINE's second metric, MEASURED outside the timed region: one whole clip = CAMA + 50 motion-injected DDIM steps (N = 1 only)
     e2e_sec, e2e_graph_sec = None, None
@@ -426,8 +492,10 @@ def main():
             "e2e_sec_per_clip_50_steps_est": round(cama_ms * 1e-3 + 50 * ms_per_step * 1e-3, 2),
             "e2e_sec_per_clip_50_steps_measured": round(e2e_sec, 2) if e2e_sec is not None else None,
             "e2e_sec_per_clip_50_steps_hip_graph": round(e2e_graph_sec, 2) if isinstance(e2e_graph_sec, float) else e2e_graph_sec,
-            "e2e_sec_per_clip_shipped_config_17f_25_dpm_steps": round(shipped_sec, 2) if isinstance(shipped_sec, float) else (
-                "skipped: profiler attached (--shipped-config forces it)" if shipped_sec is None and profiled and not args.no_shipped_config and world == 1 else shipped_sec),
+            "e2e_sec_per_clip_shipped_config_17f_25_dpm_steps": round(shipped_sec, 2) if isinstance(shipped_sec, float) else None,     # a number or null, never a string
+            "shipped_config_skipped_reason": (None if isinstance(shipped_sec, float) else shipped_sec if isinstance(shipped_sec, str) else
+                                              "rocprofv3 tool library injected (--shipped-config forces the clip)" if profiled and not args.no_shipped_config and world == 1 and not args.shipped_config
+                                              else "not requested / N > 1 / reduced model"),
             "process_group": (("gloo" if one_gpu else "nccl") + f", world {world}") if use_pg else None,
             "secondary_workloads": secondary,
             "roofline": {"kernel": "attn16_kernel<3,4,3,true> + attn_combine_kernel (joint text+video flash attention on 16x16x32 MFMAs: optimistic sweep without a running max, row sums on the matrix pipe, key-split tail; 48 heads x 64, S=%d, B=2)" % S,
@@ -435,7 +503,11 @@ def main():
                          "frac": round(flops / avg / 1e12 / 2500.0, 4) if durs else None, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "traffic_measured_in_run": False,
                          "launches": len(durs), "avg_launch_ms": round(avg * 1e3, 4) if durs else None,
-                         "algorithmic_tflop_per_launch": round(flops / 1e12, 3)},
+                         "algorithmic_tflop_per_launch": round(flops / 1e12, 3),
+                         # measured on THIS box right after the timed region (measured_ceilings): `peak` above stays the nominal 2.5 PFLOP/s of MI355X_MICROARCH.md
+                         "ceilings": ceilings,
+                         "frac_of_sustained": (round(flops / avg / 1e12 / ceilings["mfma_bf16_sustained_tflops"], 4)
+                                               if durs and ceilings and ceilings.get("mfma_bf16_sustained_tflops") else None)},
         }
         try:     # whole-clip time of the reference's eval path (README.md:47-48 quotes s/clip): every stage is a component measured in THIS run, at the shipped model sizes
             sw = secondary or {}

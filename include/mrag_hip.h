@@ -15,9 +15,11 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream);
  *   - all pointers are device pointers unless the name ends in _host;
  *   - bf16 tensors are raw uint16 bit patterns; fp32 accumulate everywhere;
- *   - no hidden allocation, no global mutable state, no environment reads:
- *     workspaces are passed in, developer tuning knobs are explicit `tuning`
- *     fields of the argument structs (0 = the shipped behaviour);
+ *   - no hidden allocation, no environment reads, and no global mutable state
+ *     on the launch path: workspaces are passed in, developer tuning knobs are
+ *     explicit `tuning` fields of the argument structs (0 = the shipped
+ *     behaviour).  The ONE piece of process-wide state is a table of
+ *     diagnostic launch counters (mrag_dispatch_counts) that nothing reads back;
  *   - row-major, innermost dimension contiguous; ld* / stride* are in ELEMENTS.
  */
 #ifndef MRAG_HIP_H
@@ -37,6 +39,58 @@ extern "C" {
 int mrag_abi_version(void);
 /* returns "gfx950" -- the only code object in the library */
 const char* mrag_target_arch(void);
+/* hex digest (sha256, first 16 digits) of the sources this binary was built from -- every csrc file + this header + the per-file compile flags, fed in
+ * by the build as -DMRAG_SOURCE_HASH: the loader compares it with the digest of the sources beside it and refuses a stale binary
+ * (motionrag_amd/_lib.py: source_hash / lib).  "unstamped" for a hand build.                                                                    */
+const char* mrag_source_hash(void);
+
+/* ------------------------------------------------------------------------ */
+/* Diagnostic launch counters: WHICH KERNEL an entry point dispatched to.     */
+/* Every launch site of the library bumps one slot (relaxed atomic add on the */
+/* host, nanoseconds); nothing on the launch path reads them.  Tests read     */
+/* them around a module call to assert that a full-width shape really ran on   */
+/* the production kernel (persistent four-wave GEMM, attn16, the folded motion */
+/* branch, the wide / implicit-GEMM tiles) and not on a fallback tile.  A      */
+/* launch recorded into a HIP graph counts once, at capture.                   */
+/* ------------------------------------------------------------------------ */
+enum mrag_kernel_id {
+  MRAG_K_GEMM_W4 = 0,          /* gemm_w4_kernel: persistent four-wave 256x256x64, plain / GELU / residual / gate epilogues */
+  MRAG_K_GEMM_W4_QKNORM_ROPE,  /* gemm_w4_kernel<MRAG_EPI_QKNORM_ROPE>: the fused QKV projection                           */
+  MRAG_K_GEMM_W4_GEGLU,        /* gemm_w4_kernel<GEGLU>                                                                     */
+  MRAG_K_GEMM_256x256,         /* gemm_bf16_kernel 8-wave 256x256 tile (16-wave developer variant included)                 */
+  MRAG_K_GEMM_256x320,         /* 8-wave 256x320 tile (N = 320 / 960 / 1 600 ...)                                           */
+  MRAG_K_GEMM_256x128,
+  MRAG_K_GEMM_128x128,         /* the small-problem tile (< 192 tiles of 256x256)                                           */
+  MRAG_K_GEMM_STREAMK_TAIL,
+  MRAG_K_CONV3_W4,             /* 3x3 (and causal 3x3x3) implicit-GEMM convolution on the persistent four-wave kernel       */
+  MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128,
+  MRAG_K_CONVT_W4,             /* (3,1,1) temporal convolution on the persistent four-wave kernel                           */
+  MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_128x128,
+  MRAG_K_ATTN16,               /* attn16_kernel, whole query tiles                                                          */
+  MRAG_K_ATTN16_KSPLIT,        /* attn16_kernel with the key-split ragged tail (+ MRAG_K_ATTN_COMBINE)                      */
+  MRAG_K_ATTN_FLASH,           /* attn_fwd_kernel (32x32x16): masked / biased / short launches                              */
+  MRAG_K_ATTN_FLASH_KSPLIT,
+  MRAG_K_ATTN_COMBINE,
+  MRAG_K_ATTN_TINY,            /* <= 16 keys, one wave per (row, head) pair                                                 */
+  MRAG_K_ATTN_SMALL,           /* mrag_attn_small_bf16                                                                      */
+  MRAG_K_ATTN_FP8,             /* attn8_kernel                                                                              */
+  MRAG_K_IP_ATTN_FOLDED,       /* ip_attn_folded_kernel                                                                     */
+  MRAG_K_LAYERNORM, MRAG_K_QKNORM_ROPE,
+  MRAG_K_GN_STATS, MRAG_K_GN_FOLD, MRAG_K_GN_APPLY, MRAG_K_GN_APPLY_MOD,
+  MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
+  MRAG_K_COUNT
+};
+/* copies min(n, MRAG_K_COUNT) counters into out_host (HOST memory) and returns MRAG_K_COUNT */
+int mrag_dispatch_counts(uint64_t* out_host, int32_t n);
+/* the enumerator's name without the MRAG_K_ prefix ("GEMM_W4", ...), NULL outside the range */
+const char* mrag_dispatch_name(int32_t id);
+
+/* Measurement probe (NOT on the product path; bench.py prints its result as `roofline.ceilings.mfma_bf16_sustained_tflops`): a register-resident loop of
+ * v_mfma_f32_16x16x32_bf16 over the caller's (random) operand bits -- 256 workgroups x 8 waves x `iters` x 32 MFMAs, no LDS, no memory traffic inside the
+ * loop.  What the part sustains on a dense bf16 matrix load in its current power state, against the nominal 2.5 PFLOP/s of SURVEY.md section 8(d).
+ * operands: >= 16 bytes of bf16 bits, 16-byte aligned; out: 256 * 512 floats (a checksum per lane, written so the loop cannot be elided).               */
+int64_t mrag_probe_mfma_flops(int32_t iters);
+int mrag_probe_mfma_bf16(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])     bf16 in/out      */

@@ -16,15 +16,15 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
-SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip"]
-ABI_VERSION = 8
+SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip", "probe.hip"]
+ABI_VERSION = 9
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"],
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mrag_abi_version", "mrag_target_arch", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
+    "mrag_abi_version", "mrag_target_arch", "mrag_source_hash", "mrag_dispatch_counts", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_bf16", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
@@ -36,7 +36,7 @@ SYMBOLS = [
 
 
 # entry points whose result is not the int32 status code (their restype is set explicitly in lib())
-_NON_INT_RESULT = ("mrag_target_arch", "mrag_gemm_workspace_bytes", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
+_NON_INT_RESULT = ("mrag_target_arch", "mrag_source_hash", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_gemm_workspace_bytes", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
                    "mrag_resampler_workspace_bytes", "mrag_cama_encoder_workspace_bytes")
 
 
@@ -149,29 +149,80 @@ MRAG_OK, MRAG_EINVAL, MRAG_ENOTSUP = 0, -1, -2
 _lib = None
 
 
+def source_hash() -> str:
+    """digest of what the library is built from: every file of csrc/, include/mrag_hip.h and the per-file compile flags (sha256, 16 hex digits).
+    The build stamps it into the binary (`mrag_source_hash()`); `lib()` refuses a binary whose stamp differs -- modification times are not
+    consulted (a checkout, a copy to the GPU box or a variant build can leave a stale binary NEWER than the sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(_HERE, "..", "include", "mrag_hip.h"), "rb") as fh:
+        h.update(b"mrag_hip.h\0" + fh.read())
+    h.update(repr((SOURCES, sorted(EXTRA_FLAGS.items()), os.environ.get("MRAG_EXTRA_HIPCC_FLAGS", ""))).encode())
+    return h.hexdigest()[:16]
+
+
+def binary_stamp(path: str) -> str:
+    """the source digest a built library carries, read from the file's bytes (no dlopen); '' when absent"""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return ""
+    i = blob.find(b"MRAG_SOURCE_HASH=")
+    if i < 0:
+        return ""
+    j = blob.find(b"\0", i)
+    return blob[i + 17:j].decode("ascii", "replace")
+
+
 def build(verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into motionrag_amd/libmrag_hip.so (in-tree; needs no GPU)."""
+    """Compile csrc/*.hip for gfx950 into motionrag_amd/libmrag_hip.so (in-tree; needs no GPU).  Rebuilds whenever the binary's stamp is not
+    the digest of the sources beside it.  MRAG_EXTRA_HIPCC_FLAGS (developer A/B builds, tools/build_variant.sh) is part of the digest."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    newest_src = max(os.path.getmtime(os.path.join(_CSRC, f)) for f in os.listdir(_CSRC))
-    newest_src = max(newest_src, os.path.getmtime(os.path.join(_HERE, "..", "include", "mrag_hip.h")))
-    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest_src:
+    want = source_hash()
+    if os.path.exists(LIB_PATH) and binary_stamp(LIB_PATH) == want:
         return LIB_PATH
+    extra = os.environ.get("MRAG_EXTRA_HIPCC_FLAGS", "").split()
     build_dir = os.path.join(_HERE, "build")
     os.makedirs(build_dir, exist_ok=True)
+    import hashlib
+    hdr = hashlib.sha256()
+    for f in sorted(f for f in os.listdir(_CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mrag_hip.h")]:
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            hdr.update(fh.read())
     procs = []
     for src in SOURCES:
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + EXTRA_FLAGS.get(src, []) + [
-            "-c", os.path.join(_CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + EXTRA_FLAGS.get(src, []) + extra + (
+            [f'-DMRAG_SOURCE_HASH="{want}"'] if src == "api.hip" else []) + ["-c", os.path.join(_CSRC, src), "-o", obj]
+        objs.append(obj)
+        # incremental: an object is reused when its source, the shared headers and its command line are what they were when it was compiled
+        with open(os.path.join(_CSRC, src), "rb") as fh:
+            key = hashlib.sha256(fh.read() + hdr.digest() + " ".join(cmd).encode()).hexdigest()
+        tag = obj + ".key"
+        if os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == key:
+            continue
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, pr in procs:
+        if os.path.exists(tag):
+            os.remove(tag)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), tag, key))
+    failed = []
+    for src, pr, tag, key in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+            failed.append(f"hipcc failed on {src}:\n{out.decode()}")
+        else:
+            with open(tag, "w") as fh:
+                fh.write(key)
+    if failed:
+        raise RuntimeError("\n".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:
@@ -196,6 +247,17 @@ def lib() -> ctypes.CDLL:
     L.mrag_target_arch.restype = c_char_p
     if L.mrag_abi_version() != ABI_VERSION:
         raise HipLibraryMissing(f"{LIB_PATH} has ABI {L.mrag_abi_version()}, expected {ABI_VERSION}: rebuild")
+    L.mrag_source_hash.restype = c_char_p
+    have, want = L.mrag_source_hash().decode(), source_hash()
+    if have != want and not os.environ.get("MRAG_HIP_LIB_ANY_SOURCE"):      # the explicit override is for tools/ A/B runs of archived variant libraries
+        raise HipLibraryMissing(f"{LIB_PATH} was built from other sources (stamp {have}, sources beside it {want}): rebuild with "
+                                "`python -m motionrag_amd._lib` -- a stale or variant binary is never loaded silently")
+    L.mrag_dispatch_name.restype = c_char_p
+    L.mrag_dispatch_name.argtypes = [c_int32]
+    L.mrag_dispatch_counts.argtypes = [c_void_p, c_int32]
+    L.mrag_probe_mfma_flops.argtypes = [c_int32]
+    L.mrag_probe_mfma_flops.restype = c_int64
+    L.mrag_probe_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int32]
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
     L.mrag_gemm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]

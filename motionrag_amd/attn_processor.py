@@ -291,10 +291,14 @@ class APAdapterAttnProcessor2_0(nn.Module):
             ipkv = ops.linear(ip, wip)
             ops.attention(ip_q.view(B, L, H, 64), ipkv[..., :C].unflatten(-1, (H, 64)), ipkv[..., C:].unflatten(-1, (H, 64)),
                           out=o, resid=o, kv_batch_div=r, out_scale=float(self.scale[0]))
+        rescale = float(attn.rescale_output_factor)
         if block_residual is not None:
             if attn.residual_connection or input_ndim == 4:
                 raise NotImplementedError("block_residual with residual_connection / 4-D input")
-            out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=block_residual)
+            # the reference divides the PROCESSOR's output (:139) and the caller adds its x afterwards: x + out / f.  The division rides in the
+            # epilogue's acc_scale -- resid + (1 / f) (o W^T + b) -- and must not touch the block's residual
+            out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=block_residual, acc_scale=1.0 / rescale)
+            rescale = 1.0
         elif attn.residual_connection and input_ndim != 4:
             out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, epilogue=ops.EPI_RESID, resid=residual.contiguous())
         else:
@@ -303,7 +307,7 @@ class APAdapterAttnProcessor2_0(nn.Module):
             out = out.transpose(-1, -2).reshape(b, c, hh, ww)
             if attn.residual_connection:
                 out = ops.add(out.contiguous(), residual.contiguous())
-        if attn.rescale_output_factor != 1.0:                                      # :139 (1.0 on every SVD attn2 site: one extra pass otherwise)
-            out = out.contiguous()
-            out = ops.axpby(out, out, 1.0 / float(attn.rescale_output_factor), 0.0)
+        if rescale != 1.0:                                                         # :139 (1.0 on every SVD attn2 site: one extra pass otherwise); with
+            out = out.contiguous()                                                 # attn.residual_connection the reference divides (out + residual) too
+            out = ops.axpby(out, out, 1.0 / rescale, 0.0)
         return out

@@ -518,6 +518,7 @@ static int launch16_plain(hipStream_t s, AttnP p) {
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH((attn16_kernel<QB, NW, NS, false>), dim3(p.n_qtiles * p.B * p.H), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN16);
   return MRAG_OK;
 }
 
@@ -535,6 +536,7 @@ static int launch16_split(hipStream_t s, AttnP p, const SplitPlan* pl, void* wor
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH((attn16_kernel<QB, NW, NS, true>), dim3(p.n_main + nbh * pl->splits), dim3(NW * 64), lds, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN16_KSPLIT);
   return mrag_launch_attn_combine(s, p);
 }
 

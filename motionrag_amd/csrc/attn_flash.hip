@@ -662,6 +662,7 @@ int launch_attn(hipStream_t s, AttnP p) {
   if (p.mask || p.bias) MRAG_LAUNCH((attn_fwd_kernel<NW, true, SHORTKV>), grid, block, lds, s, p);
   else MRAG_LAUNCH((attn_fwd_kernel<NW, false, SHORTKV>), grid, block, lds, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_FLASH);
   return MRAG_OK;
 }
 
@@ -737,8 +738,10 @@ int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspa
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH((attn_fwd_kernel<8, false, false, true>), dim3(p.n_main + nbh * pl.splits), dim3(512), lds, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_FLASH_KSPLIT);
   MRAG_LAUNCH(attn_combine_kernel, dim3((unsigned)(((long long)nbh * pl.rem_rows + 15) / 16)), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_COMBINE);
   return MRAG_OK;
 }
 
@@ -747,6 +750,7 @@ int launch_attn_split(hipStream_t s, AttnP p, const SplitPlan& pl, void* workspa
 int mrag_launch_attn_combine(hipStream_t s, const AttnP& p) {
   MRAG_LAUNCH(attn_combine_kernel, dim3((unsigned)(((long long)p.B * p.H * p.rem_rows + 15) / 16)), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_COMBINE);
   return MRAG_OK;
 }
 
@@ -937,6 +941,7 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + HG - 1) / HG), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_IP_ATTN_FOLDED);
   return MRAG_OK;
 }
 
@@ -971,6 +976,7 @@ extern "C" int mrag_attn_fwd_bf16(void* stream, const mrag_attn_args* a) {
     if (blocks > 256 * 16) blocks = 256 * 16;
     MRAG_LAUNCH(attn_tiny_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_ATTN_TINY);
     return MRAG_OK;
   }
   if (a->Sq > 128 && a->Skv <= KVB) return launch_attn<8, true>(s, p);

@@ -350,5 +350,6 @@ extern "C" int mrag_attn_fwd_fp8(void* stream, const mrag_attn_args* a) {
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH(attn8_kernel, dim3(p.n_qtiles * (unsigned)bh), dim3(512), lds, s, fp);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_FP8);
   return MRAG_OK;
 }

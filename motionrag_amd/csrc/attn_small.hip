@@ -120,6 +120,7 @@ int launch_small(hipStream_t s, const SmallP& p) {
   if (e != hipSuccess) return (int)e;
   MRAG_LAUNCH(kfn, dim3((unsigned)(p.B * p.H)), dim3(256), lds, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_ATTN_SMALL);
   return MRAG_OK;
 }
 

@@ -124,6 +124,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return base + (id >> 3);
 }
 
+// diagnostic launch counters (include/mrag_hip.h: enum mrag_kernel_id, mrag_dispatch_counts); the table lives in api.hip
+extern unsigned long long mrag_dispatch_table[];
+#define MRAG_COUNT(id) ((void)__atomic_fetch_add(&mrag_dispatch_table[(id)], 1ull, __ATOMIC_RELAXED))
+
 #define MRAG_LAUNCH_CHECK()                         \
   do {                                              \
     hipError_t e__ = hipGetLastError();             \

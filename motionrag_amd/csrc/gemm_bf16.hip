@@ -1350,6 +1350,7 @@ inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
   }
 #undef MRAG_W4_CASE
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(epi == MRAG_EPI_QKNORM_ROPE ? MRAG_K_GEMM_W4_QKNORM_ROPE : (epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) ? MRAG_K_GEMM_W4_GEGLU : MRAG_K_GEMM_W4);
   return MRAG_OK;
 }
 
@@ -1400,6 +1401,13 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
   }
 #undef MRAG_GEMM_CASE
   MRAG_LAUNCH_CHECK();
+  {
+    constexpr int tile = (BM == 256 && BN == 320) ? 1 : (BM == 256 && BN == 128) ? 2 : (BM == 128 && BN == 128) ? 3 : 0;   // 0: 256x256 (8 or 16 waves)
+    constexpr int ids[3][4] = {{MRAG_K_GEMM_256x256, MRAG_K_GEMM_256x320, MRAG_K_GEMM_256x128, MRAG_K_GEMM_128x128},
+                               {MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128},
+                               {MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_256x256, MRAG_K_CONVT_128x128}};
+    MRAG_COUNT(ids[CONV][tile]);
+  }
   if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
     if (sk) {   // the partial last round.  Its own launch: the main kernel keeps its register allocation, and whole rounds end together anyway
       const dim3 tgrid(2 * sk->units);
@@ -1421,6 +1429,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
       }
 #undef MRAG_GEMM_SK_CASE
       MRAG_LAUNCH_CHECK();
+      MRAG_COUNT(MRAG_K_GEMM_STREAMK_TAIL);
     }
   }
   return MRAG_OK;

@@ -199,6 +199,7 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   else if (a->D <= 4096) MRAG_LAUNCH(layernorm_kernel<8>, grid, block, 0, s, p);
   else MRAG_LAUNCH(layernorm_kernel<16>, grid, block, 0, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_LAYERNORM);
   return MRAG_OK;
 }
 
@@ -218,5 +219,6 @@ extern "C" int mrag_qknorm_rope_bf16(void* stream, const mrag_qknorm_rope_args* 
   if (blocks > 256 * 32) blocks = 256 * 32;
   MRAG_LAUNCH(qknorm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_QKNORM_ROPE);
   return MRAG_OK;
 }

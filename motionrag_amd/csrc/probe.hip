@@ -1,0 +1,51 @@
+// probe.hip -- measurement probes of libmrag_hip.so (NOT on the product path): what this part sustains, so that bench.py can print the
+// ceilings beside the roofline fractions it reports (SURVEY.md section 8d asks for measured ceilings next to the nominal peaks).
+//
+//   mrag_probe_mfma_bf16: a register-resident loop of v_mfma_f32_16x16x32_bf16 on caller-provided (random) operand bits -- no LDS, no memory traffic
+//   inside the loop, 8 waves per CU (2 per SIMD), 32 independent accumulator tiles per wave so the matrix pipe never waits for a result.  This is
+//   the upper bound of ANY bf16 kernel on the box in its current power state: the nominal 2.5 PFLOP/s assumes the 2.4 GHz peak clock, which the
+//   part does not hold under a dense matrix load on random data (profiles/r2_mfma_shape_power.txt).
+#include "common.h"
+#include "../../include/mrag_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(512) void probe_mfma_kernel(const bf16x8* __restrict__ operands, long long n_frag, float* __restrict__ out, int iters) {
+  bf16x8 a[8], b[4];
+  const long long t = (long long)blockIdx.x * 512 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = operands[(t * 12 + i) % n_frag];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = operands[(t * 12 + 8 + j) % n_frag];
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[t] = s;
+}
+
+}  // namespace
+
+extern "C" int64_t mrag_probe_mfma_flops(int32_t iters) {
+  // 256 workgroups x 8 waves x iters x 32 MFMAs x (2 * 16 * 16 * 32) FLOP
+  return iters <= 0 ? 0 : 256LL * 8 * (int64_t)iters * 32 * 16384;
+}
+
+extern "C" int mrag_probe_mfma_bf16(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters) {
+  if (!operands || !out || operand_bytes < 16 || iters <= 0 || ((uintptr_t)operands & 15)) return MRAG_EINVAL;
+  MRAG_LAUNCH(probe_mfma_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, (const bf16x8*)operands, (long long)(operand_bytes / 16), out, iters);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}

@@ -430,6 +430,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
     if (e != hipSuccess) return (int)e;                                                                           \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                                     \
     MRAG_LAUNCH_CHECK();                                                                                          \
+    MRAG_COUNT(MRAG_K_TOPK_SCAN_FUSED_MERGE);                                                                     \
     return MRAG_OK;                                                                                               \
   }
   MRAG_TOPK_FUSED(0, 1, 1) MRAG_TOPK_FUSED(0, 1, 4) MRAG_TOPK_FUSED(0, 4, 1) MRAG_TOPK_FUSED(0, 4, 2)
@@ -446,7 +447,9 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   MRAG_TOPK_CASE(1, 1, 1) MRAG_TOPK_CASE(1, 1, 4) MRAG_TOPK_CASE(1, 4, 1) MRAG_TOPK_CASE(1, 4, 2) MRAG_TOPK_CASE(1, 16, 1) MRAG_TOPK_CASE(1, 16, 2)
 #undef MRAG_TOPK_CASE
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_TOPK_SCAN);
   MRAG_LAUNCH(topk_merge_kernel, dim3(n_queries), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_TOPK_MERGE);
   return MRAG_OK;
 }

@@ -309,10 +309,12 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   hipStream_t s = (hipStream_t)stream;
   MRAG_LAUNCH(gn_stats_kernel, dim3(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048)), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_GN_STATS);
   if (a->C / a->G > 256) return MRAG_ENOTSUP;
   float* ab = p.part + a->N * a->chunks * a->C * 2;
   MRAG_LAUNCH(gn_fold_kernel, dim3((unsigned)a->G, (unsigned)a->N), dim3(256), 0, s, p, ab);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_GN_FOLD);
   const size_t lds = (size_t)a->C * 2 * sizeof(float);
   if (a->mod) {
     p.mod = (const bf16_t*)a->mod; p.mT = a->mod_T; p.mH = a->mod_H; p.mW = a->mod_W; p.mTz = a->mod_Tz; p.mshift = a->mod_shift; p.msplit = a->mod_split;
@@ -323,6 +325,7 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
     if (bxm > capm) bxm = capm;
     MRAG_LAUNCH(gn_apply_mod_kernel, dim3((unsigned)bxm, (unsigned)a->N), dim3(256), lds, s, p, (const float*)ab);
     MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_GN_APPLY_MOD);
     return MRAG_OK;
   }
   long long bx = (a->HW * (a->C / 8) + 1023) / 1024;          // >= 4 vectors per thread
@@ -331,6 +334,7 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   if (bx < 1) bx = 1;
   MRAG_LAUNCH(gn_apply_kernel, dim3((unsigned)bx, (unsigned)a->N), dim3(256), lds, s, p, (const float*)ab);
   MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_GN_APPLY);
   return MRAG_OK;
 }
 

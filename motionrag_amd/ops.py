@@ -29,6 +29,30 @@ class HipOnly(RuntimeError):
     """Raised when an op is handed a tensor that is not on the GPU (no CPU fallback exists)."""
 
 
+def dispatch_counts() -> dict:
+    """the library's diagnostic launch counters by kernel name (include/mrag_hip.h: enum mrag_kernel_id) -- which kernel each call dispatched to"""
+    L = _lib.lib()
+    n = L.mrag_dispatch_counts(None, 0)
+    buf = (ctypes.c_uint64 * n)()
+    L.mrag_dispatch_counts(buf, n)
+    return {L.mrag_dispatch_name(i).decode(): int(buf[i]) for i in range(n)}
+
+
+class dispatched:
+    """`with ops.dispatched() as d: module(x)` -> d.counts = {kernel name: launches inside the block} (non-zero entries only).  Tests use it to
+    assert that a full-width shape ran on the production kernel and not on a fallback tile."""
+
+    def __enter__(self):
+        self._before = dispatch_counts()
+        self.counts = {}
+        return self
+
+    def __exit__(self, *exc):
+        after = dispatch_counts()
+        self.counts = {k: after[k] - self._before[k] for k in after if after[k] != self._before[k]}
+        return False
+
+
 def _dev(t: torch.Tensor, dtype=torch.bfloat16, name="tensor") -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise HipOnly(f"{name}: motionrag_amd ops run only on a ROCm GPU (got {getattr(t, 'device', type(t))})")

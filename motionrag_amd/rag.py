@@ -272,11 +272,24 @@ class RAGDatabase:
                     plan.exclude.fill_(-1)
                 rows, dist = plan.run()
                 rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+            self._note_short(rows, top_k, post, exclude is not None)
             return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
         else:
             rows, dist = ops.topk(self.vectors, q, top_k, metric=self.metric, group=group, exclude=exclude, postfilter=post)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+        self._note_short(rows, top_k, post, exclude is not None)
         return [self._format(rows[i], dist[i], select, output_format) for i in range(Q)]
+
+    def _note_short(self, rows: np.ndarray, top_k: int, post: bool, filtered: bool) -> None:
+        """ONE warning per database when the post-filter order hands back fewer than `top_k` rows: a deployment whose LanceDB pre-filters would have
+        got `top_k` there (`RAGDatabase(prefilter=True)` is that order)."""
+        if post and filtered and top_k <= len(self) and not getattr(self, "_short_noted", False) and (rows < 0).any():
+            import warnings
+            self._short_noted = True
+            short = int((rows < 0).any(axis=1).sum())
+            warnings.warn(f"RAGDatabase: {short} of {rows.shape[0]} filtered searches returned fewer than top_k={top_k} rows -- the `where` filter is applied AFTER the "
+                          "k nearest rows were taken (lancedb 0.14.0's `where(..., prefilter=False)`, src/data/rag.py:57-58); the consumer pads the missing "
+                          "references with zero clips.  RAGDatabase(prefilter=True) filters before the selection.  (reported once per database)")
 
     def vector_search(self, vector, vector_column_name: str = None, top_k: int = 10, table=None, where: str = None,
                       select: List[str] = None, nprobes: int = 50, refine_factor: int = 30, output_format: str = "dict",

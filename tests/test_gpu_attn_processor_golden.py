@@ -90,6 +90,11 @@ def test_svd_hip_processor_against_the_reference_class(hip, golden_dir):
     proc.scale = [1.0]
     attn.rescale_output_factor = 2.0
     close(attn(hidden, (img, act)), g["out.rescale2"])
+    # `block_residual` (the caller's x of `x = attn2(norm2(x)) + x`, added in the output projection's epilogue): the reference divides only the processor's
+    # output (:139) and the caller adds x afterwards -> x + out / f, NOT (x + out) / f
+    xres = dev(g["hidden4"].reshape(2 * F, C, 36).transpose(0, 2, 1).copy())           # any [2F, 36, C] tensor
+    want = torch.from_numpy(g["out.rescale2"]) + xres.float().cpu()
+    close(attn(hidden, (img, act), block_residual=xres), want)
 
 
 class _CT:

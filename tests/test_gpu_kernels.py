@@ -437,6 +437,21 @@ def test_attention16_optimistic_sweep_ranges(hip):
     qs[:, 499, 0, 63] = -95.0                                 # a row of the ragged last query tile (the key-split units when a workspace is given)
     got = ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV))
     close(got, want, scale=0.3)
+    # AT the boundary of the range check.  A row's sum is l = sum_j exp(s_j + c) ~ 1344 e^0.5 e^c = 2^(11.1 + 1.4427 c): it crosses 2^100 at c = +61.6 nats
+    # and 2^-100 at c = -77.0 nats.  Shifts on either side of both crossings (bf16-exact values) make SOME rows of a workgroup fail the check and others
+    # pass it -- rows differ in their sums by a few bits -- so fast and checked workgroups mix inside one launch; just inside the lower bound the smallest
+    # P terms of a row flush below 2^-126 (a relative loss of about 2^-12, far below the bf16 output rounding).  +-69 / +-70 nats (2^+-100 as a LOGIT,
+    # the advisor's figure) ride along.
+    for shift in (60.0, 61.0, 61.5, 62.0, 63.0, 69.0, 70.0, -69.0, -70.0, -76.0, -76.5, -77.0, -77.5, -78.0):
+        qs = q.clone()
+        qs[..., 63] = shift
+        got = ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV))
+        close(got, want, scale=0.3)
+        close(got, base.float().cpu(), scale=0.3, rtol=2e-2, atol_frac=3e-2)
+    # a per-row ramp across the upper crossing: row r shifted by 59 + r / 64 nats (59 .. 66.8), every workgroup holds rows on both sides
+    qs = q.clone()
+    qs[..., 63] = bf(59.0 + torch.arange(Sq).float() / 64.0)[None, :, None]
+    close(ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV)), want, scale=0.3)
 
 
 def test_attention_large_sequence_properties(hip):
@@ -489,6 +504,23 @@ def test_attention_key_split_tail(hip):
         assert torch.equal(outs[""][:, :Sq - tail], outs["0"][:, :Sq - tail])              # full tiles: same code path, bit-identical
         assert not torch.equal(outs[""][:, Sq - tail:], outs["0"][:, Sq - tail:])          # the tail really took the key-split path
         close(outs[""][:, Sq - tail:], outs["0"][:, Sq - tail:].float().cpu(), scale=0.05, rtol=2e-2, atol_frac=4e-2)
+    # key-split partials of MIXED kinds in one merge: the tail rows' shift feature (q[63] = c) meets k[63] = 8 only on the first 576 keys -- exactly the
+    # first key chunk of this shape's plan (66 key tiles over 8 chunks = 9 tiles) -- so that chunk's logits move by c nats and the other chunks' do not.
+    # c = +110: the first chunk overflows the fast sweep and re-runs in the checked form (m ~ +158 in log2 units), the others stay fast (m = 0), and the
+    # merge must weigh them e^110 apart; c = -110: every P of the first chunk underflows (checked re-run, m ~ -158) and the chunk must vanish from the
+    # merge.  fp32 reference on the same bf16 inputs.
+    for c in (110.0, -110.0):
+        q2, k2 = q.clone(), k.clone()
+        q2[..., 63] = 0.0
+        k2[..., 63] = 0.0
+        k2[:, :576, :, 63] = 8.0
+        q2[:, Sq - TAIL:, :, 63] = c
+        tail_rows = torch.arange(Sq - TAIL, Sq)
+        want2 = sdpa_ref(q2[:, tail_rows], k2, v)
+        with ops.dispatched() as d:
+            got2 = ops.attention(q2.to(DEV), k2.to(DEV), vd)
+        assert d.counts.get("ATTN16_KSPLIT", 0) == 1 and d.counts.get("ATTN_COMBINE", 0) == 1, d.counts
+        close(got2[:, tail_rows.to(DEV)], want2, scale=0.05, rtol=3e-2, atol_frac=5e-2)
     # C ABI: the workspace is optional (none / too small -> the unsplit launch, same result as without the split) and must be 16-byte aligned
     import ctypes
     need = _lib.lib().mrag_attn_workspace_bytes(B, H, Sq, Skv)

@@ -14,6 +14,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def close_chained_cfg(got, want, rel_l2=4e-2, p999_frac=0.2, max_frac=0.5):
+    """Two chained CFG steps of a bf16 UNet against the fp32 oracle.  Guidance multiplies the two branches' independent bf16 errors, so single
+    elements scatter widely while the aggregate error stays put; an absolute slack wide enough for the worst element on EVERY element would hide
+    real regressions.  Three instruments instead: relative Frobenius error <= 4 % (measured 3.0 %); the 99.9th percentile of the element error
+    beyond 5 % of the element, in units of the mean magnitude, <= 0.2 (the level no element but one outlier of 4 096 has reached); a loose
+    bound of 0.5 on the maximum (catches a wrong element, not rounding)."""
+    g, w = got.float().cpu(), want.float().cpu()
+    assert g.shape == w.shape and torch.isfinite(g).all()
+    l2 = ((g - w).norm() / w.norm()).item()
+    assert l2 <= rel_l2, f"relative L2 error {l2:.4f} > {rel_l2}"
+    s = w.abs().mean().item()
+    e = (((g - w).abs() - 5e-2 * w.abs()).clamp_min(0) / s).flatten()
+    p999 = torch.quantile(e, 0.999).item()
+    assert p999 <= p999_frac, f"99.9th percentile of the element error {p999:.3f} of the mean magnitude > {p999_frac}"
+    assert e.max().item() <= max_frac, f"largest element error {e.max().item():.3f} of the mean magnitude > {max_frac}"
+
+
 class StubText:
     """T5 stand-in: deterministic [b, 10, 64] embeddings from the strings"""
 
@@ -228,10 +245,7 @@ def test_svd_ct_pipeline_matches_oracle_loop(hip):
         x = torch.cat([torch.cat([scaled, scaled]), il], dim=2)
         v = svd_ref.unet_forward(sdict, cfg, x, torch.tensor(0.25 * np.log(s)), emb2, ids, act)
         lat = svd_ref.euler_cfg_step(v[:b].double(), v[b:].double(), lat.double(), s, sn, gs.double()).float().to(torch.bfloat16).float()
-    # two chained CFG steps of a bf16 UNet against fp32: 4 % Frobenius (measured 3.0 %), elements within 5 % + 0.3 of the mean magnitude -- guidance
-    # multiplies the two branches' independent bf16 errors; with round 4's kernels ONE of 4 096 elements sits at 0.27 of the mean magnitude and
-    # no other above 0.2 (the bound was 0.25 before: a single outlier, the Frobenius error did not move)
-    close(got, lat, rel_l2=4e-2, atol_frac=0.3)
+    close_chained_cfg(got, lat)                              # Frobenius + 99.9th percentile + loose maximum (see the helper)
     vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, ref_videos=ref_videos, metadata=None, generator=torch.Generator().manual_seed(9), **kw)
     assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
     # the uint8 hop of svd/module.py:181 (tensor2PIL -> denormalize -> uint8) + pipeline.py:154-155 (pil_to_tensor / 127.5 - 1): eval_pipeline's clip is
@@ -532,7 +546,7 @@ def test_svd_baseline_pipeline_without_motion_injection(hip):
         x = torch.cat([torch.cat([scaled, scaled]), il], dim=2)
         v = svd_ref.unet_forward(sdict, cfg, x, torch.tensor(0.25 * np.log(s)), emb2, ids, None)
         lat = svd_ref.euler_cfg_step(v[:b].double(), v[b:].double(), lat.double(), s, sn, gs.double()).float().to(torch.bfloat16).float()
-    close(got, lat, rel_l2=4e-2, atol_frac=0.35)          # as the CT test, two chained bf16 CFG steps; one element of 4 096 reaches 0.32 of the mean magnitude with these weights
+    close_chained_cfg(got, lat)                              # as the CT test: two chained bf16 CFG steps
     vid = svd.eval_pipeline(pipe, img255 / 127.5 - 1.0, generator=torch.Generator().manual_seed(9), **kw)
     assert vid.shape == (b, Fr, 3, 8 * h, 8 * w) and -1.0 <= vid.min().item() and vid.max().item() <= 1.0
     u8 = (torch.clip((img255 / 127.5 - 1.0 + 1.0) / 2.0, 0.0, 1.0) * 255).to(torch.uint8)   # the reference's tensor2PIL quantisation (utils/pipeline.py:178-184)

@@ -833,8 +833,15 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(const AttnP p) {
 // hidden += scale * softmax(scores / 8) . V_ip with scores = hidden . M^T already produced by the GEMM, M = K_ip . W_q_ip per head
 // (see include/mrag_hip.h: mrag_ip_attn_folded_bf16).  One wavefront owns 16 rows x one head at a time: the 32 (25 valid) scores of a
 // (row, head) are 64 contiguous bytes = the 16x16x32 B-operand layout (row = lane & 15, 8 keys per lane >> 4) straight from global
-// memory, the softmax is 8 registers x 4 lane groups, V^T of the block's 16 heads sits transposed in LDS as the A operand, and
-// O^T = V^T . P^T leaves every lane with 4 consecutive features of one row -> 8-byte read-modify-write of `hidden`.
+// memory, the softmax is 8 registers x 4 lane groups, V^T of the block's heads sits transposed in LDS as the A operand, and
+// O^T = V^T . P^T.  HBM-bound (546 MB per launch at the DiT shape: 109 MB of scores, 218 MB of `hidden` in and out), so the layout is chosen for the
+// MEMORY side (round 5): the four MFMAs of a head take V^T rows in the PERMUTED feature order
+//     d(m, t) = 8 (m >> 2) + 4 (t & 1) + (m & 3) + 32 (t >> 1)          m = A row of MFMA t
+// so that lane (row, kq) ends up with features 8 kq .. 8 kq + 7 (MFMAs 0, 1) and 32 + 8 kq .. 32 + 8 kq + 7 (MFMAs 2, 3): `hidden` is read and written
+// as TWO 16-byte accesses per lane, each instruction covering 64 contiguous bytes per row, instead of the four 8-byte accesses (32 contiguous bytes per
+// row and instruction) the natural order d = 16 t + m gives -- half the vector-memory instructions and twice the bytes per cache-line request.  The V^T
+// image is XOR-swizzled by (d >> 3) & 3 on its 16-byte key chunks: the permuted rows of one MFMA then hit 16 distinct bank groups (the plain
+// image is 4-way conflicted for either order).
 struct IpFoldP {
   const bf16_t* scores; const bf16_t* v; bf16_t* o;
   long long rows, s_ld, o_ld, v_bs, v_ks, rows_per_batch;
@@ -848,7 +855,7 @@ struct IpFoldP {
 __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
   constexpr int HG = MRAG_IPFOLD_HG;                       // heads per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* vt = (bf16_t*)smem;                               // [HG][64 d][32 keys]
+  bf16_t* vt = (bf16_t*)smem;                               // [HG][64 d][4 swizzled chunks of 8 keys]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
   const int h0 = blockIdx.y * HG, kb = blockIdx.z;          // blockIdx.z = K/V batch (one V^T image per block)
@@ -859,9 +866,14 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
     const int c8 = i & 7, hl = (i >> 3) % nh, key = (i >> 3) / nh;
     const u32x4 raw = *(const u32x4*)(p.v + (long long)kb * p.v_bs + (long long)key * p.v_ks + (h0 + hl) * 64 + c8 * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vt[(hl * 64 + c8 * 8 + e) * 32 + key] = (bf16_t)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu));
+    for (int e = 0; e < 8; ++e) {
+      const int d = c8 * 8 + e;                                  // (d >> 3) & 3 == c8 & 3
+      vt[(hl * 64 + d) * 32 + ((((key >> 3) ^ (c8 & 3)) << 3) | (key & 7))] = (bf16_t)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu));
+    }
   }
   __syncthreads();
+  // A-operand addresses of the four MFMAs: V^T row d(r16, t), key chunk kq (swizzled by (d >> 3) & 3 = r16 >> 2)
+  const int dbase = 8 * (r16 >> 2) + (r16 & 3), kchunk = (kq ^ (r16 >> 2)) << 3;
   // this K/V batch covers q batches [kb * kv_div, (kb + 1) * kv_div): rows [row_lo, row_hi)
   const long long row_lo = (long long)kb * p.kv_div * p.rows_per_batch, row_hi = row_lo + (long long)p.kv_div * p.rows_per_batch;
   for (long long g0 = row_lo + ((long long)blockIdx.x * 4 + wave) * 16; g0 < row_hi; g0 += (long long)gridDim.x * 64) {
@@ -869,20 +881,18 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
     const long long rc = row < row_hi ? row : row_hi - 1;
     // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
     u32x4 raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + h0 * 32 + kq * 8);
-    u32x2 old_n[4];
+    u32x4 old_n[2];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) old_n[dt] = *(const u32x2*)(p.o + rc * p.o_ld + h0 * 64 + 16 * dt + 4 * kq);
+    for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(p.o + rc * p.o_ld + h0 * 64 + 32 * hf + 8 * kq);
     for (int hl = 0; hl < nh; ++hl) {
       const int h = h0 + hl;
       const u32x4 raw = raw_n;
       bf16_t* op = p.o + rc * p.o_ld + h * 64;
-      u32x2 old[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) old[dt] = old_n[dt];
+      const u32x4 old[2] = {old_n[0], old_n[1]};
       if (hl + 1 < nh) {
         raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + (h + 1) * 32 + kq * 8);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) old_n[dt] = *(const u32x2*)(op + 64 + 16 * dt + 4 * kq);
+        for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(op + 64 + 32 * hf + 8 * kq);
       }
       float sv[8], m = -INFINITY;
 #pragma unroll
@@ -905,18 +915,20 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
       const u32x4 pw = {pack_bf2(sv[0], sv[1]), pack_bf2(sv[2], sv[3]), pack_bf2(sv[4], sv[5]), pack_bf2(sv[6], sv[7])};
       const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
       const float inv = p.out_scale / l;
+      const bf16_t* vh = vt + hl * 64 * 32 + kchunk;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 va = *(const bf16x8*)(vt + ((hl * 64 + dt * 16 + r16) * 32 + kq * 8));
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 16 dt + 4 kq + i]
-        if (row < row_hi) {
-          const u32x2 od = old[dt];
-          u32x2 nw;
-          nw[0] = pack_bf2(__uint_as_float(od[0] << 16) + acc[0] * inv, __uint_as_float(od[0] & 0xffff0000u) + acc[1] * inv);
-          nw[1] = pack_bf2(__uint_as_float(od[1] << 16) + acc[2] * inv, __uint_as_float(od[1] & 0xffff0000u) + acc[3] * inv);
-          *(u32x2*)(op + 16 * dt + 4 * kq) = nw;
+      for (int hf = 0; hf < 2; ++hf) {                            // features 32 hf + 8 kq .. + 7 of this lane's row
+        u32x4 nw;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                             // MFMA t = 2 hf + q: features 32 hf + 8 kq + 4 q .. + 3
+          const bf16x8 va = *(const bf16x8*)(vh + (dbase + 4 * q + 32 * hf) * 32);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 32 hf + 8 kq + 4 q + i]
+          const unsigned o0 = old[hf][2 * q], o1 = old[hf][2 * q + 1];
+          nw[2 * q] = pack_bf2(__uint_as_float(o0 << 16) + acc[0] * inv, __uint_as_float(o0 & 0xffff0000u) + acc[1] * inv);
+          nw[2 * q + 1] = pack_bf2(__uint_as_float(o1 << 16) + acc[2] * inv, __uint_as_float(o1 & 0xffff0000u) + acc[3] * inv);
         }
+        if (row < row_hi) *(u32x4*)(op + 32 * hf + 8 * kq) = nw;
       }
     }
   }
@@ -926,8 +938,8 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
                                         int32_t kv_batch_div, int64_t scores_ld, int64_t hidden_ld, int64_t v_batch_stride, int64_t v_key_stride,
                                         float scale, float out_scale) {
   if (!scores || !v || !hidden || B <= 0 || S <= 0 || H <= 0 || keys <= 0 || keys > 32 || kv_batch_div <= 0 || B % kv_batch_div) return MRAG_EINVAL;
-  if (scores_ld % 8 || hidden_ld % 4 || scores_ld < (int64_t)H * 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;
-  if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 7) || ((uintptr_t)v & 15) || v_batch_stride % 8 || v_key_stride % 8) return MRAG_EINVAL;
+  if (scores_ld % 8 || hidden_ld % 8 || scores_ld < (int64_t)H * 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;
+  if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 15) || ((uintptr_t)v & 15) || v_batch_stride % 8 || v_key_stride % 8) return MRAG_EINVAL;
   IpFoldP p{};
   p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;
   p.rows = (long long)B * S; p.s_ld = scores_ld; p.o_ld = hidden_ld; p.v_bs = v_batch_stride; p.v_ks = v_key_stride; p.rows_per_batch = S;

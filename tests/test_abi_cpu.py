@@ -240,3 +240,25 @@ def test_add_to_db_recovers_from_an_interrupted_append(tmp_path):
     rag.add_to_db(rows[3:], 3 * np.ones((2, 8), np.float32), text_name="t", db_path=str(tmp_path))
     assert np.load(vp)[:, 0].tolist() == [1.0, 1.0, 1.0, 3.0, 3.0]
     assert rag._read_meta(str(tmp_path / "t")).column("id").to_pylist() == [0, 1, 2, 3, 4]
+
+
+def test_verify_unpinned_lists_the_unpinned_pieces_and_degrades_to_package_missing():
+    """tools/verify_unpinned.py is the one-command check of the oracle's unpinned restatements for a machine that HAS diffusers / lancedb / sentence-transformers /
+    kornia.  Here those packages are absent: `--list` names every unpinned piece with its reference call site, and a run reports
+    "package missing" per check with exit code 2 -- it never crashes and never silently passes."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "verify_unpinned.py")
+    lst = subprocess.run([sys.executable, tool, "--list"], capture_output=True, text=True, timeout=120)
+    assert lst.returncode == 0
+    for piece in ("CogVideoXTransformer3DModel", "CogVideoXDDIMScheduler", "CogVideoXDPMScheduler", "UNetSpatioTemporalConditionModel", "EulerDiscreteScheduler",
+                  "AutoencoderKLCogVideoX", "AutoencoderKLTemporalDecoder", "lancedb 0.14.0", "gte-base-en-v1.5", "kornia"):
+        assert piece in lst.stdout, piece
+    assert "src/projects/cogvideox/module.py:23-48" in lst.stdout and "src/data/rag.py:36-61" in lst.stdout
+    absent = [m for m in ("diffusers", "lancedb", "kornia") if importlib.util.find_spec(m) is None]
+    if absent:                                          # this image: every check that needs an absent package says so
+        run = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 2, run.stdout + run.stderr
+        assert run.stdout.count("package missing") >= 3 and "Traceback" not in run.stdout + run.stderr

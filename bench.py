@@ -442,7 +442,7 @@ def main():
             guarded("dynamicrafter1024_unet_16x576x1024_cfg_step", lambda: dc("bf16"))
             guarded("dynamicrafter1024_unet_16x576x1024_cfg_step_fp8_attention", lambda: dc("fp8"))        # BASELINE config #5, same weights / inputs
             holder.clear()
-            guarded("retrieval_top12_768d", lambda: mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1))))
+            guarded("retrieval_top12_768d", lambda: mb.topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 256))))   # Q = 256: the fan-out (fp32 MFMA) kernel
             guarded("dynamicrafter_kl_vae_decode_16x576x1024", mb.vae)                 # SURVEY 8f rank 2 (DynamiCrafter's per-frame KL-VAE)
             guarded("svd_temporal_vae_14x576x1024", mb.svd_vae)                         # SURVEY 8f rank 2 (SVD's temporal-decoder VAE; oracle unpinned)
             guarded("cogvideox_3d_causal_vae_49x480x720", mb.cogvideox_vae)             # SURVEY 8f rank 2 (the headline pipeline's VAE, tiled as the reference configures it; oracle unpinned)

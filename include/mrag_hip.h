@@ -75,7 +75,7 @@ enum mrag_kernel_id {
   MRAG_K_ATTN_SMALL,           /* mrag_attn_small_bf16                                                                      */
   MRAG_K_ATTN_FP8,             /* attn8_kernel                                                                              */
   MRAG_K_IP_ATTN_FOLDED,       /* ip_attn_folded_kernel                                                                     */
-  MRAG_K_LAYERNORM, MRAG_K_QKNORM_ROPE,
+  MRAG_K_LAYERNORM, MRAG_K_LAYERNORM_ROWS /* several narrow rows per wave (C = 320 / 640 / 1 280) */, MRAG_K_QKNORM_ROPE,
   MRAG_K_GN_STATS, MRAG_K_GN_FOLD, MRAG_K_GN_APPLY, MRAG_K_GN_APPLY_MOD,
   MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
   MRAG_K_COUNT
@@ -458,6 +458,21 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /* without the filter, excluded rows are then dropped and the survivors move   */
 /* up (fewer than k results possible: the tail is row -1, dist +inf);          */
 /* 0 = prefilter, excluded rows never enter the selection.                     */
+/* `order` selects the summation order of the distance (both are DEFINED and   */
+/* restated by oracle/topk_oracle.c, so rows AND distances are bit-exact):      */
+/*   1 = the 16-chain order above (mode 0 of the oracle);                       */
+/*   2 = the fan-out form for batches (src/data/datamodule.py:231-236 searches  */
+/*       per annotation; rag.attach_ref_videos batches 256): the scan as an     */
+/*       fp32 matrix product on v_mfma_f32_32x32x2_f32, the table streamed ONCE  */
+/*       per 256 queries.  dist = one fmaf chain per (query, row) over the       */
+/*       features in the order 8c, 8c+4, 8c+1, 8c+5, 8c+2, 8c+6, 8c+3, 8c+7;     */
+/*       "l2" through fmaf(-2, q.x, |q|^2 + |x|^2) with the squared norms as two */
+/*       half-block chains (mode 2 of the oracle).  n_queries >= 16, k <= 16,    */
+/*       else MRAG_ENOTSUP;                                                      */
+/*   0 = automatic: 2 where it applies (n_queries >= 16 and k <= 16), else 1 --  */
+/*       a batch of 16 or more and a single query may therefore differ in the    */
+/*       last bits of a distance (never in a rank whose gap exceeds the fp32     */
+/*       rounding of the sum: tests compare both with the float64 oracle).       */
 /* ------------------------------------------------------------------------ */
 /* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
  * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a
@@ -466,7 +481,7 @@ int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries);
 int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim,
                   const float* queries, const int32_t* exclude, int32_t n_queries,
                   int32_t k, int32_t metric,
-                  int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes, int32_t postfilter);
+                  int32_t* out_rows, float* out_dist, void* workspace, int64_t workspace_bytes, int32_t postfilter, int32_t order);
 
 /* ------------------------------------------------------------------------ */
 /* Spatio-temporal UNet denoisers (DynamiCrafter lvdm, SVD): channels-last   */

@@ -290,7 +290,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_topk_workspace_bytes.argtypes = [c_int64, c_int32]
     L.mrag_topk_workspace_bytes.restype = c_int64
     L.mrag_topk_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
-                                c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32]
+                                c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]
     L.mrag_groupnorm_workspace_bytes.argtypes = [c_int64, c_int64, c_int32]
     L.mrag_groupnorm_workspace_bytes.restype = c_int64
     L.mrag_groupnorm_bf16.argtypes = [c_void_p, POINTER(GroupNormArgs)]

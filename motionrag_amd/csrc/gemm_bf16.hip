@@ -814,6 +814,19 @@ inline bool wide_n_pays(long long N, int tuning = 0) {
   return w320 * 100 < w256 * 90;                   // at least 10 % fewer padded columns
 }
 
+// Round quantisation (round 5, tools/unet_op_table.py): one workgroup per CU means a launch costs ceil(tiles / 256) ROUNDS of one tile's time, however full the
+// last round is.  The UNets' level-2 problems (M = 16 128 rows, N = 1 280) are 63 x 5 = 315 tiles of 256x256 -- two rounds, the second 23 % full -- but
+// 63 x 4 = 252 tiles of 256x320: ONE round of tiles 1.25x as long, 1.6x less time (the 3x3 convolutions at K = 11 520 .. 23 040 and the K = 5 120 FF2 ran at
+// 0.30 of the MFMA peak there).  `rounds x tile width` prices a launch; the 320-wide tile is taken when it is at least 15 % cheaper (same bits: same K order).
+inline long long round_cost(long long M, long long N, int BN) {
+  const long long tiles = ((M + 255) / 256) * ((N + BN - 1) / BN);
+  return ((tiles + 255) / 256) * BN;
+}
+inline bool wide_rounds_pay(long long M, long long N, int tuning = 0) {
+  if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
+  return round_cost(M, N, 320) * 100 < round_cost(M, N, 256) * 85;
+}
+
 // the VAEs' finest levels are 128 channels wide: a 256-wide tile grid computes as many masked columns as real ones there
 inline bool narrow_n_pays(long long N) {
   const long long r = N % 256;
@@ -1487,6 +1500,10 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
+  // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
+  if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
+      a->epilogue != MRAG_EPI_QKNORM_ROPE)
+    return launch_cfg<2, 4, 8, 5>(s, p, epi);
   if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
        epi == EPI_GEGLU_TANH) &&
@@ -1548,7 +1565,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
       p.cv_tf = a->t_frames; p.cv_fs = (long long)a->H * a->Wd * a->Cin; p.K = 27LL * a->Cin; p.ldw = p.K;
     }
     const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
+    if (t256 >= 192 && (wide_n_pays(p.N) || wide_rounds_pay(p.M, p.N))) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
     if (t256 >= 192 && narrow_n_pays(p.N)) return launch_cfg<4, 2, 4, 4, 1>(s, p, a->epilogue);   // 256x128 tile, 8 waves of 64x64
     if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 1>(s, p, a->epilogue);
     return launch_cfg<2, 2, 4, 4, 1>(s, p, a->epilogue);
@@ -1557,7 +1574,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
   p.cv_T = a->H; p.cv_HW = a->Wd;
   p.M = (long long)a->N * a->H * a->Wd; p.K = 3LL * a->Cin; p.ldw = p.K;
   const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  if (t256 >= 192 && wide_n_pays(p.N)) return launch_cfg<2, 4, 8, 5, 2>(s, p, a->epilogue);
+  if (t256 >= 192 && (wide_n_pays(p.N) || wide_rounds_pay(p.M, p.N))) return launch_cfg<2, 4, 8, 5, 2>(s, p, a->epilogue);
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 2>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4, 2>(s, p, a->epilogue);
 }

@@ -103,6 +103,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   }
 }
 
+// Narrow rows (round 5): the UNets' LayerNorms are over C = 320 / 640 / 1 280 channels of 258 048 / 64 512 / 16 128 pixel rows.  One wave per row leaves 24 of
+// 64 lanes idle at C = 320 and retires a wave per 640 bytes (92 us = 3.6 TB/s at [258 048, 320]).  Here a row belongs to LPR = 8 / 16 / 32 lanes (CH = 5 sixteen-byte
+// chunks each, chunk index = sub-lane + LPR c: the LPR lanes of a row read 16 LPR contiguous bytes per instruction), so a wave normalises 8 / 4 / 2 rows with every
+// lane busy.  Plain LayerNorm only (gamma / beta; no AdaLN modulation, no output row remap, no RMS form: those stay on layernorm_kernel); the same two-pass
+// statistics in registers, summed over another lane partition -- results agree with layernorm_kernel to fp32 rounding of the statistics.
+template <int LPR, int CH>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnP p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rs = lane / LPR;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW + rs;
+  const long long row = row0 < p.rows ? row0 : p.rows - 1;           // rows past the end re-read the last row; their stores are masked
+  const bf16_t* x = p.x + row * p.ldx;
+  float v[CH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    unpack8(__builtin_nontemporal_load((const u32x4*)(x + (sub + LPR * c) * 8)), v[c]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[c][e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)p.D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)p.D + p.eps);
+  bf16_t* y = p.y + row * p.ldy;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int idx = (sub + LPR * c) * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+    if (p.gamma) {
+      float g[8]; unpack8(*(const u32x4*)(p.gamma + idx), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] *= g[e];
+    }
+    if (p.beta) {
+      float bb[8]; unpack8(*(const u32x4*)(p.beta + idx), bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += bb[e];
+    }
+    if (row0 < p.rows) __builtin_nontemporal_store(pack8(o), (u32x4*)(y + idx));
+  }
+}
+
 struct QkP {
   bf16_t* qkv; const bf16_t* qg; const bf16_t* qb; const bf16_t* kg; const bf16_t* kb;
   const float* cos; const float* sin;
@@ -191,6 +243,14 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   if (p.y_rpb < 0 || (p.y_rpb > 0 && p.y_bstride % 8 != 0)) return MRAG_EINVAL;
   const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (!a->shift0 && p.y_rpb == 0 && !a->rms && (a->D == 320 || a->D == 640 || a->D == 1280) && a->rows >= 1024) {   // narrow rows: several rows per wave
+    if (a->D == 320) MRAG_LAUNCH((layernorm_rows_kernel<8, 5>), dim3((unsigned)((a->rows + 31) / 32)), block, 0, s, p);
+    else if (a->D == 640) MRAG_LAUNCH((layernorm_rows_kernel<16, 5>), dim3((unsigned)((a->rows + 15) / 16)), block, 0, s, p);
+    else MRAG_LAUNCH((layernorm_rows_kernel<32, 5>), dim3((unsigned)((a->rows + 7) / 8)), block, 0, s, p);
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_LAYERNORM_ROWS);
+    return MRAG_OK;
+  }
   // the row lives in MAXC x 8 registers per lane: the tightest instantiation keeps the most waves in flight (D = 3072: 76 VGPRs and
   // 88-90 us at [35552, 3072] with MAXC = 6 against 100 VGPRs and 112-115 us with MAXC = 8 -- 4.9 TB/s, the device's copy rate)
   if (a->D <= 1024) MRAG_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, p);

@@ -90,6 +90,7 @@ struct TopkP {
 // contiguous bytes), a wavefront streams 4 rows per load instruction straight from HBM into registers (no LDS staging of the
 // database), 16 such row-quads make the 64-row batch whose candidates sit one per lane for the bitonic selection.
 // The queries (QT per workgroup pass) live in LDS and are read as 16-lane-contiguous ds_read_b128.
+template <int LIST = 64>
 __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh);
 
 template <int METRIC, int QT, int JC, bool FUSED = false, int NQD = 16>
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
     __syncthreads();
     if (!last) return;
     for (int qi = 0; qi < QT; ++qi)
-      if (q0 + qi < p.nq) merge_query(p, q0 + qi, (Cand*)smem);
+      if (q0 + qi < p.nq) merge_query<64>(p, q0 + qi, (Cand*)smem);
   }
 }
 
@@ -287,16 +288,18 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
 // whose minimum does not exceed it can contribute (about k of thousands).  Phase B merges just those.  The result is the
 // unique top-k under the total order (distance, row), whatever the merge order.
 // `sh` = 4 x 64 candidates + 1 of LDS scratch.
+// LIST = entries per partial list: 64 (the scan kernel's per-wave lists) or 16 (the fan-out kernel's per-workgroup lists; lanes >= 16 read +inf)
+template <int LIST>
 __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   Cand* thr_s = sh + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int nparts = p.slices * p.wpb;
-  const Cand* lists = p.ws + (long long)q * nparts * 64;
+  const Cand* lists = p.ws + (long long)q * nparts * LIST;
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
   Cand best = inf;
   for (int base = wave * 64; base < nparts; base += nw * 64) {
     const int part = base + lane;
-    Cand m = part < nparts ? lists[(long long)part * 64] : inf;
+    Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
     m = wave_sort(m, lane);
     best = wave_merge_top(best, m, lane);
   }
@@ -311,12 +314,12 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   Cand run = inf;
   for (int base = wave * 64; base < nparts; base += nw * 64) {
     const int part = base + lane;
-    const Cand m = part < nparts ? lists[(long long)part * 64] : inf;
+    const Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
     unsigned long long todo = __ballot(part < nparts && !cand_less(thr, m));   // min <= thr
     while (todo) {
       const int src = __builtin_ctzll(todo);
       todo &= todo - 1;
-      const Cand c = lists[(long long)(base + src) * 64 + lane];
+      const Cand c = lane < LIST ? lists[(long long)(base + src) * LIST + lane] : inf;
       run = wave_merge_top(run, c, lane);
     }
   }
@@ -349,10 +352,249 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   __syncthreads();
 }
 
+template <int LIST>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
   __shared__ Cand sh[257];
-  merge_query(p, blockIdx.x, sh);
+  merge_query<LIST>(p, blockIdx.x, sh);
 }
+
+
+// ---------------------------------------------------------------------------------------------- fan-out form: >= 16 queries per call
+// The caller that builds the retrieval tables searches in batches (src/data/datamodule.py:231-236 issues one query per annotation; attach_ref_videos
+// batches 256): the scan kernel above re-streams the database once per 16 queries and spends its time in fp32 vector FMAs (N = 10 k, Q = 256: 16 passes,
+// 246 us).  Here the batch is an fp32 MATRIX product on v_mfma_f32_32x32x2_f32 -- 64 FLOP per cycle and SIMD, the vector unit's peak rate with one VGPR per
+// operand and the VALU left free -- and the database is streamed ONCE per 256 queries.  The instruction's result is bit for bit a k-ordered fmaf chain
+// (MI355X guide, "FP32-input MFMA"), so the distances are DEFINED: one chain per (query, row) in the feature order 8c, 8c+4, 8c+1, 8c+5, ... (an MFMA takes
+// feature k from lanes 0-31 and k' from lanes 32-63; a lane's four MFMAs of a 32-byte block use the four floats of ONE ds_read_b128), squared norms as two
+// chains (oracle/topk_oracle.c mode 2 restates it; bit-exact tests).  L2 goes through |q|^2 + |x|^2 - 2 q.x.
+//   * workgroup = 4 waves; config A (large tables): 4 x 32 database rows x 32 TN queries per wave; config B (small tables, many queries): 32 rows x 4 x 32 TN
+//     queries -- the waves split the queries so that a 10 k-row table still fills the chip;
+//   * both operands ride the LDS: 32-feature slabs (128-byte rows, 16-byte chunks XOR-swizzled by row & 7 on the DMA's source side), two stages, LDS-DMA of
+//     slab i + 1 under the MFMAs of slab i; the stream runs across the row blocks of a workgroup;
+//   * accumulator layout: lane (n = lane & 31, h = lane >> 5) holds query n of a 32-query tile against rows (reg & 3) + 8 (reg >> 2) + 4 h: after a row block a
+//     lane tests its 16 rows against ITS query's current k-th distance (a register).  Survivors are rare once the lists are warm; they go, one per lane and
+//     round, through per-query slots to the query's OWNER thread, which inserts them into the workgroup's sorted top-16 list in LDS and republishes the
+//     threshold -- best candidates first, so the thresholds of a cold list converge in about k rounds;
+//   * per-workgroup lists [query][part][16] leave through the workspace and the merge kernel (LIST = 16) finishes, filter order included.
+__device__ __attribute__((aligned(128))) float g_topk_zero[32];    // source of feature chunks past `dim` (never written)
+
+struct TopkMP {
+  const float* db; const int* group; const float* q; const int* excl; const float* qq;
+  Cand* lists;
+  long long n_rows; int dim, nq, k, nparts, rows_per_part, nslab;
+};
+
+// |q|^2 of every query in the fan-out kernel's order: chains over features 8c + t and 8c + 4 + t, added once
+__global__ __launch_bounds__(256) void topk_qq_kernel(const float* q, float* qq, int nq, int dim) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  const float* x = q + (long long)i * dim;
+  float lo = 0.f, hi = 0.f;
+  for (int c = 0; 8 * c < dim; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = 8 * c + t, k1 = 8 * c + 4 + t;
+      if (k0 < dim) lo = __builtin_fmaf(x[k0], x[k0], lo);
+      if (k1 < dim) hi = __builtin_fmaf(x[k1], x[k1], hi);
+    }
+  qq[i] = lo + hi;
+}
+
+template <int METRIC, int WM, int TN>
+__global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
+  constexpr int WN = 4 / WM, RB = 32 * WM, QB = 32 * TN * WN;
+  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = (NPIECE + 3) / 4, LSTR = 17, NSLOT = 2 * WM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Cand* lists = (Cand*)(smem + 2 * STAGE);          // [QB][LSTR]: sorted ascending, entries >= k stay +inf
+  Cand* slots = lists + QB * LSTR;                  // [QB][NSLOT]: this round's candidate of each (wave, half) for the query
+  Cand* taus = slots + QB * NSLOT;                  // [QB]: the query's k-th best so far
+  float* xxs = (float*)(taus + QB);                 // [4][32]: |x|^2 of the wave's 32 rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = WM == 4 ? wave : 0, wn = WM == 4 ? 0 : wave;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * QB, part = blockIdx.x;
+  const long long row_begin = (long long)part * p.rows_per_part;
+  long long row_end = row_begin + p.rows_per_part;
+  if (row_end > p.n_rows) row_end = p.n_rows;
+  const int nblk = row_end > row_begin ? (int)((row_end - row_begin + RB - 1) / RB) : 0;
+  Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
+  for (int i = tid; i < QB * LSTR; i += 256) lists[i] = inf;
+  for (int i = tid; i < QB; i += 256) taus[i] = inf;
+
+  // per lane: the query of each of its TN tiles
+  float qqv[TN]; int exclv[TN]; bool qok[TN]; Cand tau[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int qi = q0 + (wn * TN + j) * 32 + r32;
+    qok[j] = qi < p.nq;
+    qqv[j] = (METRIC == 0 && qok[j]) ? p.qq[qi] : 0.f;
+    exclv[j] = (p.excl && p.group && qok[j]) ? p.excl[qi] : INT_MIN;
+    tau[j] = inf;
+  }
+
+  // ---- the LDS-DMA stream: item `it` = (row block, feature slab), stage it & 1
+  const int chunk = (lane & 7) ^ (lane >> 3);       // source chunk of this lane inside its 128-byte slab row (row & 7 == lane >> 3)
+  int d_blk = 0, d_s = 0;
+  auto issue = [&](const int stage) {
+    char* base = smem + stage * STAGE;
+    const int kk = d_s * 32 + chunk * 4;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < NPIECE) {
+        const float* src;
+        if (pc < RB / 8) {
+          long long row = row_begin + (long long)d_blk * RB + 8 * pc + (lane >> 3);
+          row = row < p.n_rows ? row : p.n_rows - 1;
+          src = p.db + row * p.dim;
+        } else {
+          int qi = q0 + 8 * (pc - RB / 8) + (lane >> 3);
+          qi = qi < p.nq ? qi : p.nq - 1;
+          src = p.q + (long long)qi * p.dim;
+        }
+        src = kk < p.dim ? src + kk : g_topk_zero + chunk * 4;
+        glds16(src, base + pc * 1024);
+      }
+    }
+    if (++d_s == p.nslab) { d_s = 0; ++d_blk; }
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  float xx = 0.f;
+  const int total = nblk * p.nslab;
+  __syncthreads();                                   // lists / thresholds initialised
+  if (total > 0) issue(0);
+  int s = 0, blk = 0;
+  for (int it = 0; it < total; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // slab `it` landed for every wave; every wave is done reading the other stage
+    if (it + 1 < total) issue((it + 1) & 1);
+    const char* st = smem + (it & 1) * STAGE;
+    const char* arow = st + (wm * 32 + r32) * 128;
+    const char* qrow = st + (RB + wn * TN * 32 + r32) * 128;
+    const int sw = r32 & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = ((2 * c + h) ^ sw) * 16;
+      const f32x4 a4 = *(const f32x4*)(arow + off);
+      if constexpr (METRIC == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xx = __builtin_fmaf(a4[t], a4[t], xx);
+      }
+      f32x4 b4[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b4[j] = *(const f32x4*)(qrow + j * 32 * 128 + off);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
+    }
+    if (++s < p.nslab) continue;
+    // ---- end of a row block: distances, then the selection rounds
+    s = 0;
+    const long long blk_row0 = row_begin + (long long)blk * RB + wm * 32;
+    ++blk;
+    if constexpr (METRIC == 0) {
+      const float xf = xx + __shfl_xor(xx, 32);      // the two half-row chains, added once (either lane: the same two addends)
+      if (h == 0) xxs[wave * 32 + r32] = xf;
+      xx = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const long long grow = blk_row0 + i;
+      const bool valid = grow < row_end;
+      const float xi = METRIC == 0 ? xxs[wave * 32 + i] : 0.f;
+      const int gi = p.group ? p.group[valid ? grow : row_end - 1] : INT_MIN + 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float dot = acc[j][reg];
+        const float d = METRIC == 0 ? __builtin_fmaf(-2.0f, dot, qqv[j] + xi) : 1.0f - dot;
+        acc[j][reg] = (valid && qok[j] && gi != exclv[j]) ? d : INFINITY;
+      }
+    }
+    for (;;) {
+      bool any = false;
+      int bsel[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float bd = INFINITY;
+        int br = 0;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (acc[j][reg] < bd) { bd = acc[j][reg]; br = reg; }      // strict: the lowest row among equal distances
+        Cand c;
+        c.d = bd;
+        c.r = bd < INFINITY ? (int)(blk_row0 + (br & 3) + 8 * (br >> 2) + 4 * h) : INT_MAX;
+        const bool pass = cand_less(c, tau[j]);
+        slots[((wn * TN + j) * 32 + r32) * NSLOT + wm * 2 + h] = pass ? c : inf;
+        bsel[j] = pass ? br : -1;
+        any |= pass;
+      }
+      if (!__syncthreads_or(any ? 1 : 0)) break;
+      if (tid < QB) {                                 // the owner of query tid: at most NSLOT insertions into its sorted list
+        Cand* L = lists + tid * LSTR;
+        for (int si = 0; si < NSLOT; ++si) {
+          const Cand c = slots[tid * NSLOT + si];
+          if (cand_less(c, L[p.k - 1])) {
+            int pos = p.k - 1;
+            while (pos > 0 && cand_less(c, L[pos - 1])) { L[pos] = L[pos - 1]; --pos; }
+            L[pos] = c;
+          }
+        }
+        taus[tid] = L[p.k - 1];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        tau[j] = taus[(wn * TN + j) * 32 + r32];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (reg == bsel[j]) acc[j][reg] = INFINITY;                 // consumed
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  }
+  __syncthreads();
+  if (tid < QB && q0 + tid < p.nq) {
+    Cand* out = p.lists + ((long long)(q0 + tid) * p.nparts + part) * 16;
+    const Cand* L = lists + tid * LSTR;
+    for (int e = 0; e < 16; ++e) out[e] = e < p.k ? L[e] : inf;
+  }
+}
+
+// the fan-out plan: which configuration, how many parts (workgroups along the table), rows per part
+struct MfmaPlan { bool wide_q; int TN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
+inline MfmaPlan plan_mfma(long long n_rows, int nq) {
+  MfmaPlan pl;
+  const int qtiles = (nq + 31) / 32;
+  pl.wide_q = n_rows < 65536 && qtiles >= 4;                           // small table, many queries: the waves split the queries
+  if (pl.wide_q) { pl.TN = qtiles >= 8 ? 2 : 1; pl.QB = 128 * pl.TN; pl.RB = 32; }
+  else { pl.TN = qtiles >= 8 ? 8 : qtiles >= 4 ? 4 : qtiles >= 2 ? 2 : 1; pl.QB = 32 * pl.TN; pl.RB = 128; }
+  const int WM = pl.wide_q ? 1 : 4;
+  pl.lds = 2 * (size_t)(pl.RB + pl.QB) * 128 + (size_t)pl.QB * (17 + 2 * WM + 1) * sizeof(Cand) + 4 * 32 * sizeof(float);
+  pl.gy = (nq + pl.QB - 1) / pl.QB;
+  const long long blocks = (n_rows + pl.RB - 1) / pl.RB;
+  int per_cu = (int)((160 * 1024) / pl.lds);
+  per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;                  // (160-208 VGPRs at TN <= 2: two workgroups per CU)
+  long long parts = (256LL * per_cu) / pl.gy;
+  parts = parts < 1 ? 1 : parts > blocks ? blocks : parts;
+  const long long bpp = (blocks + parts - 1) / parts;
+  pl.parts = (int)((blocks + bpp - 1) / bpp);
+  pl.rows_per_part = (int)(bpp * pl.RB);
+  pl.bytes = ((size_t)nq * sizeof(float) + 255) / 256 * 256 + (size_t)nq * pl.parts * 16 * sizeof(Cand);
+  return pl;
+}
+
+inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 && dim % 4 == 0; }
 
 inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
 
@@ -389,12 +631,14 @@ extern "C" int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries) 
   if (n_rows <= 0 || n_queries <= 0) return 0;
   int slices, rps;
   plan(n_rows, n_queries, &slices, &rps);
-  return kTicketBytes + (int64_t)n_queries * slices * 4 * 64 * (int64_t)sizeof(Cand);
+  const int64_t scan = kTicketBytes + (int64_t)n_queries * slices * 4 * 64 * (int64_t)sizeof(Cand);
+  const int64_t fan = n_queries >= 16 ? kTicketBytes + (int64_t)plan_mfma(n_rows, n_queries).bytes : 0;   // either form fits (the `order` argument picks one)
+  return scan > fan ? scan : fan;
 }
 
 extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim, const float* queries,
                              const int32_t* exclude, int32_t n_queries, int32_t k, int32_t metric, int32_t* out_rows, float* out_dist,
-                             void* workspace, int64_t workspace_bytes, int32_t postfilter) {
+                             void* workspace, int64_t workspace_bytes, int32_t postfilter, int32_t order) {
   if (!db || !queries || !out_rows || !out_dist || !workspace) return MRAG_EINVAL;
   if (n_rows <= 0 || n_rows > INT_MAX - 1 || n_queries <= 0 || dim <= 0) return MRAG_EINVAL;
   if (k <= 0 || k > 64) return MRAG_ENOTSUP;
@@ -413,6 +657,40 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   p.wpb = 4;
   const bool small = small_db(n_rows, n_queries);
   hipStream_t s = (hipStream_t)stream;
+  if (order < 0 || order > 2) return MRAG_EINVAL;
+  if (order == 2 && !mfma_applies(n_queries, k, dim)) return MRAG_ENOTSUP;
+  if (order == 2 || (order == 0 && mfma_applies(n_queries, k, dim))) {
+    // ---- the fan-out form: one fp32 MFMA pass over the table per 256 queries
+    const MfmaPlan pl = plan_mfma(n_rows, n_queries);
+    TopkMP m{};
+    m.db = db; m.group = p.group; m.q = queries; m.excl = exclude; m.n_rows = n_rows; m.dim = dim; m.nq = n_queries; m.k = k;
+    m.nparts = pl.parts; m.rows_per_part = pl.rows_per_part; m.nslab = (dim + 31) / 32;
+    float* qq = (float*)((char*)workspace + kTicketBytes);
+    m.qq = qq;
+    m.lists = (Cand*)((char*)workspace + kTicketBytes + ((size_t)n_queries * sizeof(float) + 255) / 256 * 256);
+    if (metric == 0) {
+      MRAG_LAUNCH(topk_qq_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, queries, qq, n_queries, dim);
+      MRAG_LAUNCH_CHECK();
+    }
+    const dim3 mgrid(pl.parts, pl.gy), block256(256);
+#define MRAG_TOPK_MFMA(M, W, T)                                                                                        \
+    if (metric == M && (pl.wide_q ? 1 : 4) == W && pl.TN == T) {                                                       \
+      auto kfn = topk_mfma_kernel<M, W, T>;                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
+      if (e != hipSuccess) return (int)e;                                                                              \
+      MRAG_LAUNCH(kfn, mgrid, block256, pl.lds, s, m);                                                                 \
+    }
+    MRAG_TOPK_MFMA(0, 4, 1) MRAG_TOPK_MFMA(0, 4, 2) MRAG_TOPK_MFMA(0, 4, 4) MRAG_TOPK_MFMA(0, 4, 8) MRAG_TOPK_MFMA(0, 1, 1) MRAG_TOPK_MFMA(0, 1, 2)
+    MRAG_TOPK_MFMA(1, 4, 1) MRAG_TOPK_MFMA(1, 4, 2) MRAG_TOPK_MFMA(1, 4, 4) MRAG_TOPK_MFMA(1, 4, 8) MRAG_TOPK_MFMA(1, 1, 1) MRAG_TOPK_MFMA(1, 1, 2)
+#undef MRAG_TOPK_MFMA
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_TOPK_MFMA);
+    p.ws = m.lists; p.slices = pl.parts; p.wpb = 1;
+    MRAG_LAUNCH(topk_merge_kernel<16>, dim3(n_queries), dim3(256), 0, s, p);
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_TOPK_MERGE);
+    return MRAG_OK;
+  }
   const int QT = pick_qt(n_queries), nj = (dim + 63) / 64;
   // blocks of 64 floats per register-ring step: 4 for the single query, 2 for query tiles (their chains need the registers)
   const int JCsel = QT == 1 ? (nj % 4 == 0 ? 4 : 1) : (nj % 2 == 0 ? 2 : 1);
@@ -448,7 +726,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
 #undef MRAG_TOPK_CASE
   MRAG_LAUNCH_CHECK();
   MRAG_COUNT(MRAG_K_TOPK_SCAN);
-  MRAG_LAUNCH(topk_merge_kernel, dim3(n_queries), dim3(256), 0, s, p);
+  MRAG_LAUNCH(topk_merge_kernel<64>, dim3(n_queries), dim3(256), 0, s, p);
   MRAG_LAUNCH_CHECK();
   MRAG_COUNT(MRAG_K_TOPK_MERGE);
   return MRAG_OK;

@@ -566,11 +566,16 @@ def topk_workspace(device: torch.device, N: int, Q: int) -> torch.Tensor:
     return ws
 
 
+TOPK_ORDER = {"auto": 0, "chain16": 1, "mfma": 2}
+
+
 def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None,
-         exclude: Optional[torch.Tensor] = None, out: Optional[tuple] = None, postfilter: bool = False):
+         exclude: Optional[torch.Tensor] = None, out: Optional[tuple] = None, postfilter: bool = False, order: str = "auto"):
     """flat-scan top-k: returns (rows int32 [Q, k], dist fp32 [Q, k]) sorted by (dist asc, row asc).  `out` = (rows, dist) buffers to fill
     (a caller that searches repeatedly keeps them: no allocation on the call path).  `postfilter`: rows of the excluded group are dropped
-    AFTER the k nearest were selected (lancedb's `where(..., prefilter=False)`; possibly < k results, tail row -1) instead of before."""
+    AFTER the k nearest were selected (lancedb's `where(..., prefilter=False)`; possibly < k results, tail row -1) instead of before.
+    `order`: the distance's summation order (include/mrag_hip.h): "chain16" (the scan kernel), "mfma" (the fan-out kernel: >= 16 queries, k <= 16: one
+    pass over the table per 256 queries on fp32 MFMAs) or "auto" (mfma where it applies)."""
     _dev(db, torch.float32, "db"); _dev(queries, torch.float32, "queries")
     if not db.is_contiguous() or not queries.is_contiguous():
         raise ValueError("topk: contiguous db / queries required")
@@ -590,7 +595,7 @@ def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2",
         if tuple(rows.shape) != (Q, k) or tuple(dist.shape) != (Q, k) or rows.dtype != torch.int32 or dist.dtype != torch.float32:
             raise ValueError("topk: out = (int32 [Q, k], float32 [Q, k])")
     check(_lib.lib().mrag_topk_f32(_stream(), _p(db), _p(group) if exclude is not None else None, N, D, _p(queries),
-                                   _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws.numel(), int(bool(postfilter))), "mrag_topk_f32")
+                                   _p(exclude), Q, k, m, _p(rows), _p(dist), _p(ws), ws.numel(), int(bool(postfilter)), TOPK_ORDER[order]), "mrag_topk_f32")
     return rows, dist
 
 
@@ -601,7 +606,7 @@ class TopkPlan:
     that was host overhead).  `graph=True` additionally records the launch in a HIP graph (`replay()`)."""
 
     def __init__(self, db: torch.Tensor, n_queries: int, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None, graph: bool = False,
-                 postfilter: bool = False):
+                 postfilter: bool = False, order: str = "auto"):
         _dev(db, torch.float32, "db")
         if not db.is_contiguous():
             raise ValueError("TopkPlan: contiguous db required")
@@ -616,7 +621,8 @@ class TopkPlan:
         self._ws = torch.zeros(L.mrag_topk_workspace_bytes(N, n_queries), dtype=torch.uint8, device=dev)   # private: counters stay consistent
         self._fn = L.mrag_topk_f32
         self._args = (_p(db), _p(group) if group is not None else None, N, D, _p(self.queries), _p(self.exclude) if group is not None else None,
-                      n_queries, k, {"l2": 0, "dot": 1}[metric], _p(self.rows), _p(self.dist), _p(self._ws), self._ws.numel(), int(bool(postfilter)))
+                      n_queries, k, {"l2": 0, "dot": 1}[metric], _p(self.rows), _p(self.dist), _p(self._ws), self._ws.numel(), int(bool(postfilter)),
+                      TOPK_ORDER[order])
         self._graph = None
         if graph:
             self.run()

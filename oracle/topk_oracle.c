@@ -16,10 +16,16 @@
  * no test or golden vector for retrieval, and lancedb is not installed here (the default is cited from the 0.14.0 package's
  * `lancedb/query.py`, `def where(self, where: str, prefilter: bool = False)`).
  *
- * Two scoring modes:
+ * Three scoring modes:
  *   mode 0: float32, 16 interleaved fmaf chains + a fixed pairwise tree (chain16 below) -- the exact evaluation
- *           order of the HIP kernel, so distances and indices are BIT-EXACT comparable;
- *   mode 1: float64 accumulation (canonical math), used to check that mode 0 ranks the same rows.
+ *           order of the HIP scan kernel (fewer than 16 queries per call), so distances and indices are BIT-EXACT comparable;
+ *   mode 1: float64 accumulation (canonical math), used to check that modes 0 and 2 rank the same rows;
+ *   mode 2: float32 in the order of the HIP fan-out kernel (16 or more queries per call: the scan as an fp32 matrix product on
+ *           v_mfma_f32_32x32x2_f32, whose result is bit for bit a k-ordered fmaf chain): ONE chain per (query, row) over the
+ *           features in the order 8c, 8c+4, 8c+1, 8c+5, 8c+2, 8c+6, 8c+3, 8c+7 (c = 0, 1, ..: an MFMA takes one feature from
+ *           each half of a 32-byte block); metric "dot": 1 - dot; metric "l2" through the expansion
+ *           |q - x|^2 = (|q|^2 + |x|^2) - 2 q.x = fmaf(-2, dot, qq + xx), the squared norms as TWO chains (features 8c + t and
+ *           8c + 4 + t, t = 0..3, c ascending) added once (mfma_dot / mfma_sq below).  BIT-EXACT comparable as well.
  * Ties: (distance asc, row asc).  Missing results: row = -1, dist = +inf.
  */
 #include <math.h>
@@ -55,10 +61,37 @@ static float chain16(const float* q, const float* x, int dim, int metric) {
   return p[0];
 }
 
+/* mode 2: the fan-out kernel's orders (see the header) */
+static float mfma_dot(const float* q, const float* x, int dim) {
+  float acc = 0.0f;
+  for (int c = 0; 8 * c < dim; ++c)
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = 8 * c + t, k1 = 8 * c + 4 + t;
+      if (k0 < dim) acc = fmaf(x[k0], q[k0], acc);
+      if (k1 < dim) acc = fmaf(x[k1], q[k1], acc);
+    }
+  return acc;
+}
+static float mfma_sq(const float* x, int dim) {
+  float lo = 0.0f, hi = 0.0f;
+  for (int c = 0; 8 * c < dim; ++c)
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = 8 * c + t, k1 = 8 * c + 4 + t;
+      if (k0 < dim) lo = fmaf(x[k0], x[k0], lo);
+      if (k1 < dim) hi = fmaf(x[k1], x[k1], hi);
+    }
+  return lo + hi;
+}
+
 static double score(const float* q, const float* x, int dim, int metric, int mode) {
   if (mode == 0) {
     const float acc = chain16(q, x, dim, metric);
     return metric == 0 ? (double)acc : (double)(1.0f - acc);
+  } else if (mode == 2) {
+    const float dot = mfma_dot(q, x, dim);
+    if (metric != 0) return (double)(1.0f - dot);
+    const float t = mfma_sq(q, dim) + mfma_sq(x, dim);
+    return (double)fmaf(-2.0f, dot, t);
   } else {
     double acc = 0.0;
     if (metric == 0) { for (int d = 0; d < dim; ++d) { double df = (double)q[d] - (double)x[d]; acc += df * df; } return acc; }

@@ -21,8 +21,9 @@ def build() -> str:
 
 def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, mode: str = "f32chain",
          postfilter: bool = False):
-    """returns (rows int32 [Q, k], dist float64 [Q, k]); mode 'f32chain' (bit-comparable with the HIP
-    kernel) or 'f64'.  `postfilter`: lancedb's `where(..., prefilter=False)` order (topk_oracle.c header)."""
+    """returns (rows int32 [Q, k], dist float64 [Q, k]); mode 'f32chain' (bit-comparable with the HIP scan kernel: fewer than 16 queries per
+    call), 'f32mfma' (bit-comparable with the HIP fan-out kernel: 16 or more queries per call) or 'f64'.
+    `postfilter`: lancedb's `where(..., prefilter=False)` order (topk_oracle.c header)."""
     lib = ctypes.CDLL(build())
     db = np.ascontiguousarray(db, dtype=np.float32)
     queries = np.ascontiguousarray(queries, dtype=np.float32)
@@ -38,7 +39,7 @@ def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=
     lib.topk_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     rc = lib.topk_oracle(db.ctypes.data_as(ctypes.c_void_p), gp, n, d, queries.ctypes.data_as(ctypes.c_void_p), ep, q, k,
-                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1}[mode], int(bool(postfilter)), rows.ctypes.data_as(ctypes.c_void_p),
+                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1, "f32mfma": 2}[mode], int(bool(postfilter)), rows.ctypes.data_as(ctypes.c_void_p),
                          dist.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
         raise RuntimeError(f"topk_oracle rc={rc}")

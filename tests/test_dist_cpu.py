@@ -93,8 +93,13 @@ def test_bench_detects_an_attached_profiler(monkeypatch):
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.profiler_attached()
     monkeypatch.setenv("LD_PRELOAD", "")
-    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x.so")
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.profiler_attached()
+    # a container that merely exports some ROCPROF_* / ROCP_* variable is NOT a profiler -- the default run must measure the same workload
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    monkeypatch.setenv("ROCP_METRICS", "x.xml")
+    assert not bench.profiler_attached()
 
 
 def _sp_worker(rank, world, port, ret):

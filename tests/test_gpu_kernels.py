@@ -561,14 +561,23 @@ def test_attention_baseline_shape_split_tail_properties(hip):
 
 
 # ---------------------------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104)])
+@pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104), (1027, 320), (2050, 640), (1029, 1280)])
 def test_layernorm(hip, rows, D):
+    """(the last three: the narrow-row kernel -- 8 / 4 / 2 rows per wave at C = 320 / 640 / 1 280 from 1 024 rows up -- with ragged last workgroups)"""
     from motionrag_amd import ops
     g = torch.Generator().manual_seed(rows)
     x, w, b = bf(torch.randn(rows, D, generator=g) * 2 + 0.5), bf(1 + 0.1 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
     want = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
-    close(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5), want, scale=1.0)
+    with ops.dispatched() as d:
+        got = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert d.counts == ({"LAYERNORM_ROWS": 1} if rows >= 1024 and D in (320, 640, 1280) else {"LAYERNORM": 1}), d.counts
+    close(got, want, scale=1.0)
     close(ops.layernorm(x.to(DEV), None, None, 1e-6), torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6), scale=1.0)
+    # a strided input / output view (a column slice of a wider buffer) takes the same kernels
+    wide_in, wide_out = torch.zeros(rows, D + 64, dtype=torch.bfloat16, device=DEV), torch.zeros(rows, D + 128, dtype=torch.bfloat16, device=DEV)
+    wide_in[:, :D] = x.to(DEV)
+    ops.layernorm(wide_in[:, :D], w.to(DEV), b.to(DEV), 1e-5, out=wide_out[:, 64:64 + D])
+    assert torch.equal(wide_out[:, 64:64 + D], got) and wide_out[:, :64].abs().max().item() == 0 and wide_out[:, 64 + D:].abs().max().item() == 0
 
 
 def test_layernorm_adaln_modulation_and_batched_output(hip):
@@ -668,13 +677,20 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
     db, q = _unit(rng, N, D), _unit(rng, Q, D)
     group = (np.arange(N) // 2).astype(np.int32)
     excl = group[rng.integers(0, N, Q)].astype(np.int32)
-    want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32chain")
-    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
-                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
-    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
-    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))      # same fmaf chain -> same bits
-    rows2, _ = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric)
-    np.testing.assert_array_equal(rows2.cpu().numpy(), topk_ref.topk(db, q, k, metric)[0])
+    # the 16-chain scan kernel (`order="chain16"`: every batch size) and, where it applies (>= 16 queries, k <= 16), the fan-out kernel that "auto" picks
+    for order, mode in (("chain16", "f32chain"),) + ((("auto", "f32mfma"), ("mfma", "f32mfma")) if Q >= 16 and k <= 16 else (("auto", "f32chain"),)):
+        want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode=mode)
+        with ops.dispatched() as d:
+            rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
+                                  group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order=order)
+        assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))      # same fmaf chain -> same bits
+        rows2, _ = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric, order=order)
+        np.testing.assert_array_equal(rows2.cpu().numpy(), topk_ref.topk(db, q, k, metric, mode=mode)[0])
+    if not (Q >= 16 and k <= 16):
+        with pytest.raises(Exception):
+            ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric, order="mfma")     # MRAG_ENOTSUP: the fan-out form takes >= 16 queries, k <= 16
 
 
 @pytest.mark.parametrize("metric", ["l2", "dot"])
@@ -682,7 +698,7 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
 def test_topk_filter_order_bit_exact(hip, metric, Q):
     """lancedb's post-filter (`where(..., prefilter=False)`: the k nearest first, then the filter) and the pre-filter against the C oracle in the
     matching mode, bit for bit, on a database with 6 clips per video where the two orders give different lists; Q = 1 / 3 run the fused
-    single-launch form, 5 the query-tile scan + merge kernel, 40 the 16-query tiles"""
+    single-launch form, 5 the query-tile scan + merge kernel, 40 the fan-out (fp32 MFMA) kernel"""
     from motionrag_amd import ops
     from oracle import topk_ref
     from test_oracle_golden import multi_clip_db
@@ -695,7 +711,7 @@ def test_topk_filter_order_bit_exact(hip, metric, Q):
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, own))
     lists = {}
     for post in (False, True):
-        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32chain", postfilter=post)
+        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32mfma" if Q >= 16 else "f32chain", postfilter=post)   # Q = 40: the fan-out kernel ("auto")
         rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post)
         np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
         np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
@@ -742,10 +758,44 @@ def test_topk_baseline_size(hip):
     rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
                           group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
     rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
-    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")
+    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32mfma")          # 256 queries: the fan-out kernel, ONE pass over the table
     np.testing.assert_array_equal(rows, want_r)
     np.testing.assert_array_equal(dist, want_d.astype(np.float32))
     assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
+    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
+                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order="chain16")   # the scan kernel: 16 passes of 16 queries
+    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")
+    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("N,Q,D,k", [(3000, 130, 768, 12), (70001, 40, 768, 12), (66000, 256, 256, 16), (5000, 20, 100, 1), (9000, 300, 64, 7), (130, 16, 32, 12)])
+def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
+    """the fan-out kernel (fp32 MFMA, `order="mfma"`) against mode 2 of the C oracle, rows AND distances bit for bit, in every configuration of its plan:
+    a small table with many queries (the waves split the queries: 32 rows x 4 x 32 TN queries per workgroup), a large table (4 x 32 rows per workgroup,
+    32 TN queries per wave, TN = 1 / 2 / 8), more than one query block (Q = 300), a feature count that is no multiple of the 32-feature slab (D = 100: the
+    tail chunks stream from a zero row), k = 1 / 7 / 16, a table smaller than a row block; with the self-exclusion filter in both orders"""
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    rng = np.random.default_rng(N + Q)
+    db, q = _unit(rng, N, D), _unit(rng, Q, D)
+    db[N // 2] = db[N // 3]                                                       # an exact tie: (distance, row) order decides
+    group = (np.arange(N) // 2).astype(np.int32)
+    excl = group[rng.integers(0, N, Q)].astype(np.int32)
+    q[: Q // 4] = db[(2 * excl[: Q // 4])] + 0.01 * q[: Q // 4]                   # queries next to a row of the excluded video
+    dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
+    for post in (False, True):
+        want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32mfma", postfilter=post)
+        with ops.dispatched() as d:
+            rows, dist = ops.topk(dbd, qd, k, metric=metric, group=gd, exclude=ed, postfilter=post, order="mfma")
+        assert d.counts.get("TOPK_MFMA", 0) == 1 and "TOPK_SCAN" not in d.counts, d.counts
+        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+    want_r, want_d = topk_ref.topk(db, q, k, metric, mode="f32mfma")
+    rows, dist = ops.topk(dbd, qd, k, metric=metric, order="mfma")
+    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 
 
 @pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128), (30001, 272, 192)])

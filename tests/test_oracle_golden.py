@@ -177,6 +177,16 @@ def test_topk_oracle_c_vs_numpy(metric):
     np.testing.assert_allclose(d32, d64, rtol=0, atol=5e-6)
     for qi in range(9):                             # the filter really removed the excluded group
         assert not np.any(group[r32[qi]] == excl[qi])
+    # mode 2 -- the fan-out kernel's order (one chain over the features 8c, 8c+4, 8c+1, ...; L2 through |q|^2 + |x|^2 - 2 q.x): same ranks, fp32-close distances,
+    # and its chain is a PERMUTATION of the feature order: on features that are exactly representable sums it equals the plain dot product
+    rm, dm = topk_ref.topk(db, q, 12, metric, group, excl, mode="f32mfma")
+    np.testing.assert_array_equal(rm, r64)
+    np.testing.assert_allclose(dm, d64, rtol=0, atol=5e-6)
+    ints = rng.integers(-8, 9, (40, 96)).astype(np.float32)                       # small integers: every partial sum is exact in fp32, any order gives the same bits
+    ri, di = topk_ref.topk(ints, ints[:3], 5, metric, mode="f32mfma")
+    rc, dc = topk_ref.topk(ints, ints[:3], 5, metric, mode="f32chain")
+    np.testing.assert_array_equal(ri, rc)
+    np.testing.assert_array_equal(di, dc)
 
 
 def multi_clip_db(rng, n_videos=50, clips=6, dim=64, spread=0.05):

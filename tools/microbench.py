@@ -153,6 +153,11 @@ def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
         dt = timeit(lambda: ops.topk(db, q, 12), iters=5)
         print(f"topk N={N} Q={Q}: {dt*1e6:.1f} us  db stream {N*768*4/dt/1e9:.0f} GB/s  ({Q/dt:.0f} queries/s)")
         res[f"N{N}_Q{Q}"] = {"us": round(dt * 1e6, 1), "db_stream_GBps": round(N * 768 * 4 / dt / 1e9), "queries_per_s": round(Q / dt)}
+        if Q >= 16:     # batches run the fan-out kernel (fp32 MFMA, one pass over the table per 256 queries); the 16-chain scan kernel beside it
+            res[f"N{N}_Q{Q}"]["fp32_mfma_tflops"] = round(2.0 * N * Q * 768 / dt / 1e12, 1)
+            dtc = timeit(lambda: ops.topk(db, q, 12, order="chain16"), iters=3)
+            print(f"   scan kernel (order chain16): {dtc*1e6:.1f} us; fan-out kernel {2.0*N*Q*768/dt/1e12:.1f} TFLOP/s of fp32 MFMA (peak 157)")
+            res[f"N{N}_Q{Q}"]["chain16_us"] = round(dtc * 1e6, 1)
         if Q <= 4:      # the interactive query through a prepared plan: one C-ABI call = one kernel launch, nothing allocated
             plan = ops.TopkPlan(db, Q, 12, graph=True)
             plan.queries.copy_(q)

@@ -469,8 +469,9 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       "l2" through fmaf(-2, q.x, |q|^2 + |x|^2) with the squared norms as two */
 /*       half-block chains (mode 2 of the oracle).  n_queries >= 16, k <= 16,    */
 /*       else MRAG_ENOTSUP;                                                      */
-/*   0 = automatic: 2 where it applies (n_queries >= 16 and k <= 16), else 1 --  */
-/*       a batch of 16 or more and a single query may therefore differ in the    */
+/*   0 = automatic: 2 where it applies AND the table has >= 32 768 rows (below   */
+/*       that the two forms take the same time), else 1 -- a batch of 16 or more */
+/*       against a large table and a single query may therefore differ in the    */
 /*       last bits of a distance (never in a rank whose gap exceeds the fp32     */
 /*       rounding of the sum: tests compare both with the float64 oracle).       */
 /* ------------------------------------------------------------------------ */

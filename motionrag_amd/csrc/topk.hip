@@ -21,8 +21,18 @@
 #include "common.h"
 #include "../../include/mrag_hip.h"
 #include <limits.h>
+#include <type_traits>
 
 namespace {
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 constexpr int ROWS = 256;      // rows per workgroup iteration (4 waves x 64 lanes)
 
@@ -367,10 +377,11 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
 // (MI355X guide, "FP32-input MFMA"), so the distances are DEFINED: one chain per (query, row) in the feature order 8c, 8c+4, 8c+1, 8c+5, ... (an MFMA takes
 // feature k from lanes 0-31 and k' from lanes 32-63; a lane's four MFMAs of a 32-byte block use the four floats of ONE ds_read_b128), squared norms as two
 // chains (oracle/topk_oracle.c mode 2 restates it; bit-exact tests).  L2 goes through |q|^2 + |x|^2 - 2 q.x.
-//   * workgroup = 4 waves; config A (large tables): 4 x 32 database rows x 32 TN queries per wave; config B (small tables, many queries): 32 rows x 4 x 32 TN
-//     queries -- the waves split the queries so that a 10 k-row table still fills the chip;
-//   * both operands ride the LDS: 32-feature slabs (128-byte rows, 16-byte chunks XOR-swizzled by row & 7 on the DMA's source side), two stages, LDS-DMA of
-//     slab i + 1 under the MFMAs of slab i; the stream runs across the row blocks of a workgroup;
+//   * workgroup = 4 waves x 32 database rows, every wave against the workgroup's 32 TN queries (TN = 8 / 4 / 2 / 1 tiles of 32: the plan takes the largest
+//     TN that still gives the chip >= 256 workgroups, so a 10 k-row table is cut along the QUERIES as well -- grid.y -- instead of leaving CUs idle);
+//   * both operands ride the LDS: 32-feature slabs (128-byte rows, 16-byte chunks XOR-swizzled by row & 7 on the DMA's source side) in a ring of NST stages
+//     (2 at TN = 8, where a slab is 8 192 MFMA cycles per wave; 3-4 at the narrow tiles, whose 1-2 k cycles per slab are shorter than one DMA round trip):
+//     the LDS-DMA of slab i + NST - 1 is issued under the MFMAs of slab i behind a COUNTED vmcnt wait; the stream runs across the row blocks of a workgroup;
 //   * accumulator layout: lane (n = lane & 31, h = lane >> 5) holds query n of a 32-query tile against rows (reg & 3) + 8 (reg >> 2) + 4 h: after a row block a
 //     lane tests its 16 rows against ITS query's current k-th distance (a register).  Survivors are rare once the lists are warm; they go, one per lane and
 //     round, through per-query slots to the query's OWNER thread, which inserts them into the workgroup's sorted top-16 list in LDS and republishes the
@@ -378,16 +389,33 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkP p) {
 //   * per-workgroup lists [query][part][16] leave through the workspace and the merge kernel (LIST = 16) finishes, filter order included.
 __device__ __attribute__((aligned(128))) float g_topk_zero[32];    // source of feature chunks past `dim` (never written)
 
+#ifdef MRAG_TOPK_DIAG_STATS   // developer timing build: [0] selection rounds, [1] cycles inside the selection, [2] cycles in the whole kernel, [3] row blocks (summed over workgroups)
+__device__ unsigned long long g_topk_dbg[4];
+extern "C" int mrag_debug_topk_stats(unsigned long long* out_host, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_topk_dbg), sizeof(g_topk_dbg));
+  if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_topk_dbg), z, sizeof(z)); }
+  return (int)e;
+}
+#define MRAG_TSTAMP(T) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory")
+#endif
 struct TopkMP {
   const float* db; const int* group; const float* q; const int* excl; const float* qq;
+  unsigned* tau_g;        // [nq] the best k-th distance any workgroup has published for the query, as an order-preserving unsigned key (atomicMin)
   Cand* lists;
   long long n_rows; int dim, nq, k, nparts, rows_per_part, nslab;
 };
 
-// |q|^2 of every query in the fan-out kernel's order: chains over features 8c + t and 8c + 4 + t, added once
-__global__ __launch_bounds__(256) void topk_qq_kernel(const float* q, float* qq, int nq, int dim) {
+// order-preserving map float -> unsigned (a < b  <=>  key(a) < key(b), -0 < +0): the shared thresholds are lowered with atomicMin
+__device__ __forceinline__ unsigned float_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// per call: the shared thresholds start at +inf; |q|^2 of every query in the fan-out kernel's order (chains over features
+// 8c + t and 8c + 4 + t, added once) when the metric needs it
+__global__ __launch_bounds__(256) void topk_qq_kernel(const float* q, float* qq, unsigned* tau_g, int nq, int dim, int want_qq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nq) return;
+  tau_g[i] = 0xff800000u;                            // float_key(+inf): no threshold yet
+  if (!want_qq) return;
   const float* x = q + (long long)i * dim;
   float lo = 0.f, hi = 0.f;
   for (int c = 0; 8 * c < dim; ++c)
@@ -400,17 +428,20 @@ __global__ __launch_bounds__(256) void topk_qq_kernel(const float* q, float* qq,
   qq[i] = lo + hi;
 }
 
-template <int METRIC, int WM, int TN>
+constexpr int mfma_stages(int TN) { return TN >= 8 ? 2 : TN == 4 ? 3 : TN == 2 ? 4 : 3; }   // TN = 1: three stages keep two workgroups per CU (67 KB each)
+
+template <int METRIC, int TN>
 __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
-  constexpr int WN = 4 / WM, RB = 32 * WM, QB = 32 * TN * WN;
-  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = (NPIECE + 3) / 4, LSTR = 17, NSLOT = 2 * WM;
+  constexpr int WM = 4, WN = 1, RB = 32 * WM, QB = 32 * TN * WN, NST = mfma_stages(TN);
+  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = NPIECE / 4, LSTR = 17, NSLOT = 2 * WM;
+  static_assert(NPIECE % 4 == 0, "every wave issues the same number of LDS-DMA pieces per slab (the counted vmcnt wait relies on it)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Cand* lists = (Cand*)(smem + 2 * STAGE);          // [QB][LSTR]: sorted ascending, entries >= k stay +inf
+  Cand* lists = (Cand*)(smem + NST * STAGE);        // [QB][LSTR]: sorted ascending, entries >= k stay +inf
   Cand* slots = lists + QB * LSTR;                  // [QB][NSLOT]: this round's candidate of each (wave, half) for the query
   Cand* taus = slots + QB * NSLOT;                  // [QB]: the query's k-th best so far
   float* xxs = (float*)(taus + QB);                 // [4][32]: |x|^2 of the wave's 32 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = WM == 4 ? wave : 0, wn = WM == 4 ? 0 : wave;
+  const int wm = wave, wn = 0;
   const int r32 = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.y * QB, part = blockIdx.x;
   const long long row_begin = (long long)part * p.rows_per_part;
@@ -422,41 +453,64 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
   for (int i = tid; i < QB; i += 256) taus[i] = inf;
 
   // per lane: the query of each of its TN tiles
-  float qqv[TN]; int exclv[TN]; bool qok[TN]; Cand tau[TN];
+  // (scalars and scalar arrays only below: a private ARRAY OF STRUCTS is not promoted to registers by hipcc -- it lives in scratch, and every scratch access is a
+  // vector-memory operation whose s_waitcnt vmcnt(0) also waits for the whole LDS-DMA ring: measured 50 k cycles per selection round)
+  float qqv[TN]; int exclv[TN]; bool qok[TN]; float tau_d[TN]; int tau_r[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int qi = q0 + (wn * TN + j) * 32 + r32;
     qok[j] = qi < p.nq;
     qqv[j] = (METRIC == 0 && qok[j]) ? p.qq[qi] : 0.f;
     exclv[j] = (p.excl && p.group && qok[j]) ? p.excl[qi] : INT_MIN;
-    tau[j] = inf;
+    tau_d[j] = INFINITY; tau_r[j] = INT_MAX;
   }
 
-  // ---- the LDS-DMA stream: item `it` = (row block, feature slab), stage it & 1
+  // ---- the LDS-DMA stream: item `it` = (row block, feature slab), stage it % NST.  Per wave and slab: 4 pieces of table rows + TN pieces of query rows
+  // (1 KiB = 8 rows x 128 bytes each).  The row pointers are kept in registers (queries: fixed; table rows: per row block), so a piece costs one 64-bit add;
+  // the pieces of slab it + NST - 1 are issued in four portions BETWEEN the MFMA groups of slab it (an LDS-DMA instruction takes ~100 cycles to issue: a
+  // burst of 12 in front of the MFMAs idled the matrix pipe for a fifth of a slab).
   const int chunk = (lane & 7) ^ (lane >> 3);       // source chunk of this lane inside its 128-byte slab row (row & 7 == lane >> 3)
-  int d_blk = 0, d_s = 0;
-  auto issue = [&](const int stage) {
-    char* base = smem + stage * STAGE;
-    const int kk = d_s * 32 + chunk * 4;
+  const float* qptr[TN];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int pc = wave + 4 * i;
-      if (pc < NPIECE) {
-        const float* src;
-        if (pc < RB / 8) {
-          long long row = row_begin + (long long)d_blk * RB + 8 * pc + (lane >> 3);
-          row = row < p.n_rows ? row : p.n_rows - 1;
-          src = p.db + row * p.dim;
-        } else {
-          int qi = q0 + 8 * (pc - RB / 8) + (lane >> 3);
-          qi = qi < p.nq ? qi : p.nq - 1;
-          src = p.q + (long long)qi * p.dim;
-        }
-        src = kk < p.dim ? src + kk : g_topk_zero + chunk * 4;
-        glds16(src, base + pc * 1024);
-      }
+  for (int i = 0; i < TN; ++i) {
+    int qi = q0 + 8 * (wave + 4 * i) + (lane >> 3);
+    qi = qi < p.nq ? qi : p.nq - 1;
+    qptr[i] = p.q + (long long)qi * p.dim;
+  }
+  const float* aptr[4];
+  int d_blk = 0, d_s = 0;
+  auto set_rows = [&](const int blk_) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long long row = row_begin + (long long)blk_ * RB + 8 * (wave + 4 * i) + (lane >> 3);
+      row = row < p.n_rows ? row : p.n_rows - 1;     // (past the table -- also past the END of the stream -- the last row is re-read and never used)
+      aptr[i] = p.db + row * p.dim;
     }
-    if (++d_s == p.nslab) { d_s = 0; ++d_blk; }
+  };
+  set_rows(0);
+  auto issue_piece = [&](auto I, const int stage) {  // piece I (< 4: table rows, else query rows) of the cursor's slab
+    constexpr int i = decltype(I)::value;
+    const int kk = d_s * 32 + chunk * 4;
+    const float* src = i < 4 ? aptr[i < 4 ? i : 0] : qptr[i < 4 ? 0 : i - 4];
+    src = kk < p.dim ? src + kk : g_topk_zero + chunk * 4;
+    char* dst = smem + stage * STAGE + ((i < 4 ? 0 : RB / 8) + wave + 4 * (i < 4 ? i : i - 4)) * 1024;
+#ifndef MRAG_TOPK_DIAG_NODMA  // developer timing build: no operand traffic (the MFMAs run on whatever the LDS holds)
+    glds16(src, dst);
+#endif
+  };
+  auto advance = [&]() {
+    if (++d_s == p.nslab) { d_s = 0; ++d_blk; set_rows(d_blk); }
+  };
+  auto issue_phase = [&](auto C, const int stage) {  // the pieces of phase C = 0..3 of a slab: piece i belongs to phase (4 i) / PPW
+    constexpr int c = decltype(C)::value;
+    static_for<PPW>([&](auto I) __attribute__((always_inline)) {
+      if constexpr ((4 * decltype(I)::value) / PPW == c) issue_piece(I, stage);
+    });
+    if constexpr (c == 3) advance();
+  };
+  auto issue_all = [&](const int stage) {
+    issue_phase(std::integral_constant<int, 0>{}, stage); issue_phase(std::integral_constant<int, 1>{}, stage);
+    issue_phase(std::integral_constant<int, 2>{}, stage); issue_phase(std::integral_constant<int, 3>{}, stage);
   };
 
   f32x16 acc[TN];
@@ -465,20 +519,28 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   float xx = 0.f;
+#ifdef MRAG_TOPK_DIAG_STATS
+  unsigned long long dbg_t0, dbg_sel = 0, dbg_rounds = 0, dbg_a, dbg_b;
+  MRAG_TSTAMP(dbg_t0);
+#endif
   const int total = nblk * p.nslab;
   __syncthreads();                                   // lists / thresholds initialised
-  if (total > 0) issue(0);
-  int s = 0, blk = 0;
+  // prologue: NST - 1 slabs in flight.  Past the end of the stream `issue` keeps requesting (the cursor clamps to the table's last row and re-reads a slab into a
+  // stage nobody reads again), so EVERY iteration issues exactly PPW pieces per wave and one counted wait fits all of them
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue_all(i);
+  int s = 0, blk = 0, stg = 0;
   for (int it = 0; it < total; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                 // slab `it` landed for every wave; every wave is done reading the other stage
-    if (it + 1 < total) issue((it + 1) & 1);
-    const char* st = smem + (it & 1) * STAGE;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (NST - 2)) : "memory");   // all but the newest NST - 2 slabs have landed: slab `it` is in LDS
+    __syncthreads();                                 // ... for every wave; and every wave is done reading the stage that slab it + NST - 1 overwrites
+    const int nstage = stg == 0 ? NST - 1 : stg - 1; // slab it + NST - 1 -> stage (it + NST - 1) % NST
+    const char* st = smem + stg * STAGE;
+    stg = stg + 1 == NST ? 0 : stg + 1;
     const char* arow = st + (wm * 32 + r32) * 128;
     const char* qrow = st + (RB + wn * TN * 32 + r32) * 128;
     const int sw = r32 & 7;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    static_for<4>([&](auto C) __attribute__((always_inline)) {
+      constexpr int c = decltype(C)::value;
       const int off = ((2 * c + h) ^ sw) * 16;
       const f32x4 a4 = *(const f32x4*)(arow + off);
       if constexpr (METRIC == 0) {
@@ -489,80 +551,180 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) b4[j] = *(const f32x4*)(qrow + j * 32 * 128 + off);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[j][0], acc[j], 0, 0, 0);
+      issue_phase(C, nstage);                          // (behind the first MFMAs of the group: the DMA's issue time passes under the matrix pipe)
+#pragma unroll
+      for (int t = 1; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
-    }
+    });
     if (++s < p.nslab) continue;
     // ---- end of a row block: distances, then the selection rounds
     s = 0;
+#ifdef MRAG_TOPK_DIAG_NOSEL   // developer timing build (tools/build_variant.sh): the MFMA / DMA stream alone
+    ++blk;
+    continue;
+#endif
     const long long blk_row0 = row_begin + (long long)blk * RB + wm * 32;
     ++blk;
+#ifdef MRAG_TOPK_DIAG_STATS
+    MRAG_TSTAMP(dbg_a);
+#endif
     if constexpr (METRIC == 0) {
       const float xf = xx + __shfl_xor(xx, 32);      // the two half-row chains, added once (either lane: the same two addends)
       if (h == 0) xxs[wave * 32 + r32] = xf;
       xx = 0.f;
     }
     __syncthreads();
+    int gid[16];                                      // the rows' video ids (prefilter): 16 independent loads, one wait
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) gid[reg] = INT_MIN + 1;
+    if (p.group) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long long grow = blk_row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        gid[reg] = p.group[grow < row_end ? grow : row_end - 1];
+      }
+    }
+    // the SHARED threshold of each query: the smallest k-th distance any workgroup has published so far.  A row farther than that has k rows in front of it
+    // somewhere in the table and cannot be in the answer (equal distances stay: `<=`), so it never becomes a candidate here -- a workgroup sees 1 / parts of
+    // the table and its own k-th distance alone admits parts-times more rows (3.5 workgroup-synchronous rounds per row block instead of ~1).  Reading a
+    // stale value is harmless (the thresholds only fall).
+    float gt[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) gt[j] = qok[j] ? key_float(__hip_atomic_load(p.tau_g + q0 + (wn * TN + j) * 32 + r32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -INFINITY;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
       const long long grow = blk_row0 + i;
       const bool valid = grow < row_end;
       const float xi = METRIC == 0 ? xxs[wave * 32 + i] : 0.f;
-      const int gi = p.group ? p.group[valid ? grow : row_end - 1] : INT_MIN + 1;
+      const int gi = gid[reg];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const float dot = acc[j][reg];
         const float d = METRIC == 0 ? __builtin_fmaf(-2.0f, dot, qqv[j] + xi) : 1.0f - dot;
-        acc[j][reg] = (valid && qok[j] && gi != exclv[j]) ? d : INFINITY;
+        acc[j][reg] = (valid && d <= gt[j] && gi != exclv[j]) ? d : INFINITY;     // (gt = -inf for a query past the batch; NaN distances drop out too)
       }
     }
+    float bd[TN];                                     // the lane's best remaining row of each tile (re-scanned only after it was consumed)
+    int br[TN];
+    auto rescan = [&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      // branch-free (hipcc turned the compare-and-keep form into a chain of exec-masked branches, ~370 instructions per tile): the minimum by v_min, then the
+      // LOWEST register that holds it (the lowest row among equal distances)
+      float m = acc[j][0];
+#pragma unroll
+      for (int reg = 1; reg < 16; ++reg) m = fminf(m, acc[j][reg]);
+      int r = 0;
+#pragma unroll
+      for (int reg = 15; reg >= 1; --reg) r = acc[j][reg] == m ? reg : r;
+      r = acc[j][0] == m ? 0 : r;
+      bd[j] = m; br[j] = r;
+    };
+    static_for<TN>([&](auto J) __attribute__((always_inline)) { rescan(J); });
     for (;;) {
       bool any = false;
       int bsel[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float bd = INFINITY;
-        int br = 0;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          if (acc[j][reg] < bd) { bd = acc[j][reg]; br = reg; }      // strict: the lowest row among equal distances
+        const int brow = bd[j] < INFINITY ? (int)(blk_row0 + (br[j] & 3) + 8 * (br[j] >> 2) + 4 * h) : INT_MAX;
+        const bool pass = bd[j] < tau_d[j] || (bd[j] == tau_d[j] && brow < tau_r[j]);
         Cand c;
-        c.d = bd;
-        c.r = bd < INFINITY ? (int)(blk_row0 + (br & 3) + 8 * (br >> 2) + 4 * h) : INT_MAX;
-        const bool pass = cand_less(c, tau[j]);
-        slots[((wn * TN + j) * 32 + r32) * NSLOT + wm * 2 + h] = pass ? c : inf;
-        bsel[j] = pass ? br : -1;
+        c.d = pass ? bd[j] : INFINITY;
+        c.r = pass ? brow : INT_MAX;
+        slots[((wn * TN + j) * 32 + r32) * NSLOT + wm * 2 + h] = c;
+        bsel[j] = pass ? br[j] : -1;
         any |= pass;
       }
+#ifdef MRAG_TOPK_DIAG_STATS
+      ++dbg_rounds;
+#endif
       if (!__syncthreads_or(any ? 1 : 0)) break;
       if (tid < QB) {                                 // the owner of query tid: at most NSLOT insertions into its sorted list
-        Cand* L = lists + tid * LSTR;
+        // the list and the round's candidates come into REGISTERS in two bursts of independent LDS reads; every insertion is then a fixed chain of
+        // compare / select steps (the list keeps its best 16: entries k .. 15 are harmless extras, the threshold is entry k - 1).  A pointer-chasing
+        // insertion in LDS cost ~20 k cycles per round -- two dependent LDS accesses per shifted entry -- and the rounds are workgroup-synchronous.
+        Cand* Lp = lists + tid * LSTR;
+        float Ld[16], cd[NSLOT];
+        int Lr[16], cr[NSLOT];
+        bool anyc = false;
+#pragma unroll
         for (int si = 0; si < NSLOT; ++si) {
           const Cand c = slots[tid * NSLOT + si];
-          if (cand_less(c, L[p.k - 1])) {
-            int pos = p.k - 1;
-            while (pos > 0 && cand_less(c, L[pos - 1])) { L[pos] = L[pos - 1]; --pos; }
-            L[pos] = c;
-          }
+          cd[si] = c.d; cr[si] = c.r;
+          anyc |= c.r != INT_MAX;
         }
-        taus[tid] = L[p.k - 1];
+        if (anyc) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const Cand l = Lp[e]; Ld[e] = l.d; Lr[e] = l.r; }
+          auto less = [](float ad, int ar, float bd2, int br2) { return ad < bd2 || (ad == bd2 && ar < br2); };
+          // one insertion per loop trip, best candidate first: the trip count is the LARGEST number of candidates any owner of the wave holds this round
+          // (1-2 once the lists are warm), not NSLOT -- a wave pays every trip of its busiest lane with all 64 lanes
+          for (;;) {
+            float md = INFINITY;
+            int mr = INT_MAX, ms = -1;
+#pragma unroll
+            for (int si = 0; si < NSLOT; ++si)
+              if (less(cd[si], cr[si], md, mr)) { md = cd[si]; mr = cr[si]; ms = si; }
+            if (mr == INT_MAX) break;
+#pragma unroll
+            for (int si = 0; si < NSLOT; ++si)
+              if (si == ms) { cd[si] = INFINITY; cr[si] = INT_MAX; }
+#pragma unroll
+            for (int e = 15; e >= 1; --e) {
+              const bool before_prev = less(md, mr, Ld[e - 1], Lr[e - 1]), before_this = less(md, mr, Ld[e], Lr[e]);
+              Ld[e] = before_prev ? Ld[e - 1] : (before_this ? md : Ld[e]);
+              Lr[e] = before_prev ? Lr[e - 1] : (before_this ? mr : Lr[e]);
+            }
+            const bool b0 = less(md, mr, Ld[0], Lr[0]);
+            Ld[0] = b0 ? md : Ld[0];
+            Lr[0] = b0 ? mr : Lr[0];
+          }
+          float thd = Ld[0];
+          int thr = Lr[0];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            Cand l; l.d = Ld[e]; l.r = Lr[e];
+            Lp[e] = l;
+            if (e == p.k - 1) { thd = Ld[e]; thr = Lr[e]; }
+          }
+          Cand th; th.d = thd; th.r = thr;
+          taus[tid] = th;
+          if (thr != INT_MAX && q0 + tid < p.nq) atomicMin(p.tau_g + q0 + tid, float_key(thd));   // a full list: publish its k-th distance
+        }
       }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        tau[j] = taus[(wn * TN + j) * 32 + r32];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          if (reg == bsel[j]) acc[j][reg] = INFINITY;                 // consumed
+        const Cand tq = taus[(wn * TN + j) * 32 + r32];
+        tau_d[j] = tq.d; tau_r[j] = tq.r;
       }
+      static_for<TN>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        if (__any(bsel[j] >= 0)) {                    // (wave-uniform: most tiles of most rounds have nothing to consume)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) acc[j][reg] = reg == bsel[j] ? INFINITY : acc[j][reg];   // consumed
+          rescan(J);
+        }
+      });
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#ifdef MRAG_TOPK_DIAG_STATS
+    MRAG_TSTAMP(dbg_b);
+    dbg_sel += dbg_b - dbg_a;
+#endif
   }
+#ifdef MRAG_TOPK_DIAG_STATS
+  if (tid == 0) {
+    MRAG_TSTAMP(dbg_b);
+    atomicAdd(&g_topk_dbg[0], dbg_rounds); atomicAdd(&g_topk_dbg[1], dbg_sel); atomicAdd(&g_topk_dbg[2], dbg_b - dbg_t0); atomicAdd(&g_topk_dbg[3], (unsigned long long)nblk);
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last NST - 1 (redundant) slabs must have landed before the workgroup gives its LDS back
   __syncthreads();
   if (tid < QB && q0 + tid < p.nq) {
     Cand* out = p.lists + ((long long)(q0 + tid) * p.nparts + part) * 16;
@@ -571,30 +733,36 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
   }
 }
 
-// the fan-out plan: which configuration, how many parts (workgroups along the table), rows per part
-struct MfmaPlan { bool wide_q; int TN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
+// the fan-out plan: queries per workgroup (32 TN), parts (workgroups along the table), rows per part
+struct MfmaPlan { int TN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
 inline MfmaPlan plan_mfma(long long n_rows, int nq) {
   MfmaPlan pl;
   const int qtiles = (nq + 31) / 32;
-  pl.wide_q = n_rows < 65536 && qtiles >= 4;                           // small table, many queries: the waves split the queries
-  if (pl.wide_q) { pl.TN = qtiles >= 8 ? 2 : 1; pl.QB = 128 * pl.TN; pl.RB = 32; }
-  else { pl.TN = qtiles >= 8 ? 8 : qtiles >= 4 ? 4 : qtiles >= 2 ? 2 : 1; pl.QB = 32 * pl.TN; pl.RB = 128; }
-  const int WM = pl.wide_q ? 1 : 4;
-  pl.lds = 2 * (size_t)(pl.RB + pl.QB) * 128 + (size_t)pl.QB * (17 + 2 * WM + 1) * sizeof(Cand) + 4 * 32 * sizeof(float);
-  pl.gy = (nq + pl.QB - 1) / pl.QB;
+  pl.RB = 128;
   const long long blocks = (n_rows + pl.RB - 1) / pl.RB;
+  // the widest query tile that still gives >= 256 workgroups (row blocks x query blocks); a large table takes TN = 8 whenever the batch has 8 tiles
+  pl.TN = 1;
+  for (int t = 8; t >= 1; t >>= 1)
+    if (t <= qtiles && (t == 1 || blocks * ((qtiles + t - 1) / t) >= 256)) { pl.TN = t; break; }
+  pl.QB = 32 * pl.TN;
+  pl.lds = (size_t)mfma_stages(pl.TN) * (pl.RB + pl.QB) * 128 + (size_t)pl.QB * (17 + 8 + 1) * sizeof(Cand) + 4 * 32 * sizeof(float);
+  pl.gy = (nq + pl.QB - 1) / pl.QB;
   int per_cu = (int)((160 * 1024) / pl.lds);
   per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;                  // (160-208 VGPRs at TN <= 2: two workgroups per CU)
-  long long parts = (256LL * per_cu) / pl.gy;
+  long long parts = (256LL * per_cu + pl.gy - 1) / pl.gy;
   parts = parts < 1 ? 1 : parts > blocks ? blocks : parts;
   const long long bpp = (blocks + parts - 1) / parts;
   pl.parts = (int)((blocks + bpp - 1) / bpp);
   pl.rows_per_part = (int)(bpp * pl.RB);
-  pl.bytes = ((size_t)nq * sizeof(float) + 255) / 256 * 256 + (size_t)nq * pl.parts * 16 * sizeof(Cand);
+  pl.bytes = 2 * (((size_t)nq * sizeof(float) + 255) / 256 * 256) + (size_t)nq * pl.parts * 16 * sizeof(Cand);   // |q|^2, shared thresholds, per-workgroup lists
   return pl;
 }
 
 inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 && dim % 4 == 0; }
+// where `order = 0` (automatic) takes the fan-out form: a table of 32 768 rows or more.  Measured on MI355X (tools/microbench.py topk, k = 12, D = 768):
+// 10^6 rows x 256 queries 4.2 ms against 17.2 ms through the scan kernel, 10^6 x 64 1.6 against 5.0 ms; at 10^4 rows x 256 queries the two are equal
+// (0.27 ms: every workgroup's lists start cold, and the ~6 workgroup-synchronous selection rounds of a first row block cost as much as its MFMAs)
+inline bool mfma_auto(long long n_rows, int nq, int k, int dim) { return mfma_applies(nq, k, dim) && n_rows >= 32768; }
 
 inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
 
@@ -659,29 +827,29 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   hipStream_t s = (hipStream_t)stream;
   if (order < 0 || order > 2) return MRAG_EINVAL;
   if (order == 2 && !mfma_applies(n_queries, k, dim)) return MRAG_ENOTSUP;
-  if (order == 2 || (order == 0 && mfma_applies(n_queries, k, dim))) {
+  if (order == 2 || (order == 0 && mfma_auto(n_rows, n_queries, k, dim))) {
     // ---- the fan-out form: one fp32 MFMA pass over the table per 256 queries
     const MfmaPlan pl = plan_mfma(n_rows, n_queries);
     TopkMP m{};
     m.db = db; m.group = p.group; m.q = queries; m.excl = exclude; m.n_rows = n_rows; m.dim = dim; m.nq = n_queries; m.k = k;
     m.nparts = pl.parts; m.rows_per_part = pl.rows_per_part; m.nslab = (dim + 31) / 32;
+    const size_t qbytes = ((size_t)n_queries * sizeof(float) + 255) / 256 * 256;
     float* qq = (float*)((char*)workspace + kTicketBytes);
     m.qq = qq;
-    m.lists = (Cand*)((char*)workspace + kTicketBytes + ((size_t)n_queries * sizeof(float) + 255) / 256 * 256);
-    if (metric == 0) {
-      MRAG_LAUNCH(topk_qq_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, queries, qq, n_queries, dim);
-      MRAG_LAUNCH_CHECK();
-    }
+    m.tau_g = (unsigned*)((char*)workspace + kTicketBytes + qbytes);
+    m.lists = (Cand*)((char*)workspace + kTicketBytes + 2 * qbytes);
+    MRAG_LAUNCH(topk_qq_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, queries, qq, m.tau_g, n_queries, dim, metric == 0 ? 1 : 0);
+    MRAG_LAUNCH_CHECK();
     const dim3 mgrid(pl.parts, pl.gy), block256(256);
-#define MRAG_TOPK_MFMA(M, W, T)                                                                                        \
-    if (metric == M && (pl.wide_q ? 1 : 4) == W && pl.TN == T) {                                                       \
-      auto kfn = topk_mfma_kernel<M, W, T>;                                                                             \
+#define MRAG_TOPK_MFMA(M, T)                                                                                           \
+    if (metric == M && pl.TN == T) {                                                                                   \
+      auto kfn = topk_mfma_kernel<M, T>;                                                                                \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
       if (e != hipSuccess) return (int)e;                                                                              \
       MRAG_LAUNCH(kfn, mgrid, block256, pl.lds, s, m);                                                                 \
     }
-    MRAG_TOPK_MFMA(0, 4, 1) MRAG_TOPK_MFMA(0, 4, 2) MRAG_TOPK_MFMA(0, 4, 4) MRAG_TOPK_MFMA(0, 4, 8) MRAG_TOPK_MFMA(0, 1, 1) MRAG_TOPK_MFMA(0, 1, 2)
-    MRAG_TOPK_MFMA(1, 4, 1) MRAG_TOPK_MFMA(1, 4, 2) MRAG_TOPK_MFMA(1, 4, 4) MRAG_TOPK_MFMA(1, 4, 8) MRAG_TOPK_MFMA(1, 1, 1) MRAG_TOPK_MFMA(1, 1, 2)
+    MRAG_TOPK_MFMA(0, 1) MRAG_TOPK_MFMA(0, 2) MRAG_TOPK_MFMA(0, 4) MRAG_TOPK_MFMA(0, 8)
+    MRAG_TOPK_MFMA(1, 1) MRAG_TOPK_MFMA(1, 2) MRAG_TOPK_MFMA(1, 4) MRAG_TOPK_MFMA(1, 8)
 #undef MRAG_TOPK_MFMA
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_TOPK_MFMA);

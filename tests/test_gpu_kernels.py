@@ -677,8 +677,9 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
     db, q = _unit(rng, N, D), _unit(rng, Q, D)
     group = (np.arange(N) // 2).astype(np.int32)
     excl = group[rng.integers(0, N, Q)].astype(np.int32)
-    # the 16-chain scan kernel (`order="chain16"`: every batch size) and, where it applies (>= 16 queries, k <= 16), the fan-out kernel that "auto" picks
-    for order, mode in (("chain16", "f32chain"),) + ((("auto", "f32mfma"), ("mfma", "f32mfma")) if Q >= 16 and k <= 16 else (("auto", "f32chain"),)):
+    # the 16-chain scan kernel (`order="chain16"`: every batch size; also what "auto" picks below 32 768 rows) and, where it applies (>= 16 queries, k <= 16),
+    # the fan-out kernel
+    for order, mode in (("chain16", "f32chain"), ("auto", "f32chain")) + ((("mfma", "f32mfma"),) if Q >= 16 and k <= 16 else ()):
         want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode=mode)
         with ops.dispatched() as d:
             rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
@@ -698,7 +699,7 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
 def test_topk_filter_order_bit_exact(hip, metric, Q):
     """lancedb's post-filter (`where(..., prefilter=False)`: the k nearest first, then the filter) and the pre-filter against the C oracle in the
     matching mode, bit for bit, on a database with 6 clips per video where the two orders give different lists; Q = 1 / 3 run the fused
-    single-launch form, 5 the query-tile scan + merge kernel, 40 the fan-out (fp32 MFMA) kernel"""
+    single-launch form, 5 the query-tile scan + merge kernel, 40 the 16-query tiles (the fan-out kernel's filter orders: test_topk_fanout_bit_exact)"""
     from motionrag_amd import ops
     from oracle import topk_ref
     from test_oracle_golden import multi_clip_db
@@ -711,7 +712,7 @@ def test_topk_filter_order_bit_exact(hip, metric, Q):
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, own))
     lists = {}
     for post in (False, True):
-        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32mfma" if Q >= 16 else "f32chain", postfilter=post)   # Q = 40: the fan-out kernel ("auto")
+        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32chain", postfilter=post)
         rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post)
         np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
         np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
@@ -758,13 +759,13 @@ def test_topk_baseline_size(hip):
     rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
                           group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
     rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
-    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32mfma")          # 256 queries: the fan-out kernel, ONE pass over the table
+    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")         # 10 k rows: "auto" = the scan kernel, 16 passes of 16 queries
     np.testing.assert_array_equal(rows, want_r)
     np.testing.assert_array_equal(dist, want_d.astype(np.float32))
     assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
     rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
-                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order="chain16")   # the scan kernel: 16 passes of 16 queries
-    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")
+                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order="mfma")      # the fan-out kernel: ONE pass over the table
+    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32mfma")
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 
@@ -793,7 +794,11 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
         np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
         np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
     want_r, want_d = topk_ref.topk(db, q, k, metric, mode="f32mfma")
-    rows, dist = ops.topk(dbd, qd, k, metric=metric, order="mfma")
+    with ops.dispatched() as d:
+        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out kernel from 32 768 rows up, the scan kernel below
+    assert ("TOPK_MFMA" in d.counts) == (N >= 32768), d.counts
+    if N < 32768:
+        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="mfma")
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 
@@ -923,9 +928,9 @@ def test_topk_baseline_size_ranks_equal_float64_oracle(hip):
     group = np.arange(10000, dtype=np.int32)
     excl = rng.integers(0, 10000, 256).astype(np.int32)
     q[:64] = db[excl[:64]] + 0.01 * q[:64]
-    for metric in ("l2", "dot"):
+    for metric, order in (("l2", "auto"), ("dot", "auto"), ("l2", "mfma"), ("dot", "mfma")):          # both summation orders rank like the float64 oracle
         rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric=metric,
-                              group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
+                              group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order=order)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
         want_r, want_d = topk_ref.topk(db, q, 13, metric, group, excl, mode="f64")          # one more: the gap below rank 12 matters too
         gap = np.diff(want_d, axis=1)                                                             # [Q, 12] float64 gaps between neighbours

@@ -62,10 +62,11 @@ enum mrag_kernel_id {
   MRAG_K_GEMM_256x128,
   MRAG_K_GEMM_128x128,         /* the small-problem tile (< 192 tiles of 256x256)                                           */
   MRAG_K_GEMM_STREAMK_TAIL,
+  MRAG_K_GEMM_192x256,         /* 8-wave 192x256 tile: long-K problems whose 256-row tile grid leaves the last round mostly empty */
   MRAG_K_CONV3_W4,             /* 3x3 (and causal 3x3x3) implicit-GEMM convolution on the persistent four-wave kernel       */
-  MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128,
+  MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128, MRAG_K_CONV3_192x256,
   MRAG_K_CONVT_W4,             /* (3,1,1) temporal convolution on the persistent four-wave kernel                           */
-  MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_128x128,
+  MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_128x128, MRAG_K_CONVT_192x256,
   MRAG_K_ATTN16,               /* attn16_kernel, whole query tiles                                                          */
   MRAG_K_ATTN16_KSPLIT,        /* attn16_kernel with the key-split ragged tail (+ MRAG_K_ATTN_COMBINE)                      */
   MRAG_K_ATTN_FLASH,           /* attn_fwd_kernel (32x32x16): masked / biased / short launches                              */

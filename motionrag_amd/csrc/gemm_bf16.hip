@@ -826,6 +826,16 @@ inline bool wide_rounds_pay(long long M, long long N, int tuning = 0) {
   if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
   return round_cost(M, N, 320) * 100 < round_cost(M, N, 256) * 85;
 }
+// DynamiCrafter's level 2 (M = 18 432 rows, N = 1 280) is 72 x 5 = 360 tiles of 256x256 -- two rounds, the second 41 % full -- and 288 of 256x320 (two rounds
+// of larger tiles: worse).  A 192-row tile (8 waves of 96 x 64; the generic K loop and the direct epilogue, ~8 % behind the pipelined 256x256 loop per FLOP)
+// makes it 96 x 5 = 480 tiles: two nearly full rounds of tiles 3/4 the size.  Taken for LONG reductions only (convolutions, K >= 2 560 linears), where the
+// epilogue's 8-byte stores are noise.
+inline bool short_rows_pay(long long M, long long N, int tuning = 0) {
+  if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
+  const long long t192 = ((M + 191) / 192) * ((N + 255) / 256), t256 = ((M + 255) / 256) * ((N + 255) / 256);
+  const long long c192 = ((t192 + 255) / 256) * 192 * 108, c256 = ((t256 + 255) / 256) * 256 * 100;     // rounds x rows per tile x per-FLOP cost
+  return c192 * 100 < c256 * 90 && round_cost(M, N, 320) * 100 >= round_cost(M, N, 256) * 85;
+}
 
 // the VAEs' finest levels are 128 channels wide: a 256-wide tile grid computes as many masked columns as real ones there
 inline bool narrow_n_pays(long long N) {
@@ -1415,10 +1425,10 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
 #undef MRAG_GEMM_CASE
   MRAG_LAUNCH_CHECK();
   {
-    constexpr int tile = (BM == 256 && BN == 320) ? 1 : (BM == 256 && BN == 128) ? 2 : (BM == 128 && BN == 128) ? 3 : 0;   // 0: 256x256 (8 or 16 waves)
-    constexpr int ids[3][4] = {{MRAG_K_GEMM_256x256, MRAG_K_GEMM_256x320, MRAG_K_GEMM_256x128, MRAG_K_GEMM_128x128},
-                               {MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128},
-                               {MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_256x256, MRAG_K_CONVT_128x128}};
+    constexpr int tile = (BM == 256 && BN == 320) ? 1 : (BM == 256 && BN == 128) ? 2 : (BM == 128 && BN == 128) ? 3 : (BM == 192) ? 4 : 0;   // 0: 256x256 (8 or 16 waves)
+    constexpr int ids[3][5] = {{MRAG_K_GEMM_256x256, MRAG_K_GEMM_256x320, MRAG_K_GEMM_256x128, MRAG_K_GEMM_128x128, MRAG_K_GEMM_192x256},
+                               {MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128, MRAG_K_CONV3_192x256},
+                               {MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_256x256, MRAG_K_CONVT_128x128, MRAG_K_CONVT_192x256}};
     MRAG_COUNT(ids[CONV][tile]);
   }
   if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
@@ -1504,6 +1514,9 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
       a->epilogue != MRAG_EPI_QKNORM_ROPE)
     return launch_cfg<2, 4, 8, 5>(s, p, epi);
+  if (t256 >= 192 && a->K >= 2560 && !wide_n_pays(a->N, a->tuning) && short_rows_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) &&
+      (a->epilogue == MRAG_EPI_NONE || a->epilogue == MRAG_EPI_RESID))
+    return launch_cfg<2, 4, 6, 4>(s, p, epi);                                                        // 192x256 tile (see short_rows_pay)
   if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
        epi == EPI_GEGLU_TANH) &&
@@ -1567,6 +1580,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
     const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (t256 >= 192 && (wide_n_pays(p.N) || wide_rounds_pay(p.M, p.N))) return launch_cfg<2, 4, 8, 5, 1>(s, p, a->epilogue);
     if (t256 >= 192 && narrow_n_pays(p.N)) return launch_cfg<4, 2, 4, 4, 1>(s, p, a->epilogue);   // 256x128 tile, 8 waves of 64x64
+    if (t256 >= 192 && short_rows_pay(p.M, p.N)) return launch_cfg<2, 4, 6, 4, 1>(s, p, a->epilogue);   // 192x256 tile
     if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 1>(s, p, a->epilogue);
     return launch_cfg<2, 2, 4, 4, 1>(s, p, a->epilogue);
   }
@@ -1575,6 +1589,7 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
   p.M = (long long)a->N * a->H * a->Wd; p.K = 3LL * a->Cin; p.ldw = p.K;
   const long long t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (t256 >= 192 && (wide_n_pays(p.N) || wide_rounds_pay(p.M, p.N))) return launch_cfg<2, 4, 8, 5, 2>(s, p, a->epilogue);
+  if (t256 >= 192 && short_rows_pay(p.M, p.N)) return launch_cfg<2, 4, 6, 4, 2>(s, p, a->epilogue);      // 192x256 tile
   if (t256 >= 192) return launch_cfg<2, 4, 8, 4, 2>(s, p, a->epilogue);
   return launch_cfg<2, 2, 4, 4, 2>(s, p, a->epilogue);
 }

@@ -9,7 +9,9 @@ the persistent four-wave GEMM (`gemm_w4_kernel`, incl. the fused qk-LayerNorm + 
     python -m oracle.gen_golden_fullwidth            # writes tests/golden/fullwidth_{cog,svd,dc}.npz
 
   cog  `APAdapterCogVideoXAttnProcessor2_0.__call__`   /root/reference/src/projects/condition/attn_processor.py:176-283
-       D = 3072, 48 heads x 64, text 226 + video (2, 30, 45) = 2 926 rows, B = 2, rope on, motion tokens [1, 25, 1024] (the `(b r)` repeat)
+       D = 3072, 48 heads x 64, text 226 + video (3, 30, 45) = 4 276 rows, B = 2, rope on, motion tokens [1, 25, 1024] (the `(b r)` repeat).  (Three latent
+       frames, not two: at 2 x 2 926 rows the to_out projection is 276 tiles of 256x256 -- two rounds on 256 CUs, the second 8 % full -- and the library then
+       takes the 320-wide 8-wave tile; at 2 x 4 276 rows it runs on the persistent four-wave kernel like the 35 552-row benchmark shape.)
   svd  `APAdapterAttnProcessor2_0.__call__`            .../attn_processor.py:18-141
        C = 320, 5 heads, cross 1024, hidden [2 F = 4, 72 x 128 = 9 216, 320] (the real level-0 resolution), motion tokens [2, 25, 1024]
   dc   `SpatialTransformer` C = 320 / 5 heads / context 1024 (text 77 + image 16 + action 25 tokens), `TemporalTransformer`, `ResBlock` 320 -> 640
@@ -68,7 +70,7 @@ def sample_rows(n: int, count: int, edges=(0, 1, 127, 128, 191, 192, 255, 256, 2
     return np.array(sorted(base | set(spread.tolist())), dtype=np.int64)
 
 
-COG = dict(D=3072, H=48, ip_dim=1024, text_len=226, thw=(2, 30, 45), B=2, attn_seed=701, proc_seed=702, input_seed=703, std=0.02)
+COG = dict(D=3072, H=48, ip_dim=1024, text_len=226, thw=(3, 30, 45), B=2, attn_seed=701, proc_seed=702, input_seed=703, std=0.02)
 SVD = dict(C=320, H=5, cross_dim=1024, F=2, hw=(72, 128), attn_seed=711, proc_seed=712, input_seed=713, std=0.03)
 DC = dict(C=320, heads=5, ctx_dim=1024, B=2, T=5, hw=(48, 64), st_seed=721, tt_seed=722, rb_seed=723, input_seed=724, emb_dim=1280, out_ch=640)
 

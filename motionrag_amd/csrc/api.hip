@@ -23,7 +23,7 @@ extern "C" int mrag_dispatch_counts(uint64_t* out_host, int32_t n) {
 
 extern "C" const char* mrag_dispatch_name(int32_t id) {
   static const char* const names[MRAG_K_COUNT] = {
-      "GEMM_W4", "GEMM_W4_QKNORM_ROPE", "GEMM_W4_GEGLU", "GEMM_256x256", "GEMM_256x320", "GEMM_256x128", "GEMM_128x128", "GEMM_STREAMK_TAIL", "GEMM_192x256",
+      "GEMM_W4", "GEMM_W4_QKNORM_ROPE", "GEMM_W4_GEGLU", "GEMM_256x256", "GEMM_256x320", "GEMM_256x128", "GEMM_128x128", "GEMM_STREAMK_TAIL", "GEMM_N320K320", "GEMM_192x256",
       "CONV3_W4", "CONV3_256x256", "CONV3_256x320", "CONV3_256x128", "CONV3_128x128", "CONV3_192x256",
       "CONVT_W4", "CONVT_256x256", "CONVT_256x320", "CONVT_128x128", "CONVT_192x256",
       "ATTN16", "ATTN16_KSPLIT", "ATTN_FLASH", "ATTN_FLASH_KSPLIT", "ATTN_COMBINE", "ATTN_TINY", "ATTN_SMALL", "ATTN_FP8", "IP_ATTN_FOLDED",

@@ -828,8 +828,9 @@ inline bool wide_rounds_pay(long long M, long long N, int tuning = 0) {
 }
 // DynamiCrafter's level 2 (M = 18 432 rows, N = 1 280) is 72 x 5 = 360 tiles of 256x256 -- two rounds, the second 41 % full -- and 288 of 256x320 (two rounds
 // of larger tiles: worse).  A 192-row tile (8 waves of 96 x 64; the generic K loop and the direct epilogue, ~8 % behind the pipelined 256x256 loop per FLOP)
-// makes it 96 x 5 = 480 tiles: two nearly full rounds of tiles 3/4 the size.  Taken for LONG reductions only (convolutions, K >= 2 560 linears), where the
-// epilogue's 8-byte stores are noise.
+// makes it 96 x 5 = 480 tiles: two nearly full rounds of tiles 3/4 the size.  Taken by the convolutions only (K = 3 840 .. 23 040: 626 -> 537 us at K = 11 520,
+// 1 291 -> 1 000 us at K = 23 040, the (3,1,1) one 227 -> 178 us); a K = 5 120 LINEAR measured slower on it (259 vs 248 us on the persistent kernel: the
+// direct epilogue's 8-byte stores), so linears keep their kernels.
 inline bool short_rows_pay(long long M, long long N, int tuning = 0) {
   if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
   const long long t192 = ((M + 191) / 192) * ((N + 255) / 256), t256 = ((M + 255) / 256) * ((N + 255) / 256);
@@ -1377,6 +1378,139 @@ inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
   return MRAG_OK;
 }
 
+
+// ---- N = 320, K = 320: the UNets' level-0 projections (to_q / to_out / proj_in / proj_out of the 320-channel transformers: 35-50 launches per CFG step over
+// 258 048 / 294 912 pixel rows).  0.06 TFLOP and 0.5 GB each: HBM-bound -- but a 256x320 tile re-stages the whole 200 KB weight per tile and runs load, five
+// short K-tiles and store strictly one after the other with one workgroup per CU: 204-245 us = 2.4 TB/s (tools/unet_op_table.py).  Here the weight never
+// moves: ten waves hold W as MFMA operands in REGISTERS (wave w owns output columns 32 w .. 32 w + 31: 2 column tiles x 10 k-steps = 80 VGPRs), persistent
+// workgroups stream 64-row activation tiles through a two-stage LDS-DMA ring (40 KB per stage, the K-tile-major swizzled image of the other kernels), and the
+// outputs leave through an LDS staging tile as whole 640-byte rows with the residual added in the row layout.  Same K order and rounding points as the other
+// tiles: bit-equal results.
+constexpr int SK320_ROWS = 64, SK320_STAGE = SK320_ROWS * 640, SK320_CPITCH = 656;   // C staging: 64 rows x 640 B, pitch 656 B (8-byte writes of 16 rows spread over the banks)
+
+template <int EPI>
+__global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* cst = smem + 2 * SK320_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, swz = lane & 7;
+  const int n0 = wave * 32;
+  // the wave's weight fragments: W[n0 + 16 j + fr][32 ks + 8 fq .. + 7]
+  bf16x8 wf[2][10];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) wf[j][ks] = *(const bf16x8*)(p.W + (long long)(n0 + 16 * j + fr) * p.ldw + 32 * ks + 8 * fq);
+  u32x2 bias[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias[j] = p.bias ? *(const u32x2*)(p.bias + n0 + 16 * j + 4 * fq) : u32x2{0u, 0u};
+  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS), G = (int)gridDim.x;
+  // DMA: piece q = wave + 10 i (i < 4) of a tile: K-tile q / 8, rows 8 (q % 8) .. + 7; lane -> row (lane >> 3), source chunk (lane & 7) ^ row
+  auto issue = [&](const int tile, const int stage) {
+    const long long m0 = (long long)tile * SK320_ROWS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = wave + 10 * i, kt = q >> 3;
+      long long row = m0 + 8 * (q & 7) + (lane >> 3);
+      row = row < p.M ? row : p.M - 1;                      // tail rows re-read the last valid row; their stores are masked
+      glds16(p.A + row * p.lda + kt * 64 + (((lane & 7) ^ (lane >> 3)) * 8), smem + stage * SK320_STAGE + q * 1024);
+    }
+  };
+  int tile = (int)blockIdx.x;
+  if (tile < tiles) issue(tile, 0);
+  for (int it = 0; tile < tiles; ++it, tile += G) {
+    const int stage = it & 1;
+    const bool more = tile + G < tiles;
+    if (more) {
+      issue(tile + G, stage ^ 1);                           // (the other stage was released by the barrier that closed the previous iteration)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this tile's four pieces have landed, the next tile's four are in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const char* st = smem + stage * SK320_STAGE;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+      const int off = (ks >> 1) * 8192 + (((fq + 4 * (ks & 1)) ^ swz) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {                      // two row tiles at a time: 8 fragment registers live (168 VGPRs at three waves per SIMD)
+        const bf16x8 a0 = *(const bf16x8*)(st + off + (i * 16 + fr) * 128), a1 = *(const bf16x8*)(st + off + ((i + 1) * 16 + fr) * 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], a0, acc[i][j], 0, 0, 0);
+          acc[i + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], a1, acc[i + 1][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                    // (keeps hipcc from hoisting the next k-steps' fragment reads: they would spill)
+    }
+    // ---- epilogue: bias (+ scale), ONE rounding to bf16 in the accumulator layout, staged to rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        v[0] += __uint_as_float(bias[j][0] << 16); v[1] += __uint_as_float(bias[j][0] & 0xffff0000u);
+        v[2] += __uint_as_float(bias[j][1] << 16); v[3] += __uint_as_float(bias[j][1] & 0xffff0000u);
+        if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+        }
+        *(u32x2*)(cst + (i * 16 + fr) * SK320_CPITCH + (n0 + 16 * j + 4 * fq) * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      }
+    __syncthreads();
+    const long long m0 = (long long)tile * SK320_ROWS;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {                           // 64 rows x 40 sixteen-byte chunks = 2 560 = 4 x 640 threads: whole 640-byte rows per 40 lanes (not unrolled: the 80 weight registers stay live)
+      const int idx = tid + 640 * u, row = idx / 40, ch = idx - row * 40;
+      const long long m = m0 + row;
+      u32x4 val = *(const u32x4*)(cst + row * SK320_CPITCH + ch * 16);
+      if (m < p.M) {
+        if constexpr (EPI == MRAG_EPI_RESID) {
+          const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + ch * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(rr[e] << 16);
+            const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u);
+            val[e] = pack_bf2(lo, hi);
+          }
+        }
+        *(u32x4*)(p.C + m * p.ldc + ch * 8) = val;
+      }
+    }
+    __syncthreads();                                        // the staging tile and this stage are free again
+  }
+}
+
+inline bool skinny320_applies(const mrag_gemm_args* a) {
+  return a->N == 320 && a->K == 320 && a->M >= 16384 && (a->epilogue == MRAG_EPI_NONE || a->epilogue == MRAG_EPI_RESID) && !(a->tuning & MRAG_GEMM_TUNE_NO_WIDE) &&
+         a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 7) == 0);
+}
+
+inline int launch_skinny320(hipStream_t s, const GemmP& p, int epi) {
+  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS);
+  const dim3 grid((unsigned)(tiles < SK_CUS ? tiles : SK_CUS)), block(640);
+  const size_t lds = 2 * SK320_STAGE + SK320_ROWS * SK320_CPITCH;
+  if (epi == MRAG_EPI_RESID) {
+    auto kfn = gemm_n320k320_kernel<MRAG_EPI_RESID>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+  } else {
+    auto kfn = gemm_n320k320_kernel<MRAG_EPI_NONE>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+  }
+  MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_GEMM_N320K320);
+  return MRAG_OK;
+}
+
 template <int WM, int WN, int TM, int TN, int CONV = 0>
 int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullptr) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1510,13 +1644,11 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
+  if (skinny320_applies(a)) return launch_skinny320(s, p, epi);      // N = K = 320: the weight in registers, activations streamed (gemm_n320k320_kernel)
   // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
   if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
       a->epilogue != MRAG_EPI_QKNORM_ROPE)
     return launch_cfg<2, 4, 8, 5>(s, p, epi);
-  if (t256 >= 192 && a->K >= 2560 && !wide_n_pays(a->N, a->tuning) && short_rows_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) &&
-      (a->epilogue == MRAG_EPI_NONE || a->epilogue == MRAG_EPI_RESID))
-    return launch_cfg<2, 4, 6, 4>(s, p, epi);                                                        // 192x256 tile (see short_rows_pay)
   if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
        epi == EPI_GEGLU_TANH) &&

@@ -803,6 +803,43 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 
 
+@pytest.mark.parametrize("M", [16384, 40000, 36864 + 37])
+def test_gemm_n320_k320_weight_in_registers(hip, M):
+    """N = K = 320 from 16 384 rows up (the UNets' level-0 projections): gemm_n320k320_kernel -- the weight as MFMA operands in registers, 64-row activation
+    tiles streamed, rows leaving whole through an LDS staging tile.  Against torch fp32, bit-equal to the 256x256 / 256x320 tiles (same K order and rounding
+    points), with bias, with the residual epilogue and its acc_scale, a ragged last tile, and strided input / output / residual views (column slices)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x, w, b, r = bf(torch.randn(M, 320, generator=g)), bf(torch.randn(320, 320, generator=g) * 0.05), bf(torch.randn(320, generator=g)), bf(torch.randn(M, 320, generator=g))
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    ref = x.float() @ w.float().t()
+    cases = {"plain": dict(), "bias": dict(bias=bd), "resid": dict(bias=bd, epilogue=ops.EPI_RESID, resid=rd), "resid_scaled": dict(epilogue=ops.EPI_RESID, resid=rd, acc_scale=0.25)}
+    outs = {}
+    for name, kw in cases.items():
+        bias = kw.pop("bias", None)
+        with ops.dispatched() as d:
+            outs[name] = ops.linear(xd, wd, bias, **kw)
+        assert d.counts == {"GEMM_N320K320": 1}, (name, d.counts)
+        ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_WIDE
+        try:
+            with ops.dispatched() as d:
+                other = ops.linear(xd, wd, bias, **kw)
+        finally:
+            ops.TUNING["gemm"] = 0
+        assert "GEMM_N320K320" not in d.counts and torch.equal(other, outs[name]), (name, d.counts)
+    close(outs["plain"], ref, scale=1.0)
+    close(outs["bias"], ref + b.float(), scale=1.0)
+    close(outs["resid"], r.float() + (ref + b.float()).to(torch.bfloat16).float(), scale=1.0)
+    close(outs["resid_scaled"], r.float() + (0.25 * ref).to(torch.bfloat16).float(), scale=1.0)
+    # column slices of wider buffers: lda / ldc / ldr > 320
+    xw, ow, rw = torch.zeros(M, 384, dtype=torch.bfloat16, device=DEV), torch.zeros(M, 640, dtype=torch.bfloat16, device=DEV), torch.zeros(M, 328, dtype=torch.bfloat16, device=DEV)
+    xw[:, 64:] = xd; rw[:, 8:] = rd
+    with ops.dispatched() as d:
+        ops.linear(xw[:, 64:], wd, bd, out=ow[:, 320:], epilogue=ops.EPI_RESID, resid=rw[:, 8:])
+    assert d.counts == {"GEMM_N320K320": 1}, d.counts
+    assert torch.equal(ow[:, 320:], outs["resid"]) and ow[:, :320].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128), (30001, 272, 192)])
 def test_gemm_geglu_epilogue(hip, M, inner, K):
     """C = v * gelu_erf(g) with [v | g] = x W^T + b (lvdm attention.py:448-455 / diffusers GEGLU), both tile configurations"""

@@ -62,7 +62,7 @@ enum mrag_kernel_id {
   MRAG_K_GEMM_256x128,
   MRAG_K_GEMM_128x128,         /* the small-problem tile (< 192 tiles of 256x256)                                           */
   MRAG_K_GEMM_STREAMK_TAIL,
-  MRAG_K_GEMM_N320K320,        /* gemm_n320k320_kernel: N = K = 320 with the weight resident in registers (the UNets' level-0 projections) */
+  MRAG_K_GEMM_N320K320,        /* gemm_k320_kernel: K = 320, N = 320 .. 2 560 with a 320-column weight slice resident in registers (the UNets' level-0 linears) */
   MRAG_K_GEMM_192x256,         /* 8-wave 192x256 tile: long-K problems whose 256-row tile grid leaves the last round mostly empty */
   MRAG_K_CONV3_W4,             /* 3x3 (and causal 3x3x3) implicit-GEMM convolution on the persistent four-wave kernel       */
   MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128, MRAG_K_CONV3_192x256,

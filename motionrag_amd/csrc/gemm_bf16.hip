@@ -1379,22 +1379,29 @@ inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
 }
 
 
-// ---- N = 320, K = 320: the UNets' level-0 projections (to_q / to_out / proj_in / proj_out of the 320-channel transformers: 35-50 launches per CFG step over
-// 258 048 / 294 912 pixel rows).  0.06 TFLOP and 0.5 GB each: HBM-bound -- but a 256x320 tile re-stages the whole 200 KB weight per tile and runs load, five
-// short K-tiles and store strictly one after the other with one workgroup per CU: 204-245 us = 2.4 TB/s (tools/unet_op_table.py).  Here the weight never
-// moves: ten waves hold W as MFMA operands in REGISTERS (wave w owns output columns 32 w .. 32 w + 31: 2 column tiles x 10 k-steps = 80 VGPRs), persistent
-// workgroups stream 64-row activation tiles through a two-stage LDS-DMA ring (40 KB per stage, the K-tile-major swizzled image of the other kernels), and the
-// outputs leave through an LDS staging tile as whole 640-byte rows with the residual added in the row layout.  Same K order and rounding points as the other
-// tiles: bit-equal results.
-constexpr int SK320_ROWS = 64, SK320_STAGE = SK320_ROWS * 640, SK320_CPITCH = 656;   // C staging: 64 rows x 640 B, pitch 656 B (8-byte writes of 16 rows spread over the banks)
+// ---- K = 320, N a multiple of 320: the UNets' level-0 linears (to_q / to_out / proj_in / proj_out: N = 320; the fused QKV: N = 960; the GEGLU projection:
+// N = 2 560 -- 75-95 launches per CFG step over 258 048 / 294 912 pixel rows).  0.05-0.5 TFLOP against 0.4-0.9 GB each: memory-bound -- but a 256x320 or
+// 256x256 tile re-stages 160-200 KB of weights per tile and runs load, five short K-tiles and store strictly one after the other with one workgroup per
+// CU: 2.4-2.5 TB/s on the plain shapes, 1.4 TB/s with GEGLU (tools/unet_op_table.py).  Here the weight never moves.  A workgroup owns ONE 320-column slice of
+// W: its ten waves hold it as MFMA operands in REGISTERS (wave w: slice columns 32 w .. 32 w + 31 = 2 column tiles x 10 k-steps = 80 VGPRs) for its
+// lifetime, and streams 64-row activation tiles through a two-stage LDS-DMA ring (40 KB per stage, the K-tile-major swizzled image of the other kernels);
+// the outputs leave through an LDS staging tile as whole rows of the slice, the residual added in the row layout.  N / 320 slices x G persistent
+// workgroups; block id = slice * G + g with G a multiple of 8, so the workgroups that read the SAME activation tiles (equal g) share an XCD's L2 and the
+// activations come from HBM once.  GEGLU: a wave's two column tiles are the value and the gate tile of the same 16 outputs (the 16-row [value | gate]
+// interleave of the other GEGLU epilogues).  Same K order and rounding points as the other tiles: bit-equal results.
+constexpr int SK320_ROWS = 64, SK320_STAGE = SK320_ROWS * 640, SK320_CPITCH = 656;   // C staging: 64 rows x <= 640 B, pitch 656 B (8-byte writes of 16 rows spread over the banks)
 
 template <int EPI>
-__global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
+__global__ __launch_bounds__(640) void gemm_k320_kernel(const GemmP p) {
+  constexpr bool GEGLU = is_geglu<EPI>;
+  constexpr int CW = GEGLU ? 160 : 320, CH = CW / 8;        // columns / 16-byte chunks of a staged output row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* cst = smem + 2 * SK320_STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, swz = lane & 7;
-  const int n0 = wave * 32;
+  const int slices = (int)(p.N / 320), G = (int)gridDim.x / slices;
+  const int slice = (int)blockIdx.x / G, g = (int)blockIdx.x - slice * G;
+  const int n0 = slice * 320 + wave * 32;                   // the wave's first column of W / bias
   // the wave's weight fragments: W[n0 + 16 j + fr][32 ks + 8 fq .. + 7]
   bf16x8 wf[2][10];
 #pragma unroll
@@ -1404,7 +1411,8 @@ __global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
   u32x2 bias[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) bias[j] = p.bias ? *(const u32x2*)(p.bias + n0 + 16 * j + 4 * fq) : u32x2{0u, 0u};
-  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS), G = (int)gridDim.x;
+  const long long c0 = GEGLU ? slice * 160 : slice * 320;   // the slice's first output column
+  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS);
   // DMA: piece q = wave + 10 i (i < 4) of a tile: K-tile q / 8, rows 8 (q % 8) .. + 7; lane -> row (lane >> 3), source chunk (lane & 7) ^ row
   auto issue = [&](const int tile, const int stage) {
     const long long m0 = (long long)tile * SK320_ROWS;
@@ -1416,7 +1424,7 @@ __global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
       glds16(p.A + row * p.lda + kt * 64 + (((lane & 7) ^ (lane >> 3)) * 8), smem + stage * SK320_STAGE + q * 1024);
     }
   };
-  int tile = (int)blockIdx.x;
+  int tile = g;
   if (tile < tiles) issue(tile, 0);
   for (int it = 0; tile < tiles; ++it, tile += G) {
     const int stage = it & 1;
@@ -1438,7 +1446,7 @@ __global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
     for (int ks = 0; ks < 10; ++ks) {
       const int off = (ks >> 1) * 8192 + (((fq + 4 * (ks & 1)) ^ swz) * 16);
 #pragma unroll
-      for (int i = 0; i < 4; i += 2) {                      // two row tiles at a time: 8 fragment registers live (168 VGPRs at three waves per SIMD)
+      for (int i = 0; i < 4; i += 2) {                      // two row tiles at a time: 8 fragment registers live (158 VGPRs at three waves per SIMD)
         const bf16x8 a0 = *(const bf16x8*)(st + off + (i * 16 + fr) * 128), a1 = *(const bf16x8*)(st + off + ((i + 1) * 16 + fr) * 128);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1448,30 +1456,39 @@ __global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
       }
       __builtin_amdgcn_sched_barrier(0);                    // (keeps hipcc from hoisting the next k-steps' fragment reads: they would spill)
     }
-    // ---- epilogue: bias (+ scale), ONE rounding to bf16 in the accumulator layout, staged to rows
+    // ---- epilogue: bias (+ scale | GEGLU), ONE rounding to bf16 in the accumulator layout, staged to rows
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      float v[2][4];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        v[0] += __uint_as_float(bias[j][0] << 16); v[1] += __uint_as_float(bias[j][0] & 0xffff0000u);
-        v[2] += __uint_as_float(bias[j][1] << 16); v[3] += __uint_as_float(bias[j][1] & 0xffff0000u);
-        if constexpr (EPI == MRAG_EPI_RESID) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
-        }
-        *(u32x2*)(cst + (i * 16 + fr) * SK320_CPITCH + (n0 + 16 * j + 4 * fq) * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        v[j][0] = acc[i][j][0] + __uint_as_float(bias[j][0] << 16); v[j][1] = acc[i][j][1] + __uint_as_float(bias[j][0] & 0xffff0000u);
+        v[j][2] = acc[i][j][2] + __uint_as_float(bias[j][1] << 16); v[j][3] = acc[i][j][3] + __uint_as_float(bias[j][1] & 0xffff0000u);
       }
+      if constexpr (GEGLU) {                                // column tile 0: values, tile 1: the gates of the same 16 outputs
+        geglu4<EPI == EPI_GEGLU_TANH>(v[0], v[1]);
+        *(u32x2*)(cst + (i * 16 + fr) * SK320_CPITCH + (wave * 16 + 4 * fq) * 2) = u32x2{pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] *= p.acc_scale;
+          }
+          *(u32x2*)(cst + (i * 16 + fr) * SK320_CPITCH + (wave * 32 + 16 * j + 4 * fq) * 2) = u32x2{pack_bf2(v[j][0], v[j][1]), pack_bf2(v[j][2], v[j][3])};
+        }
+      }
+    }
     __syncthreads();
     const long long m0 = (long long)tile * SK320_ROWS;
 #pragma unroll 1
-    for (int u = 0; u < 4; ++u) {                           // 64 rows x 40 sixteen-byte chunks = 2 560 = 4 x 640 threads: whole 640-byte rows per 40 lanes (not unrolled: the 80 weight registers stay live)
-      const int idx = tid + 640 * u, row = idx / 40, ch = idx - row * 40;
+    for (int idx = tid; idx < SK320_ROWS * CH; idx += 640) {  // whole rows of the slice: CH sixteen-byte chunks per row (not unrolled: the 80 weight registers stay live)
+      const int row = idx / CH, ch = idx - row * CH;
       const long long m = m0 + row;
       u32x4 val = *(const u32x4*)(cst + row * SK320_CPITCH + ch * 16);
       if (m < p.M) {
         if constexpr (EPI == MRAG_EPI_RESID) {
-          const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + ch * 8);
+          const u32x4 rr = *(const u32x4*)(p.resid + m * p.ldr + c0 + ch * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(rr[e] << 16);
@@ -1479,33 +1496,42 @@ __global__ __launch_bounds__(640) void gemm_n320k320_kernel(const GemmP p) {
             val[e] = pack_bf2(lo, hi);
           }
         }
-        *(u32x4*)(p.C + m * p.ldc + ch * 8) = val;
+        *(u32x4*)(p.C + m * p.ldc + c0 + ch * 8) = val;
       }
     }
     __syncthreads();                                        // the staging tile and this stage are free again
   }
 }
 
-inline bool skinny320_applies(const mrag_gemm_args* a) {
-  return a->N == 320 && a->K == 320 && a->M >= 16384 && (a->epilogue == MRAG_EPI_NONE || a->epilogue == MRAG_EPI_RESID) && !(a->tuning & MRAG_GEMM_TUNE_NO_WIDE) &&
+inline bool k320_applies(const mrag_gemm_args* a, int epi) {
+  return a->K == 320 && a->N % 320 == 0 && a->N <= 2560 && a->M >= 16384 &&
+         (epi == MRAG_EPI_NONE || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) &&
+         !(a->tuning & (MRAG_GEMM_TUNE_NO_WIDE | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_GEGLU_NO_STAGED | MRAG_GEMM_TUNE_STREAMK)) &&
          a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 7) == 0);
 }
 
-inline int launch_skinny320(hipStream_t s, const GemmP& p, int epi) {
-  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS);
-  const dim3 grid((unsigned)(tiles < SK_CUS ? tiles : SK_CUS)), block(640);
+inline int launch_k320(hipStream_t s, const GemmP& p, int epi) {
+  const int tiles = (int)((p.M + SK320_ROWS - 1) / SK320_ROWS), slices = (int)(p.N / 320);
+  int G = (SK_CUS / slices) & ~7;                           // persistent workgroups per slice: a multiple of 8 (block id % 8 = XCD: equal g -> one XCD)
+  if (G > tiles) G = tiles >= 8 ? (tiles & ~7) : tiles;
+  const dim3 grid((unsigned)(slices * G)), block(640);
   const size_t lds = 2 * SK320_STAGE + SK320_ROWS * SK320_CPITCH;
-  if (epi == MRAG_EPI_RESID) {
-    auto kfn = gemm_n320k320_kernel<MRAG_EPI_RESID>;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    MRAG_LAUNCH(kfn, grid, block, lds, s, p);
-  } else {
-    auto kfn = gemm_n320k320_kernel<MRAG_EPI_NONE>;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+#define MRAG_K320_CASE(E)                                                                              \
+  case E: {                                                                                            \
+    auto kfn = gemm_k320_kernel<E>;                                                                    \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
+    break;                                                                                             \
   }
+  switch (epi) {
+    MRAG_K320_CASE(MRAG_EPI_NONE)
+    MRAG_K320_CASE(MRAG_EPI_RESID)
+    MRAG_K320_CASE(MRAG_EPI_GEGLU)
+    MRAG_K320_CASE(EPI_GEGLU_TANH)
+    default: return MRAG_ENOTSUP;
+  }
+#undef MRAG_K320_CASE
   MRAG_LAUNCH_CHECK();
   MRAG_COUNT(MRAG_K_GEMM_N320K320);
   return MRAG_OK;
@@ -1644,7 +1670,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
-  if (skinny320_applies(a)) return launch_skinny320(s, p, epi);      // N = K = 320: the weight in registers, activations streamed (gemm_n320k320_kernel)
+  if (k320_applies(a, epi)) return launch_k320(s, p, epi);           // K = 320, N = 320 .. 2 560: the weight in registers, activations streamed (gemm_k320_kernel)
   // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
   if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
       a->epilogue != MRAG_EPI_QKNORM_ROPE)

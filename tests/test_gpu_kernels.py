@@ -805,7 +805,7 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
 
 @pytest.mark.parametrize("M", [16384, 40000, 36864 + 37])
 def test_gemm_n320_k320_weight_in_registers(hip, M):
-    """N = K = 320 from 16 384 rows up (the UNets' level-0 projections): gemm_n320k320_kernel -- the weight as MFMA operands in registers, 64-row activation
+    """K = 320, N = 320 / 960 / 2 560 from 16 384 rows up (the UNets' level-0 linears): gemm_k320_kernel -- a 320-column weight slice as MFMA operands in registers, 64-row activation
     tiles streamed, rows leaving whole through an LDS staging tile.  Against torch fp32, bit-equal to the 256x256 / 256x320 tiles (same K order and rounding
     points), with bias, with the residual epilogue and its acc_scale, a ragged last tile, and strided input / output / residual views (column slices)"""
     from motionrag_amd import ops
@@ -838,6 +838,26 @@ def test_gemm_n320_k320_weight_in_registers(hip, M):
         ops.linear(xw[:, 64:], wd, bd, out=ow[:, 320:], epilogue=ops.EPI_RESID, resid=rw[:, 8:])
     assert d.counts == {"GEMM_N320K320": 1}, d.counts
     assert torch.equal(ow[:, 320:], outs["resid"]) and ow[:, :320].abs().max().item() == 0
+    # N = 960 (the fused QKV projection: three 320-column slices) and N = 2 560 with the GEGLU epilogue (eight slices, value / gate pairs inside a wave)
+    w3, b3 = bf(torch.randn(960, 320, generator=g) * 0.05), bf(torch.randn(960, generator=g))
+    wg, bg = bf(torch.randn(2560, 320, generator=g) * 0.05), bf(torch.randn(2560, generator=g) * 0.2)
+    wgi, bgi = ops.geglu_interleave(wg.to(DEV), bg.to(DEV))
+    for name, fn in (("qkv", lambda: ops.linear(xd, w3.to(DEV), b3.to(DEV))), ("geglu", lambda: ops.linear(xd, wgi, bgi, epilogue=ops.EPI_GEGLU))):
+        with ops.dispatched() as d:
+            got = fn()
+        assert d.counts == {"GEMM_N320K320": 1}, (name, d.counts)
+        ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_WIDE
+        try:
+            with ops.dispatched() as d:
+                other = fn()
+        finally:
+            ops.TUNING["gemm"] = 0
+        assert "GEMM_N320K320" not in d.counts and torch.equal(other, got), (name, d.counts)
+        if name == "qkv":
+            close(got, x.float() @ w3.float().t() + b3.float(), scale=1.0)
+        else:
+            y = (x.float() @ wg.float().t() + bg.float()).to(torch.bfloat16).float()
+            close(got, y[:, :1280] * torch.nn.functional.gelu(y[:, 1280:]), scale=1.0)
 
 
 @pytest.mark.parametrize("M,inner,K", [(300, 128, 64), (3000, 1280, 320), (40000, 256, 128), (30001, 272, 192)])

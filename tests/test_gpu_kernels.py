@@ -838,14 +838,14 @@ def test_gemm_n320_k320_weight_in_registers(hip, M):
         ops.linear(xw[:, 64:], wd, bd, out=ow[:, 320:], epilogue=ops.EPI_RESID, resid=rw[:, 8:])
     assert d.counts == {"GEMM_N320K320": 1}, d.counts
     assert torch.equal(ow[:, 320:], outs["resid"]) and ow[:, :320].abs().max().item() == 0
-    # N = 960 (the fused QKV projection: three 320-column slices) and N = 2 560 with the GEGLU epilogue (eight slices, value / gate pairs inside a wave)
+    # N = 960 (the fused QKV projection: three 320-column slices); the N = 2 560 GEGLU projection on the persistent kernel against the 8-wave tile
     w3, b3 = bf(torch.randn(960, 320, generator=g) * 0.05), bf(torch.randn(960, generator=g))
     wg, bg = bf(torch.randn(2560, 320, generator=g) * 0.05), bf(torch.randn(2560, generator=g) * 0.2)
     wgi, bgi = ops.geglu_interleave(wg.to(DEV), bg.to(DEV))
     for name, fn in (("qkv", lambda: ops.linear(xd, w3.to(DEV), b3.to(DEV))), ("geglu", lambda: ops.linear(xd, wgi, bgi, epilogue=ops.EPI_GEGLU))):
         with ops.dispatched() as d:
             got = fn()
-        assert d.counts == {"GEMM_N320K320": 1}, (name, d.counts)
+        assert d.counts == ({"GEMM_N320K320": 1} if name == "qkv" else {"GEMM_W4_GEGLU": 1}), (name, d.counts)    # (GEGLU stays on the persistent four-wave kernel: measured faster)
         ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_WIDE
         try:
             with ops.dispatched() as d:

@@ -90,6 +90,29 @@ def ipfold():
     print(f"literal to_q_ip GEMM: {dt*1e3:.3f} ms")
 
 
+def hbm5():
+    """round 5's memory-bound kernels at their BASELINE shapes (tools/pmc_traffic_r5.sh profiles this target): the folded motion branch, the K = 320 linear with the
+    weight in registers (+ residual), the narrow-row LayerNorm, the fan-out top-k"""
+    B, S, H = 2, 17776, 48
+    o = torch.randn(B, S, H * 64, device=DEV).to(torch.bfloat16)
+    v = torch.randn(B, 25, H * 64, device=DEV).to(torch.bfloat16)
+    sc = torch.randn(B, S, H * 32, device=DEV).to(torch.bfloat16)
+    dt = timeit(lambda: ops.ip_attn_folded_(sc, v, o, H, 25))
+    print(f"ip_attn_folded [2 x 17776 x 48 heads]: {dt*1e6:.1f} us  {(sc.numel()+2*o.numel())*2/dt/1e9:.0f} GB/s algorithmic")
+    M = 258048
+    x = torch.randn(M, 320, device=DEV).to(torch.bfloat16); w = (torch.randn(320, 320, device=DEV) * 0.05).to(torch.bfloat16)
+    r = torch.randn(M, 320, device=DEV).to(torch.bfloat16); bias = torch.randn(320, device=DEV).to(torch.bfloat16)
+    dt = timeit(lambda: ops.linear(x, w, bias, epilogue=ops.EPI_RESID, resid=r))
+    print(f"gemm_k320 [258048 x 320 x 320] + resid: {dt*1e6:.1f} us  {3*M*320*2/dt/1e9:.0f} GB/s algorithmic")
+    g = torch.ones(320, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty_like(x)
+    dt = timeit(lambda: ops.layernorm(x, g, g, 1e-5, out=y))
+    print(f"layernorm_rows [258048 x 320]: {dt*1e6:.1f} us  {2*M*320*2/dt/1e9:.0f} GB/s algorithmic")
+    db = torch.randn(1000000, 768, device=DEV); q = torch.randn(256, 768, device=DEV)
+    dt = timeit(lambda: ops.topk(db, q, 12), iters=3)
+    print(f"topk fan-out [10^6 x 768] x 256 queries: {dt*1e6:.1f} us  {db.numel()*4/dt/1e9:.0f} GB/s of table per pass, {2.0*1e6*256*768/dt/1e12:.1f} TFLOP/s fp32 MFMA")
+
+
 def ceilings():
     """the box's practical ceilings: vendor-library bf16 GEMM (hipBLASLt through torch) and device-to-device copy bandwidth"""
     M, N, K = 35552, 9216, 3072
@@ -198,7 +221,7 @@ def unet(precision="bf16", net=None):
     net = W.dynamicrafter1024_unet(DEV) if net is None else net
     dc.set_attention_precision(net, precision)
     x, ts, ctx, fs = W.dynamicrafter1024_inputs(DEV)
-    dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=3, warm=1)
+    dt = timeit(lambda: net(x, ts, context=ctx, fs=fs), iters=5, warm=2)
     dc.set_attention_precision(net, "bf16")
     T = W.DC1024_STEP_TFLOP
     print(f"DynamiCrafter-1024 UNet CFG step (16x576x1024, attention {precision}): {dt*1e3:.1f} ms  {T/dt:.0f} TFLOP/s of {T} TFLOP algorithmic  -> {16/dt:.1f} frames/s")
@@ -217,7 +240,7 @@ def svd():
     step, _, _ = W.svd_step(net, DEV)
     Fr = 14
     fl = count_flops(step)
-    dt = timeit(step, iters=3, warm=1)
+    dt = timeit(step, iters=5, warm=2)
     print(f"SVD UNet CFG step (14x576x1024, {len(names)} adapter sites): {dt*1e3:.1f} ms  {fl/dt/1e12:.0f} TFLOP/s of {fl/1e12:.1f} TFLOP algorithmic  -> {Fr/dt:.1f} frames/s")
     return {"ms_per_cfg_step": round(dt * 1e3, 1), "algorithmic_tflop": round(fl / 1e12, 1), "tflops_per_s": round(fl / dt / 1e12), "frames_per_s": round(Fr / dt, 1)}
 

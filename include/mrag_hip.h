@@ -93,6 +93,11 @@ const char* mrag_dispatch_name(int32_t id);
  * operands: >= 16 bytes of bf16 bits, 16-byte aligned; out: 256 * 512 floats (a checksum per lane, written so the loop cannot be elided).               */
 int64_t mrag_probe_mfma_flops(int32_t iters);
 int mrag_probe_mfma_bf16(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
+/* the same for the fp32 matrix pipe of the retrieval fan-out kernel (`retrieval_top12_768d.fp32_mfma_sustained_tflops` in bench.py's JSON): 256 workgroups x
+ * 4 waves (one per SIMD, the fan-out kernel's shape) x `iters` x 32 v_mfma_f32_32x32x2_f32, nominal 157 TFLOP/s.  operands: >= 4 bytes of fp32 values,
+ * 4-byte aligned; out: 256 * 256 floats.                                                                                                            */
+int64_t mrag_probe_mfma_f32_flops(int32_t iters);
+int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])     bf16 in/out      */
@@ -471,11 +476,11 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       "l2" through fmaf(-2, q.x, |q|^2 + |x|^2) with the squared norms as two */
 /*       half-block chains (mode 2 of the oracle).  n_queries >= 16, k <= 16,    */
 /*       else MRAG_ENOTSUP;                                                      */
-/*   0 = automatic: 2 where it applies AND the table has >= 32 768 rows (below   */
-/*       that the two forms take the same time), else 1 -- a batch of 16 or more */
-/*       against a large table and a single query may therefore differ in the    */
-/*       last bits of a distance (never in a rank whose gap exceeds the fp32     */
-/*       rounding of the sum: tests compare both with the float64 oracle).       */
+/*   0 = automatic: 2 where it applies (faster at every table size measured,     */
+/*       1 000 to 10^6 rows), else 1 -- a batch of 16 or more and a single query */
+/*       may therefore differ in the last bits of a distance (never in a rank    */
+/*       whose gap exceeds the fp32 rounding of the sum: tests compare both with */
+/*       the float64 oracle).                                                    */
 /* ------------------------------------------------------------------------ */
 /* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
  * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a

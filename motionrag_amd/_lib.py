@@ -24,7 +24,7 @@ EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"],
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mrag_abi_version", "mrag_target_arch", "mrag_source_hash", "mrag_dispatch_counts", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_bf16", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
+    "mrag_abi_version", "mrag_target_arch", "mrag_source_hash", "mrag_dispatch_counts", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_bf16", "mrag_probe_mfma_f32_flops", "mrag_probe_mfma_f32", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
@@ -36,7 +36,7 @@ SYMBOLS = [
 
 
 # entry points whose result is not the int32 status code (their restype is set explicitly in lib())
-_NON_INT_RESULT = ("mrag_target_arch", "mrag_source_hash", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_gemm_workspace_bytes", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
+_NON_INT_RESULT = ("mrag_target_arch", "mrag_source_hash", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_f32_flops", "mrag_gemm_workspace_bytes", "mrag_attn_workspace_bytes", "mrag_attn_fp8_workspace_bytes", "mrag_topk_workspace_bytes", "mrag_groupnorm_workspace_bytes",
                    "mrag_resampler_workspace_bytes", "mrag_cama_encoder_workspace_bytes")
 
 
@@ -258,6 +258,9 @@ def lib() -> ctypes.CDLL:
     L.mrag_probe_mfma_flops.argtypes = [c_int32]
     L.mrag_probe_mfma_flops.restype = c_int64
     L.mrag_probe_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int32]
+    L.mrag_probe_mfma_f32_flops.argtypes = [c_int32]
+    L.mrag_probe_mfma_f32_flops.restype = c_int64
+    L.mrag_probe_mfma_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int32]
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
     L.mrag_gemm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]

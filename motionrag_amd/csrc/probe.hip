@@ -5,6 +5,7 @@
 //   inside the loop, 8 waves per CU (2 per SIMD), 32 independent accumulator tiles per wave so the matrix pipe never waits for a result.  This is
 //   the upper bound of ANY bf16 kernel on the box in its current power state: the nominal 2.5 PFLOP/s assumes the 2.4 GHz peak clock, which the
 //   part does not hold under a dense matrix load on random data (profiles/r2_mfma_shape_power.txt).
+//   mrag_probe_mfma_f32: the same for v_mfma_f32_32x32x2_f32 (nominal 157 TFLOP/s), the pipe of the retrieval fan-out kernel.
 #include "common.h"
 #include "../../include/mrag_hip.h"
 
@@ -36,7 +37,49 @@ __global__ __launch_bounds__(512) void probe_mfma_kernel(const bf16x8* __restric
   out[t] = s;
 }
 
+// the fp32 matrix pipe the retrieval fan-out kernel runs on: v_mfma_f32_32x32x2_f32, four waves per CU (one per SIMD, the fan-out kernel's shape), 8 independent
+// 32x32 accumulators per wave -- the kernel's own register image without its LDS / DMA traffic
+__global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __restrict__ operands, long long n, float* __restrict__ out, int iters) {
+  float a[4], b[8][4];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = operands[(t * 36 + i) % n];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[j][i] = operands[(t * 36 + 4 + 4 * j + i) % n];
+  f32x16 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j][i], acc[j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[j][e];
+  out[t] = s;
+}
+
 }  // namespace
+
+extern "C" int64_t mrag_probe_mfma_f32_flops(int32_t iters) {
+  // 256 workgroups x 4 waves x iters x 32 MFMAs x (2 * 32 * 32 * 2) FLOP
+  return iters <= 0 ? 0 : 256LL * 4 * (int64_t)iters * 32 * 4096;
+}
+
+extern "C" int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters) {
+  if (!operands || !out || operand_bytes < 4 || iters <= 0 || ((uintptr_t)operands & 3)) return MRAG_EINVAL;
+  MRAG_LAUNCH(probe_mfma_f32_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)operands, (long long)(operand_bytes / 4), out, iters);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
 
 extern "C" int64_t mrag_probe_mfma_flops(int32_t iters) {
   // 256 workgroups x 8 waves x iters x 32 MFMAs x (2 * 16 * 16 * 32) FLOP

@@ -410,38 +410,45 @@ __device__ __forceinline__ unsigned float_key(float f) { const unsigned u = __fl
 __device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // per call: the shared thresholds start at +inf; |q|^2 of every query in the fan-out kernel's order (chains over features
-// 8c + t and 8c + 4 + t, added once) when the metric needs it
-__global__ __launch_bounds__(256) void topk_qq_kernel(const float* q, float* qq, unsigned* tau_g, int nq, int dim, int want_qq) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nq) return;
-  tau_g[i] = 0xff800000u;                            // float_key(+inf): no threshold yet
+// 8c + t and 8c + 4 + t, added once) when the metric needs it.  One wave per query: the row comes into LDS with coalesced 16-byte loads, then lane 0 runs the
+// `lo` chain and lane 1 the `hi` chain over ds_read_b128 quads -- the chains are sequential by definition (dim / 2 dependent FMAs each), the loads need not be
+// (a thread per query, the first form, took 91 us at 256 queries x 768: a serial walk over a 3 KB-strided row)
+__global__ __launch_bounds__(64) void topk_qq_kernel(const float* q, float* qq, unsigned* tau_g, int nq, int dim, int want_qq) {
+  __shared__ __attribute__((aligned(16))) float row[1024];   // dim <= 1024 (mrag_topk_f32)
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) tau_g[i] = 0xff800000u;             // float_key(+inf): no threshold yet
   if (!want_qq) return;
-  const float* x = q + (long long)i * dim;
-  float lo = 0.f, hi = 0.f;
-  for (int c = 0; 8 * c < dim; ++c)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int k0 = 8 * c + t, k1 = 8 * c + 4 + t;
-      if (k0 < dim) lo = __builtin_fmaf(x[k0], x[k0], lo);
-      if (k1 < dim) hi = __builtin_fmaf(x[k1], x[k1], hi);
+  const float4* src = (const float4*)(q + (long long)i * dim);
+  const int nquad = dim >> 2;                        // dim % 4 == 0 (mrag_topk_f32)
+  for (int c = lane; c < nquad; c += 64) ((float4*)row)[c] = src[c];
+  __syncthreads();
+  if (lane < 2) {                                    // lane 0: quads 0, 2, 4, .. (features 8c + t); lane 1: quads 1, 3, 5, .. (8c + 4 + t; none for the last block of an odd quad count)
+    float acc = 0.f;
+    for (int c = lane; c < nquad; c += 2) {
+      const float4 v = ((const float4*)row)[c];
+      acc = __builtin_fmaf(v.x, v.x, acc); acc = __builtin_fmaf(v.y, v.y, acc); acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc);
     }
-  qq[i] = lo + hi;
+    const float other = __shfl_xor(acc, 1);
+    if (lane == 0) qq[i] = acc + other;              // lo + hi
+  }
 }
 
 constexpr int mfma_stages(int TN) { return TN >= 8 ? 2 : TN == 4 ? 3 : TN == 2 ? 4 : 3; }   // TN = 1: three stages keep two workgroups per CU (67 KB each)
 
-template <int METRIC, int TN>
-__global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
-  constexpr int WM = 4, WN = 1, RB = 32 * WM, QB = 32 * TN * WN, NST = mfma_stages(TN);
-  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = NPIECE / 4, LSTR = 17, NSLOT = 2 * WM;
-  static_assert(NPIECE % 4 == 0, "every wave issues the same number of LDS-DMA pieces per slab (the counted vmcnt wait relies on it)");
+// WN = 2: eight waves -- four row groups x two query groups of TN tiles each -- so every SIMD holds TWO waves and one's LDS-read / DMA-issue / barrier
+// stalls pass under the other's MFMAs (the 256-query workgroup: TN = 4, WN = 2; as four waves of TN = 8 its matrix pipe idled a quarter of the stream)
+template <int METRIC, int TN, int WN>
+__global__ __launch_bounds__(256 * WN) void topk_mfma_kernel(const TopkMP p) {
+  constexpr int WM = 4, NW = WM * WN, NT = 64 * NW, RB = 32 * WM, QB = 32 * TN * WN, NST = mfma_stages(TN * WN);
+  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = NPIECE / NW, NTAB = (RB / 8) / NW, LSTR = 17, NSLOT = 2 * WM;
+  static_assert(NPIECE % NW == 0 && (RB / 8) % NW == 0 && PPW == NTAB + TN, "every wave issues the same number of LDS-DMA pieces per slab (the counted vmcnt wait relies on it)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Cand* lists = (Cand*)(smem + NST * STAGE);        // [QB][LSTR]: sorted ascending, entries >= k stay +inf
   Cand* slots = lists + QB * LSTR;                  // [QB][NSLOT]: this round's candidate of each (wave, half) for the query
   Cand* taus = slots + QB * NSLOT;                  // [QB]: the query's k-th best so far
   float* xxs = (float*)(taus + QB);                 // [4][32]: |x|^2 of the wave's 32 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave, wn = 0;
+  const int wm = wave & (WM - 1), wn = wave / WM;
   const int r32 = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.y * QB, part = blockIdx.x;
   const long long row_begin = (long long)part * p.rows_per_part;
@@ -449,8 +456,8 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
   if (row_end > p.n_rows) row_end = p.n_rows;
   const int nblk = row_end > row_begin ? (int)((row_end - row_begin + RB - 1) / RB) : 0;
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
-  for (int i = tid; i < QB * LSTR; i += 256) lists[i] = inf;
-  for (int i = tid; i < QB; i += 256) taus[i] = inf;
+  for (int i = tid; i < QB * LSTR; i += NT) lists[i] = inf;
+  for (int i = tid; i < QB; i += NT) taus[i] = inf;
 
   // per lane: the query of each of its TN tiles
   // (scalars and scalar arrays only below: a private ARRAY OF STRUCTS is not promoted to registers by hipcc -- it lives in scratch, and every scratch access is a
@@ -465,35 +472,39 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
     tau_d[j] = INFINITY; tau_r[j] = INT_MAX;
   }
 
-  // ---- the LDS-DMA stream: item `it` = (row block, feature slab), stage it % NST.  Per wave and slab: 4 pieces of table rows + TN pieces of query rows
+  // ---- the LDS-DMA stream: item `it` = (row block, feature slab), stage it % NST.  Per wave and slab: NTAB pieces of table rows + TN pieces of query rows
   // (1 KiB = 8 rows x 128 bytes each).  The row pointers are kept in registers (queries: fixed; table rows: per row block), so a piece costs one 64-bit add;
   // the pieces of slab it + NST - 1 are issued in four portions BETWEEN the MFMA groups of slab it (an LDS-DMA instruction takes ~100 cycles to issue: a
   // burst of 12 in front of the MFMAs idled the matrix pipe for a fifth of a slab).
-  const int chunk = (lane & 7) ^ (lane >> 3);       // source chunk of this lane inside its 128-byte slab row (row & 7 == lane >> 3)
+  // LDS image: 128-byte rows, the 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).  ds_read_b128 serves a wave in four 16-lane groups
+  // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32: MI355X_MICROARCH.md, LDS) over a 256-byte bank row, i.e. a group's 8 even and 8 odd rows
+  // must each hit 8 distinct chunks: (r >> 1) & 7 is distinct over them, r & 7 (the first form) was not -- every fragment read was a 2-way conflict
+  // (SQ_LDS_BANK_CONFLICT = 54 % of SQ_LDS_IDX_ACTIVE).  A DMA piece is 8 rows starting at row 8 P, P = wave + NW i: (r >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7.
+  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);   // source chunk of this lane inside its 128-byte slab row
   const float* qptr[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
-    int qi = q0 + 8 * (wave + 4 * i) + (lane >> 3);
+    int qi = q0 + 8 * (wave + NW * i) + (lane >> 3);
     qi = qi < p.nq ? qi : p.nq - 1;
     qptr[i] = p.q + (long long)qi * p.dim;
   }
-  const float* aptr[4];
+  const float* aptr[NTAB];
   int d_blk = 0, d_s = 0;
   auto set_rows = [&](const int blk_) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      long long row = row_begin + (long long)blk_ * RB + 8 * (wave + 4 * i) + (lane >> 3);
+    for (int i = 0; i < NTAB; ++i) {
+      long long row = row_begin + (long long)blk_ * RB + 8 * (wave + NW * i) + (lane >> 3);
       row = row < p.n_rows ? row : p.n_rows - 1;     // (past the table -- also past the END of the stream -- the last row is re-read and never used)
       aptr[i] = p.db + row * p.dim;
     }
   };
   set_rows(0);
-  auto issue_piece = [&](auto I, const int stage) {  // piece I (< 4: table rows, else query rows) of the cursor's slab
+  auto issue_piece = [&](auto I, const int stage) {  // piece I (< NTAB: table rows, else query rows) of the cursor's slab
     constexpr int i = decltype(I)::value;
     const int kk = d_s * 32 + chunk * 4;
-    const float* src = i < 4 ? aptr[i < 4 ? i : 0] : qptr[i < 4 ? 0 : i - 4];
+    const float* src = i < NTAB ? aptr[i < NTAB ? i : 0] : qptr[i < NTAB ? 0 : i - NTAB];
     src = kk < p.dim ? src + kk : g_topk_zero + chunk * 4;
-    char* dst = smem + stage * STAGE + ((i < 4 ? 0 : RB / 8) + wave + 4 * (i < 4 ? i : i - 4)) * 1024;
+    char* dst = smem + stage * STAGE + ((i < NTAB ? 0 : RB / 8) + wave + NW * (i < NTAB ? i : i - NTAB)) * 1024;
 #ifndef MRAG_TOPK_DIAG_NODMA  // developer timing build: no operand traffic (the MFMAs run on whatever the LDS holds)
     glds16(src, dst);
 #endif
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
     stg = stg + 1 == NST ? 0 : stg + 1;
     const char* arow = st + (wm * 32 + r32) * 128;
     const char* qrow = st + (RB + wn * TN * 32 + r32) * 128;
-    const int sw = r32 & 7;
+    const int sw = (r32 >> 1) & 7;
     static_for<4>([&](auto C) __attribute__((always_inline)) {
       constexpr int c = decltype(C)::value;
       const int off = ((2 * c + h) ^ sw) * 16;
@@ -561,7 +572,12 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
     if (++s < p.nslab) continue;
     // ---- end of a row block: distances, then the selection rounds
     s = 0;
-#ifdef MRAG_TOPK_DIAG_NOSEL   // developer timing build (tools/build_variant.sh): the MFMA / DMA stream alone
+#ifdef MRAG_TOPK_DIAG_NOSEL   // developer timing build (tools/topk_variants.sh): the MFMA / DMA stream alone
+#if defined(__HIP_DEVICE_COMPILE__)   // (the accumulators stay live: without a consumer hipcc deletes the MFMAs; the host pass cannot parse the "v" constraint)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[j]));
+    asm volatile("" :: "v"(xx));
+#endif
     ++blk;
     continue;
 #endif
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
 #endif
     if constexpr (METRIC == 0) {
       const float xf = xx + __shfl_xor(xx, 32);      // the two half-row chains, added once (either lane: the same two addends)
-      if (h == 0) xxs[wave * 32 + r32] = xf;
+      if (h == 0 && wn == 0) xxs[wm * 32 + r32] = xf;   // (the query groups hold the same rows: one writes)
       xx = 0.f;
     }
     __syncthreads();
@@ -598,7 +614,7 @@ __global__ __launch_bounds__(256) void topk_mfma_kernel(const TopkMP p) {
       const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
       const long long grow = blk_row0 + i;
       const bool valid = grow < row_end;
-      const float xi = METRIC == 0 ? xxs[wave * 32 + i] : 0.f;
+      const float xi = METRIC == 0 ? xxs[wm * 32 + i] : 0.f;
       const int gi = gid[reg];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -740,10 +756,22 @@ inline MfmaPlan plan_mfma(long long n_rows, int nq) {
   const int qtiles = (nq + 31) / 32;
   pl.RB = 128;
   const long long blocks = (n_rows + pl.RB - 1) / pl.RB;
-  // the widest query tile that still gives >= 256 workgroups (row blocks x query blocks); a large table takes TN = 8 whenever the batch has 8 tiles
-  pl.TN = 1;
+  // Query tile (32 TN queries per workgroup).  A table that fits ONE round of workgroups with one row block each takes the SMALLEST tile that still fits the
+  // round (512 workgroups at TN = 1 -- two per CU --, 256 above): every workgroup pays its pipeline fill and the ~6 selection rounds of a cold list once, so
+  // more, smaller workgroups finish sooner (4 000 rows x 256 queries: 94 / 111 / 137 / 191 us at TN = 1 / 2 / 4 / 8; 10 000 rows: 166 / 169 / 140 / 190;
+  // 20 000 rows: 221 / 225 / 231 / 190; profiles/r5_topk_query_tile_by_table_size.txt).  A larger table streams: the widest tile the batch fills (one pass
+  // over the table per 256 queries).
+  int widest = 1;
   for (int t = 8; t >= 1; t >>= 1)
-    if (t <= qtiles && (t == 1 || blocks * ((qtiles + t - 1) / t) >= 256)) { pl.TN = t; break; }
+    if (t <= qtiles) { widest = t; break; }
+  pl.TN = widest;
+  for (int t = 1; t <= widest; t <<= 1)
+    if (blocks * ((qtiles + t - 1) / t) <= (t == 1 ? 512 : 256)) { pl.TN = t; break; }
+#ifdef MRAG_TOPK_FORCE_TN   // developer knob (tools/topk_variants.sh): the query tile of every plan
+  pl.TN = 1;
+  for (int t = MRAG_TOPK_FORCE_TN; t >= 1; t >>= 1)
+    if (t <= qtiles) { pl.TN = t; break; }
+#endif
   pl.QB = 32 * pl.TN;
   pl.lds = (size_t)mfma_stages(pl.TN) * (pl.RB + pl.QB) * 128 + (size_t)pl.QB * (17 + 8 + 1) * sizeof(Cand) + 4 * 32 * sizeof(float);
   pl.gy = (nq + pl.QB - 1) / pl.QB;
@@ -759,10 +787,11 @@ inline MfmaPlan plan_mfma(long long n_rows, int nq) {
 }
 
 inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 && dim % 4 == 0; }
-// where `order = 0` (automatic) takes the fan-out form: a table of 32 768 rows or more.  Measured on MI355X (tools/microbench.py topk, k = 12, D = 768):
-// 10^6 rows x 256 queries 4.2 ms against 17.2 ms through the scan kernel, 10^6 x 64 1.6 against 5.0 ms; at 10^4 rows x 256 queries the two are equal
-// (0.27 ms: every workgroup's lists start cold, and the ~6 workgroup-synchronous selection rounds of a first row block cost as much as its MFMAs)
-inline bool mfma_auto(long long n_rows, int nq, int k, int dim) { return mfma_applies(nq, k, dim) && n_rows >= 32768; }
+// `order = 0` (automatic) takes the fan-out form whenever it applies.  Measured on MI355X (tools/topk_sizes.py, k = 12, D = 768; fan-out / scan kernel):
+// 1 000 rows x 256 queries 94 / 164 us, 10 000 x 256 140 / 228 us, 10^5 x 256 0.59 / 2.0 ms, 10^6 x 256 3.8 / 17.2 ms; 10 000 x 16 90 / 158 us
+// (profiles/r5_topk_fanout_vs_scan_by_size.txt).  (Until the |q|^2 pre-pass became a wave per query -- it took 91 us as a thread per query -- the two forms were
+// equal at 10 000 rows and the switch sat at 32 768.)
+inline bool mfma_auto(long long n_rows, int nq, int k, int dim) { (void)n_rows; return mfma_applies(nq, k, dim); }
 
 inline int pick_qt(int nq) { return nq >= 9 ? 16 : nq >= 2 ? 4 : 1; }   // queries per workgroup pass
 
@@ -838,18 +867,18 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
     m.qq = qq;
     m.tau_g = (unsigned*)((char*)workspace + kTicketBytes + qbytes);
     m.lists = (Cand*)((char*)workspace + kTicketBytes + 2 * qbytes);
-    MRAG_LAUNCH(topk_qq_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, queries, qq, m.tau_g, n_queries, dim, metric == 0 ? 1 : 0);
+    MRAG_LAUNCH(topk_qq_kernel, dim3(n_queries), dim3(64), 0, s, queries, qq, m.tau_g, n_queries, dim, metric == 0 ? 1 : 0);
     MRAG_LAUNCH_CHECK();
-    const dim3 mgrid(pl.parts, pl.gy), block256(256);
-#define MRAG_TOPK_MFMA(M, T)                                                                                           \
-    if (metric == M && pl.TN == T) {                                                                                   \
-      auto kfn = topk_mfma_kernel<M, T>;                                                                                \
+    const dim3 mgrid(pl.parts, pl.gy);
+#define MRAG_TOPK_MFMA(M, T, W)                                                                                        \
+    if (metric == M && pl.TN == T * W) {                                                                               \
+      auto kfn = topk_mfma_kernel<M, T, W>;                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
       if (e != hipSuccess) return (int)e;                                                                              \
-      MRAG_LAUNCH(kfn, mgrid, block256, pl.lds, s, m);                                                                 \
+      MRAG_LAUNCH(kfn, mgrid, dim3(256 * W), pl.lds, s, m);                                                            \
     }
-    MRAG_TOPK_MFMA(0, 1) MRAG_TOPK_MFMA(0, 2) MRAG_TOPK_MFMA(0, 4) MRAG_TOPK_MFMA(0, 8)
-    MRAG_TOPK_MFMA(1, 1) MRAG_TOPK_MFMA(1, 2) MRAG_TOPK_MFMA(1, 4) MRAG_TOPK_MFMA(1, 8)
+    MRAG_TOPK_MFMA(0, 1, 1) MRAG_TOPK_MFMA(0, 2, 1) MRAG_TOPK_MFMA(0, 4, 1) MRAG_TOPK_MFMA(0, 4, 2)   // (256 queries per workgroup: eight waves of four tiles)
+    MRAG_TOPK_MFMA(1, 1, 1) MRAG_TOPK_MFMA(1, 2, 1) MRAG_TOPK_MFMA(1, 4, 1) MRAG_TOPK_MFMA(1, 4, 2)
 #undef MRAG_TOPK_MFMA
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_TOPK_MFMA);

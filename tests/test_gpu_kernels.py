@@ -677,9 +677,10 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
     db, q = _unit(rng, N, D), _unit(rng, Q, D)
     group = (np.arange(N) // 2).astype(np.int32)
     excl = group[rng.integers(0, N, Q)].astype(np.int32)
-    # the 16-chain scan kernel (`order="chain16"`: every batch size; also what "auto" picks below 32 768 rows) and, where it applies (>= 16 queries, k <= 16),
-    # the fan-out kernel
-    for order, mode in (("chain16", "f32chain"), ("auto", "f32chain")) + ((("mfma", "f32mfma"),) if Q >= 16 and k <= 16 else ()):
+    # the 16-chain scan kernel (`order="chain16"`: every batch size) and, where it applies (>= 16 queries, k <= 16), the fan-out kernel -- which is also what
+    # "auto" then picks, at every table size
+    fan = Q >= 16 and k <= 16
+    for order, mode in (("chain16", "f32chain"), ("auto", "f32mfma" if fan else "f32chain")) + ((("mfma", "f32mfma"),) if fan else ()):
         want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode=mode)
         with ops.dispatched() as d:
             rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
@@ -699,7 +700,8 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
 def test_topk_filter_order_bit_exact(hip, metric, Q):
     """lancedb's post-filter (`where(..., prefilter=False)`: the k nearest first, then the filter) and the pre-filter against the C oracle in the
     matching mode, bit for bit, on a database with 6 clips per video where the two orders give different lists; Q = 1 / 3 run the fused
-    single-launch form, 5 the query-tile scan + merge kernel, 40 the 16-query tiles (the fan-out kernel's filter orders: test_topk_fanout_bit_exact)"""
+    single-launch form, 5 the query-tile scan + merge kernel, 40 the fan-out kernel ("auto" takes it from 16 queries up: oracle mode f32mfma) and, pinned
+    with order="chain16", the scan kernel's 16-query tiles"""
     from motionrag_amd import ops
     from oracle import topk_ref
     from test_oracle_golden import multi_clip_db
@@ -712,10 +714,13 @@ def test_topk_filter_order_bit_exact(hip, metric, Q):
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, own))
     lists = {}
     for post in (False, True):
-        want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode="f32chain", postfilter=post)
-        rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post)
-        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
-        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+        for order, mode in (("auto", "f32mfma" if Q >= 16 else "f32chain"), ("chain16", "f32chain")):
+            want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode=mode, postfilter=post)
+            with ops.dispatched() as d:
+                rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post, order=order)
+            assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+            np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
+            np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
         lists[post] = rows.cpu().numpy()
     assert (lists[False] >= 0).all()
     short = (lists[True] >= 0).sum(axis=1)
@@ -756,18 +761,17 @@ def test_topk_baseline_size(hip):
     group = np.arange(10000, dtype=np.int32)
     excl = rng.integers(0, 10000, 256).astype(np.int32)
     q[:64] = db[excl[:64]] + 0.01 * q[:64]                                   # queries whose own row must be filtered out
-    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
-                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV))
-    rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
-    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32chain")         # 10 k rows: "auto" = the scan kernel, 16 passes of 16 queries
-    np.testing.assert_array_equal(rows, want_r)
-    np.testing.assert_array_equal(dist, want_d.astype(np.float32))
-    assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
-    rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), 12, metric="l2",
-                          group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order="mfma")      # the fan-out kernel: ONE pass over the table
-    want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode="f32mfma")
-    np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
-    np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+    dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
+    # "auto" = the fan-out kernel (ONE pass over the table, oracle mode f32mfma); order="chain16" = the scan kernel, 16 passes of 16 queries (mode f32chain)
+    for order, mode in (("auto", "f32mfma"), ("chain16", "f32chain"), ("mfma", "f32mfma")):
+        with ops.dispatched() as d:
+            rows, dist = ops.topk(dbd, qd, 12, metric="l2", group=gd, exclude=ed, order=order)
+        assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+        rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
+        want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode=mode)
+        np.testing.assert_array_equal(rows, want_r)
+        np.testing.assert_array_equal(dist, want_d.astype(np.float32))
+        assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
 
 
 @pytest.mark.parametrize("metric", ["l2", "dot"])
@@ -795,10 +799,8 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
         np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
     want_r, want_d = topk_ref.topk(db, q, k, metric, mode="f32mfma")
     with ops.dispatched() as d:
-        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out kernel from 32 768 rows up, the scan kernel below
-    assert ("TOPK_MFMA" in d.counts) == (N >= 32768), d.counts
-    if N < 32768:
-        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="mfma")
+        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out kernel wherever it applies
+    assert "TOPK_MFMA" in d.counts and "TOPK_SCAN" not in d.counts, d.counts
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 

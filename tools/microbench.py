@@ -167,9 +167,29 @@ def gemm_epi():
     print(f"gemm qkv + qknorm + rope N=9216 K=3072: {dt*1e3:.3f} ms  {2.0*B*S*3*D*D/dt/1e12:.0f} TFLOP/s")
 
 
+def mfma_f32_sustained(seconds=0.5):
+    """measured ceiling (not product path): what the fp32 matrix pipe sustains here -- libmrag_hip.so's register-resident v_mfma_f32_32x32x2_f32 loop,
+    four waves per CU like the fan-out kernel, random operands, back-to-back launches for `seconds`"""
+    import ctypes
+    from motionrag_amd import _lib
+    L = _lib.lib()
+    operands = torch.randn(1 << 20, device=DEV)
+    sink = torch.empty(256 * 256, dtype=torch.float32, device=DEV)
+    iters = 4000
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    launch = lambda: _lib.check(L.mrag_probe_mfma_f32(st, ctypes.c_void_p(operands.data_ptr()), operands.numel() * 4, ctypes.c_void_p(sink.data_ptr()), iters),  # noqa: E731
+                                "mrag_probe_mfma_f32")
+    one = timeit(launch, iters=2, warm=1)
+    dt = timeit(launch, iters=max(2, int(seconds / max(one, 1e-4))), warm=0)
+    return L.mrag_probe_mfma_f32_flops(iters) / dt / 1e12
+
+
 def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
     import time
     res = {}
+    if any(Q >= 16 for _, Q in cases):
+        res["fp32_mfma_sustained_tflops"] = round(mfma_f32_sustained(), 1)
+        print(f"fp32 MFMA probe (v_mfma_f32_32x32x2_f32, 4 waves per CU, register-resident): {res['fp32_mfma_sustained_tflops']} TFLOP/s sustained of 157 nominal")
     for N, Q in cases:
         db = torch.randn(N, 768, device=DEV)
         q = torch.randn(Q, 768, device=DEV)
@@ -382,6 +402,14 @@ def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
     print(f"CogVideoX VAE encode of the conditioning image (tiled): {de*1e3:.1f} ms")
     res["encode_image_ms"] = round(de * 1e3, 1)
     return res
+
+
+def topk_small():
+    """the fan-out kernel at BASELINE config #1's table size (10 000 rows) x 256 queries, for a kernel trace (tools/prof.sh topk_small)"""
+    db = torch.randn(10000, 768, device=DEV); q = torch.randn(256, 768, device=DEV)
+    for order in ("mfma", "chain16"):
+        dt = timeit(lambda: ops.topk(db, q, 12, order=order), iters=50, warm=5)
+        print(f"topk 10000 x 256 order {order}: {dt*1e6:.1f} us")
 
 
 if __name__ == "__main__":

@@ -80,6 +80,7 @@ enum mrag_kernel_id {
   MRAG_K_LAYERNORM, MRAG_K_LAYERNORM_ROWS /* several narrow rows per wave (C = 320 / 640 / 1 280) */, MRAG_K_QKNORM_ROPE,
   MRAG_K_GN_STATS, MRAG_K_GN_FOLD, MRAG_K_GN_APPLY, MRAG_K_GN_APPLY_MOD,
   MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
+  MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
   MRAG_K_COUNT
 };
 /* copies min(n, MRAG_K_COUNT) counters into out_host (HOST memory) and returns MRAG_K_COUNT */
@@ -165,7 +166,8 @@ typedef struct mrag_gemm_args {
                               order only).  OPT-IN: measured slower than the partial round on MI355X               */
 } mrag_gemm_args;
 enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8,
-       MRAG_GEMM_TUNE_NO_W4 = 1 << 16 /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */ };
+       MRAG_GEMM_TUNE_NO_W4 = 1 << 16, /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */
+       MRAG_GEMM_TUNE_NO_SKINNY = 1 << 17 /* keep few-row problems (M <= 256) on the 128x128 tile instead of the K-split few-row kernel */ };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */

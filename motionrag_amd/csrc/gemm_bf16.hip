@@ -1503,6 +1503,138 @@ __global__ __launch_bounds__(640) void gemm_k320_kernel(const GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Few-row GEMM (M <= 256: CAMA's Perceiver latents and encoder tokens, 25-251 rows; the retrieval query's text embedder, 16 rows).  On the tiled kernels such a
+// problem is 8-96 workgroups, each walking the whole K through an LDS ring with a barrier per K-tile: 15-45 us per launch whatever the size.
+// Here a workgroup owns a 32 x 64 output tile and its EIGHT waves split K between them (wave w takes the 32-deep K-steps w, w + 8, ...): every wave streams its
+// fragments straight from L2 / HBM into MFMA operands -- no LDS staging, no barrier in the loop, dozens of independent 16-byte loads in flight per lane -- and the
+// eight partial tiles meet once in LDS, where they are added in wave order (a fixed order: bit-reproducible; NOT the summation order of the tiled kernels, so
+// the last bits differ from theirs).  Grid = ceil(M / 32) x ceil(N / 64) workgroups: 128-512 for CAMA's shapes.  Epilogue and rounding points: epilogue_direct's.
+constexpr int SKM_ROWS = 32, SKM_COLS = 64, SKM_WAVES = 8;
+
+template <int EPI>
+__global__ __launch_bounds__(64 * SKM_WAVES) void gemm_skinny_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* part = (float*)smem;                                   // [SKM_WAVES][SKM_ROWS][SKM_COLS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long m0 = (long long)blockIdx.y * SKM_ROWS, n0 = (long long)blockIdx.x * SKM_COLS;
+  const int r = lane & 15, kc = (lane >> 4) * 8;
+  const bf16_t* ap[2];
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    long long m = m0 + i * 16 + r;
+    m = m < p.M ? m : p.M - 1;                                  // (rows / columns past the problem are computed on a clamped copy and never stored)
+    ap[i] = p.A + m * p.lda + kc;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    long long n = n0 + j * 16 + r;
+    n = n < p.N ? n : p.N - 1;
+    wp[j] = p.W + n * p.ldw + kc;
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = (int)(p.K / 32);
+  auto steps = [&](auto U, const int ks0) __attribute__((always_inline)) {       // U K-steps of this wave from ks0: all loads first (6 U independent 16-byte loads in flight)
+    constexpr int u_n = decltype(U)::value;
+    bf16x8 a[u_n][2], w[u_n][4];
+#pragma unroll
+    for (int u = 0; u < u_n; ++u) {
+      const int k = (ks0 + u * SKM_WAVES) * 32;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[u][i] = *(const bf16x8*)(ap[i] + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[u][j] = *(const bf16x8*)(wp[j] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < u_n; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][j], a[u][i], acc[i][j], 0, 0, 0);
+  };
+  int ks = wave;
+  for (; ks + 3 * SKM_WAVES < nks; ks += 4 * SKM_WAVES) steps(std::integral_constant<int, 4>{}, ks);
+  for (; ks < nks; ks += SKM_WAVES) steps(std::integral_constant<int, 1>{}, ks);
+  // accumulator layout: lane owns row i * 16 + (lane & 15), columns j * 16 + (lane >> 4) * 4 + {0..3}
+  float* mine = part + wave * (SKM_ROWS * SKM_COLS);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(mine + (i * 16 + r) * SKM_COLS + j * 16 + (lane >> 4) * 4) = acc[i][j];
+  __syncthreads();
+  // 512 threads x 4 consecutive columns = the 32 x 64 tile
+  const int row = tid >> 4, col = (tid & 15) * 4;
+  const long long m = m0 + row, n = n0 + col;
+  if (m >= p.M || n >= p.N) return;
+  f32x4 t = *(const f32x4*)(part + row * SKM_COLS + col);
+#pragma unroll
+  for (int w8 = 1; w8 < SKM_WAVES; ++w8) {
+    const f32x4 u = *(const f32x4*)(part + w8 * (SKM_ROWS * SKM_COLS) + row * SKM_COLS + col);
+    t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
+  }
+  float v[4] = {t[0], t[1], t[2], t[3]};
+  if (p.bias) {
+    const u32x2 bb = *(const u32x2*)(p.bias + n);
+    v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+    v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+  if constexpr (EPI == MRAG_EPI_RESID) {
+    const u32x2 rr = *(const u32x2*)(p.resid + m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+    v[0] = bf_round(v[0]) + __uint_as_float(rr[0] << 16); v[1] = bf_round(v[1]) + __uint_as_float(rr[0] & 0xffff0000u);
+    v[2] = bf_round(v[2]) + __uint_as_float(rr[1] << 16); v[3] = bf_round(v[3]) + __uint_as_float(rr[1] & 0xffff0000u);
+  }
+  u32x2 out;
+  out[0] = pack_bf2(v[0], v[1]);
+  out[1] = pack_bf2(v[2], v[3]);
+  *(u32x2*)(p.C + m * p.ldc + n) = out;
+}
+
+// where the few-row kernel runs: measured against the 128 x 128 tile on MI355X (tools/skinny_sweep.py, profiles/r5_gemm_skinny_sweep.txt)
+inline bool skinny_applies(const mrag_gemm_args* a, int epi) {
+  // (W is read once per 32-row tile, through L2: past ~134 MB of such reads the tiled kernel's larger tiles win again -- [256 x 10240 x 4096] 115 vs 50 us,
+  // [256 x 4096 x 4096] 49 vs 47, [128 x 4096 x 4096] 27 vs 47, [250 x 1024 x 4096] 25 vs 46; a single row tile streams any weight once: the UNets' batched
+  // time-embedding projection, 32 x 36 480 x 1 280)
+  const long long row_tiles = (a->M + SKM_ROWS - 1) / SKM_ROWS;
+  return a->M <= 256 && row_tiles * a->N * a->K <= 8LL * 4096 * 2048 && a->K >= 256 && a->N >= 256 &&
+         !(a->tuning & MRAG_GEMM_TUNE_NO_SKINNY) && ((a->tuning >> 4) & 0xf) == 0 &&
+         (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_GELU_ERF || epi == MRAG_EPI_SILU || epi == MRAG_EPI_RESID) &&
+         (!a->bias || (((uintptr_t)a->bias) & 7) == 0);
+}
+
+inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
+  const dim3 grid((unsigned)((p.N + SKM_COLS - 1) / SKM_COLS), (unsigned)((p.M + SKM_ROWS - 1) / SKM_ROWS)), block(64 * SKM_WAVES);
+  const size_t lds = (size_t)SKM_WAVES * SKM_ROWS * SKM_COLS * sizeof(float);
+#define MRAG_SKINNY_CASE(E)                                                                            \
+  case E: {                                                                                            \
+    auto kfn = gemm_skinny_kernel<E>;                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                \
+    MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
+    break;                                                                                             \
+  }
+  switch (epi) {
+    MRAG_SKINNY_CASE(MRAG_EPI_NONE)
+    MRAG_SKINNY_CASE(MRAG_EPI_GELU_TANH)
+    MRAG_SKINNY_CASE(MRAG_EPI_GELU_ERF)
+    MRAG_SKINNY_CASE(MRAG_EPI_SILU)
+    MRAG_SKINNY_CASE(MRAG_EPI_RESID)
+    default: return MRAG_ENOTSUP;
+  }
+#undef MRAG_SKINNY_CASE
+  MRAG_LAUNCH_CHECK();
+  MRAG_COUNT(MRAG_K_GEMM_SKINNY);
+  return MRAG_OK;
+}
+
 inline bool k320_applies(const mrag_gemm_args* a, int epi) {
   // (the GEGLU projection, N = 2 560 = eight slices, is instantiated and bit-equal but NOT dispatched: 758 vs 683 us -- a tile costs ~12 k cycles here whatever
   // the slice count, so eight passes over the activations lose against the persistent four-wave kernel; N = 960 gains 8 %, N = 320 40 %)
@@ -1669,6 +1801,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
+  if (skinny_applies(a, epi)) return launch_skinny(s, p, epi);       // M <= 256: eight waves split K, no LDS ring (gemm_skinny_kernel)
   if (k320_applies(a, epi)) return launch_k320(s, p, epi);           // K = 320, N = 320 .. 2 560: the weight in registers, activations streamed (gemm_k320_kernel)
   // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
   if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&

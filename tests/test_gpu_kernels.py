@@ -1028,3 +1028,45 @@ def test_topk_prepared_plan_single_launch(hip):
     want_r, want_d = topk_ref.topk(db, qs[:4], 12, "dot", mode="f32chain")
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+
+
+@pytest.mark.parametrize("M,N,K", [(250, 768, 1024), (251, 4096, 1024), (25, 1024, 4096), (16, 2304, 768), (256, 1000, 320), (1, 260, 256), (33, 4100, 2048)])
+def test_gemm_few_rows_k_split(hip, M, N, K):
+    """M <= 256 (CAMA's Perceiver latents / encoder tokens, the retrieval query's embedder): gemm_skinny_kernel -- 32 x 64 output tiles, the workgroup's eight waves
+    split K and meet once in LDS in a fixed order.  Against torch fp32 for every epilogue it carries, ragged M / N (N % 64 != 0, rows past the last tile), strided
+    input / output / residual views, run-to-run bit-equality, and the developer knob back to the 128 x 128 tile (equal within the fp32 summation order)"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    b = torch.randn(N, generator=g).to(DEV, torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    lin = x.float() @ w.float().T
+    cases = {"none": ({}, lin + b.float()), "nobias": (None, lin), "gelu_erf": (dict(epilogue=ops.EPI_GELU_ERF), torch.nn.functional.gelu(lin + b.float())),
+             "gelu_tanh": (dict(epilogue=ops.EPI_GELU_TANH), torch.nn.functional.gelu(lin + b.float(), approximate="tanh")),
+             "silu": (dict(epilogue=ops.EPI_SILU), torch.nn.functional.silu(lin + b.float())),
+             "resid": (dict(epilogue=ops.EPI_RESID, resid=r), (lin + b.float()).to(torch.bfloat16).float() + r.float()),
+             "resid_scaled": (dict(epilogue=ops.EPI_RESID, resid=r, acc_scale=0.25), (0.25 * (lin + b.float())).to(torch.bfloat16).float() + r.float())}
+    for name, (kw, want) in cases.items():
+        with ops.dispatched() as d:
+            got = ops.linear(x, w, None, **{}) if kw is None else ops.linear(x, w, b, **kw)
+        assert d.counts == {"GEMM_SKINNY": 1}, (name, d.counts)
+        rel = ((got.float() - want).norm() / want.norm()).item()
+        assert rel < 4e-3, (name, rel)
+        again = ops.linear(x, w, None) if kw is None else ops.linear(x, w, b, **kw)
+        assert torch.equal(got, again), name                                          # fixed summation order: bit-reproducible
+        ops.TUNING["gemm"] = 1 << 17                                                   # MRAG_GEMM_TUNE_NO_SKINNY
+        try:
+            with ops.dispatched() as d:
+                tiled = ops.linear(x, w, None) if kw is None else ops.linear(x, w, b, **kw)
+        finally:
+            ops.TUNING["gemm"] = 0
+        assert "GEMM_SKINNY" not in d.counts and ((tiled.float() - got.float()).norm() / want.norm()).item() < 4e-3, (name, d.counts)
+    # strided views: A a column slice of a wider buffer, C / resid column slices of wider buffers
+    xa = torch.zeros(M, K + 64, device=DEV, dtype=torch.bfloat16); xa[:, 64:] = x
+    cw = torch.zeros(M, N + 128, device=DEV, dtype=torch.bfloat16)
+    rw = torch.zeros(M, N + 64, device=DEV, dtype=torch.bfloat16); rw[:, 64:] = r
+    with ops.dispatched() as d:
+        ops.linear(xa[:, 64:], w, b, epilogue=ops.EPI_RESID, resid=rw[:, 64:], out=cw[:, 64:64 + N])
+    assert d.counts == {"GEMM_SKINNY": 1}, d.counts
+    assert torch.equal(cw[:, 64:64 + N], ops.linear(x, w, b, epilogue=ops.EPI_RESID, resid=r)) and cw[:, :64].abs().max().item() == 0 and cw[:, 64 + N:].abs().max().item() == 0

@@ -109,6 +109,13 @@ int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_byte
 /*     src/projects/condition/encoders/resampler.py:45-52,93-105,157-166;     */
 /*   nn.TransformerEncoder in_proj/out_proj/linear1/linear2                   */
 /*     src/projects/condition/module.py:305; diffusers CogVideoXBlock FF.     */
+/* Summation order: fp32 accumulation over K in ascending 32-deep MFMA steps   */
+/* (every tiled kernel: the same bits whichever tile a size selects); a        */
+/* problem of M <= 256 rows (CAMA's latents / encoder tokens, a query's        */
+/* embedder) runs on the few-row kernel, whose eight waves take every eighth   */
+/* K-step and add their partial sums in wave order -- bit-reproducible, but a   */
+/* row computed inside a batch of <= 256 rows and inside a larger one may      */
+/* differ in the last bit of the bf16 result.                                  */
 /* ------------------------------------------------------------------------ */
 enum mrag_epilogue {
   MRAG_EPI_NONE = 0,        /* C = acc + bias                                         */
@@ -167,7 +174,8 @@ typedef struct mrag_gemm_args {
 } mrag_gemm_args;
 enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8,
        MRAG_GEMM_TUNE_NO_W4 = 1 << 16, /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */
-       MRAG_GEMM_TUNE_NO_SKINNY = 1 << 17 /* keep few-row problems (M <= 256) on the 128x128 tile instead of the K-split few-row kernel */ };
+       MRAG_GEMM_TUNE_NO_SKINNY = 1 << 17, /* keep few-row problems (M <= 256) on the 128x128 tile instead of the K-split few-row kernel */
+       MRAG_GEMM_TUNE_SKINNY_8 = 1 << 18 /* few-row kernel: eight waves x 64 columns also for K >= 2 048 (shipped there: sixteen waves x 32 columns) */ };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */

@@ -1510,17 +1510,19 @@ __global__ __launch_bounds__(640) void gemm_k320_kernel(const GemmP p) {
 // fragments straight from L2 / HBM into MFMA operands -- no LDS staging, no barrier in the loop, dozens of independent 16-byte loads in flight per lane -- and the
 // eight partial tiles meet once in LDS, where they are added in wave order (a fixed order: bit-reproducible; NOT the summation order of the tiled kernels, so
 // the last bits differ from theirs).  Grid = ceil(M / 32) x ceil(N / 64) workgroups: 128-512 for CAMA's shapes.  Epilogue and rounding points: epilogue_direct's.
-constexpr int SKM_ROWS = 32, SKM_COLS = 64, SKM_WAVES = 8;
+// Long K (>= 2 048: the feed-forward's second projection) takes SIXTEEN waves over a 32 x 32 tile instead: half the K-steps per wave, twice the workgroups.
+constexpr int SKM_ROWS = 32;
 
-template <int EPI>
-__global__ __launch_bounds__(64 * SKM_WAVES) void gemm_skinny_kernel(const GemmP p) {
+template <int EPI, int NWV, int COLS>
+__global__ __launch_bounds__(64 * NWV) void gemm_skinny_kernel(const GemmP p) {
+  constexpr int TJ = COLS / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* part = (float*)smem;                                   // [SKM_WAVES][SKM_ROWS][SKM_COLS]
+  float* part = (float*)smem;                                   // [NWV][SKM_ROWS][COLS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long m0 = (long long)blockIdx.y * SKM_ROWS, n0 = (long long)blockIdx.x * SKM_COLS;
+  const long long m0 = (long long)blockIdx.y * SKM_ROWS, n0 = (long long)blockIdx.x * COLS;
   const int r = lane & 15, kc = (lane >> 4) * 8;
   const bf16_t* ap[2];
-  const bf16_t* wp[4];
+  const bf16_t* wp[TJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     long long m = m0 + i * 16 + r;
@@ -1528,53 +1530,54 @@ __global__ __launch_bounds__(64 * SKM_WAVES) void gemm_skinny_kernel(const GemmP
     ap[i] = p.A + m * p.lda + kc;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TJ; ++j) {
     long long n = n0 + j * 16 + r;
     n = n < p.N ? n : p.N - 1;
     wp[j] = p.W + n * p.ldw + kc;
   }
-  f32x4 acc[2][4];
+  f32x4 acc[2][TJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nks = (int)(p.K / 32);
-  auto steps = [&](auto U, const int ks0) __attribute__((always_inline)) {       // U K-steps of this wave from ks0: all loads first (6 U independent 16-byte loads in flight)
+  auto steps = [&](auto U, const int ks0) __attribute__((always_inline)) {       // U K-steps of this wave from ks0: all loads first ((2 + TJ) U independent 16-byte loads in flight)
     constexpr int u_n = decltype(U)::value;
-    bf16x8 a[u_n][2], w[u_n][4];
+    bf16x8 a[u_n][2], w[u_n][TJ];
 #pragma unroll
     for (int u = 0; u < u_n; ++u) {
-      const int k = (ks0 + u * SKM_WAVES) * 32;
+      const int k = (ks0 + u * NWV) * 32;
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[u][i] = *(const bf16x8*)(ap[i] + k);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[u][j] = *(const bf16x8*)(wp[j] + k);
+      for (int j = 0; j < TJ; ++j) w[u][j] = *(const bf16x8*)(wp[j] + k);
     }
 #pragma unroll
     for (int u = 0; u < u_n; ++u)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][j], a[u][i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][j], a[u][i], acc[i][j], 0, 0, 0);
   };
   int ks = wave;
-  for (; ks + 3 * SKM_WAVES < nks; ks += 4 * SKM_WAVES) steps(std::integral_constant<int, 4>{}, ks);
-  for (; ks < nks; ks += SKM_WAVES) steps(std::integral_constant<int, 1>{}, ks);
+  for (; ks + 3 * NWV < nks; ks += 4 * NWV) steps(std::integral_constant<int, 4>{}, ks);
+  for (; ks < nks; ks += NWV) steps(std::integral_constant<int, 1>{}, ks);
   // accumulator layout: lane owns row i * 16 + (lane & 15), columns j * 16 + (lane >> 4) * 4 + {0..3}
-  float* mine = part + wave * (SKM_ROWS * SKM_COLS);
+  float* mine = part + wave * (SKM_ROWS * COLS);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(f32x4*)(mine + (i * 16 + r) * SKM_COLS + j * 16 + (lane >> 4) * 4) = acc[i][j];
+    for (int j = 0; j < TJ; ++j) *(f32x4*)(mine + (i * 16 + r) * COLS + j * 16 + (lane >> 4) * 4) = acc[i][j];
   __syncthreads();
-  // 512 threads x 4 consecutive columns = the 32 x 64 tile
-  const int row = tid >> 4, col = (tid & 15) * 4;
+  // one thread per 4 consecutive columns of the 32 x COLS tile
+  if (tid >= SKM_ROWS * COLS / 4) return;
+  const int row = tid / (COLS / 4), col = (tid % (COLS / 4)) * 4;
   const long long m = m0 + row, n = n0 + col;
   if (m >= p.M || n >= p.N) return;
-  f32x4 t = *(const f32x4*)(part + row * SKM_COLS + col);
+  f32x4 t = *(const f32x4*)(part + row * COLS + col);
 #pragma unroll
-  for (int w8 = 1; w8 < SKM_WAVES; ++w8) {
-    const f32x4 u = *(const f32x4*)(part + w8 * (SKM_ROWS * SKM_COLS) + row * SKM_COLS + col);
+  for (int w8 = 1; w8 < NWV; ++w8) {
+    const f32x4 u = *(const f32x4*)(part + w8 * (SKM_ROWS * COLS) + row * COLS + col);
     t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
   }
   float v[4] = {t[0], t[1], t[2], t[3]};
@@ -1611,16 +1614,24 @@ inline bool skinny_applies(const mrag_gemm_args* a, int epi) {
 }
 
 inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
-  const dim3 grid((unsigned)((p.N + SKM_COLS - 1) / SKM_COLS), (unsigned)((p.M + SKM_ROWS - 1) / SKM_ROWS)), block(64 * SKM_WAVES);
-  const size_t lds = (size_t)SKM_WAVES * SKM_ROWS * SKM_COLS * sizeof(float);
-#define MRAG_SKINNY_CASE(E)                                                                            \
-  case E: {                                                                                            \
-    auto kfn = gemm_skinny_kernel<E>;                                                                  \
+  // 16 waves x 32 columns where K is long and the 8-wave grid would leave most CUs idle ([250 x 1024 x 4096] 25.5 -> 20.1 us, [64 x 4096 x 4096] 26.1 -> 20.7;
+  // a grid that already fills the chip loses: [128 x 4096 x 4096] 26.6 -> 34.6; profiles/r5_gemm_skinny_sweep.txt).  MRAG_GEMM_TUNE_SKINNY_8: the 8-wave form always (A/B runs)
+  const long long wg8 = ((p.M + SKM_ROWS - 1) / SKM_ROWS) * ((p.N + 63) / 64);
+  const bool sixteen = p.K >= 2048 && p.N >= 1024 && wg8 < 256 && !(p.tuning & MRAG_GEMM_TUNE_SKINNY_8);
+  const int cols = sixteen ? 32 : 64, nw = sixteen ? 16 : 8;
+  const dim3 grid((unsigned)((p.N + cols - 1) / cols), (unsigned)((p.M + SKM_ROWS - 1) / SKM_ROWS)), block(64 * nw);
+  const size_t lds = (size_t)nw * SKM_ROWS * cols * sizeof(float);
+#define MRAG_SKINNY_LAUNCH(E, W, C)                                                                    \
+  {                                                                                                    \
+    auto kfn = gemm_skinny_kernel<E, W, C>;                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
-    break;                                                                                             \
   }
+#define MRAG_SKINNY_CASE(E)                                                                            \
+  case E:                                                                                              \
+    if (sixteen) MRAG_SKINNY_LAUNCH(E, 16, 32) else MRAG_SKINNY_LAUNCH(E, 8, 64)                        \
+    break;
   switch (epi) {
     MRAG_SKINNY_CASE(MRAG_EPI_NONE)
     MRAG_SKINNY_CASE(MRAG_EPI_GELU_TANH)
@@ -1630,6 +1641,7 @@ inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
     default: return MRAG_ENOTSUP;
   }
 #undef MRAG_SKINNY_CASE
+#undef MRAG_SKINNY_LAUNCH
   MRAG_LAUNCH_CHECK();
   MRAG_COUNT(MRAG_K_GEMM_SKINNY);
   return MRAG_OK;

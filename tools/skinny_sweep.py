@@ -19,7 +19,7 @@ for M, N, K, kind in SHAPES:
     ref = x.float() @ w.float().T + b.float()
     ref = torch.nn.functional.gelu(ref) if kind == "gelu" else ref + r.float() if kind == "resid" else ref
     out = []
-    for name, t in (("few-row", 0), ("128x128", NO_SKINNY)):
+    for name, t in (("few-row", 0), ("128x128", NO_SKINNY)) + ((("few-row 8 waves", 1 << 18),) if K >= 2048 else ()):
         ops.TUNING["gemm"] = t
         with ops.dispatched() as d:
             y = ops.linear(x, w, b, **kw)

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 // Narrow rows (round 5): the UNets' LayerNorms are over C = 320 / 640 / 1 280 channels of 258 048 / 64 512 / 16 128 pixel rows.  One wave per row leaves 24 of
 // 64 lanes idle at C = 320 and retires a wave per 640 bytes (92 us = 3.6 TB/s at [258 048, 320]).  Here a row belongs to LPR = 8 / 16 / 32 lanes (CH = 5 sixteen-byte
 // chunks each, chunk index = sub-lane + LPR c: the LPR lanes of a row read 16 LPR contiguous bytes per instruction), so a wave normalises 8 / 4 / 2 rows with every
-// lane busy.  Plain LayerNorm only (gamma / beta; no AdaLN modulation, no output row remap, no RMS form: those stay on layernorm_kernel); the same two-pass
+// lane busy.  Plain LayerNorm only (gamma / beta, output row remap; no AdaLN modulation, no RMS form: those stay on layernorm_kernel); the same two-pass
 // statistics in registers, summed over another lane partition -- results agree with layernorm_kernel to fp32 rounding of the statistics.
 template <int LPR, int CH>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnP p) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const LnP p) {
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   const float rstd = rsqrtf(sq / (float)p.D + p.eps);
-  bf16_t* y = p.y + row * p.ldy;
+  bf16_t* y = p.y_rpb > 0 ? p.y + (long long)((unsigned)row / (unsigned)p.y_rpb) * p.y_bstride + (long long)((unsigned)row % (unsigned)p.y_rpb) * p.ldy : p.y + row * p.ldy;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int idx = (sub + LPR * c) * 8;
@@ -243,9 +243,10 @@ extern "C" int mrag_layernorm_bf16(void* stream, const mrag_ln_args* a) {
   if (p.y_rpb < 0 || (p.y_rpb > 0 && p.y_bstride % 8 != 0)) return MRAG_EINVAL;
   const dim3 grid((unsigned)((a->rows + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (!a->shift0 && p.y_rpb == 0 && !a->rms && (a->D == 320 || a->D == 640 || a->D == 1280) && a->rows >= 1024) {   // narrow rows: several rows per wave
+  if (!a->shift0 && !a->rms && (a->D == 320 || a->D == 640 || a->D == 1280 || a->D == 1024) && a->rows >= 1024) {   // narrow rows: several rows per wave
     if (a->D == 320) MRAG_LAUNCH((layernorm_rows_kernel<8, 5>), dim3((unsigned)((a->rows + 31) / 32)), block, 0, s, p);
     else if (a->D == 640) MRAG_LAUNCH((layernorm_rows_kernel<16, 5>), dim3((unsigned)((a->rows + 15) / 16)), block, 0, s, p);
+    else if (a->D == 1024) MRAG_LAUNCH((layernorm_rows_kernel<16, 8>), dim3((unsigned)((a->rows + 15) / 16)), block, 0, s, p);   // CAMA's media rows (15 680 x 1 024, into the K/V concat buffer): 36 -> ? us
     else MRAG_LAUNCH((layernorm_rows_kernel<32, 5>), dim3((unsigned)((a->rows + 7) / 8)), block, 0, s, p);
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_LAYERNORM_ROWS);

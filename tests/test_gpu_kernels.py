@@ -561,16 +561,16 @@ def test_attention_baseline_shape_split_tail_properties(hip):
 
 
 # ---------------------------------------------------------------------------------------------- norms
-@pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104), (1027, 320), (2050, 640), (1029, 1280)])
+@pytest.mark.parametrize("rows,D", [(37, 1024), (300, 3072), (9, 64), (5, 320), (4, 4104), (1027, 320), (2050, 640), (1029, 1280), (1571, 1024)])
 def test_layernorm(hip, rows, D):
-    """(the last three: the narrow-row kernel -- 8 / 4 / 2 rows per wave at C = 320 / 640 / 1 280 from 1 024 rows up -- with ragged last workgroups)"""
+    """(the last four: the narrow-row kernel -- 8 / 4 / 2 / 4 rows per wave at C = 320 / 640 / 1 280 / 1 024 from 1 024 rows up -- with ragged last workgroups)"""
     from motionrag_amd import ops
     g = torch.Generator().manual_seed(rows)
     x, w, b = bf(torch.randn(rows, D, generator=g) * 2 + 0.5), bf(1 + 0.1 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
     want = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
     with ops.dispatched() as d:
         got = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
-    assert d.counts == ({"LAYERNORM_ROWS": 1} if rows >= 1024 and D in (320, 640, 1280) else {"LAYERNORM": 1}), d.counts
+    assert d.counts == ({"LAYERNORM_ROWS": 1} if rows >= 1024 and D in (320, 640, 1280, 1024) else {"LAYERNORM": 1}), d.counts
     close(got, want, scale=1.0)
     close(ops.layernorm(x.to(DEV), None, None, 1e-6), torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6), scale=1.0)
     # a strided input / output view (a column slice of a wider buffer) takes the same kernels
@@ -599,6 +599,17 @@ def test_layernorm_adaln_modulation_and_batched_output(hip):
     ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_batched=buf[:, 9:])
     close(buf[:, 9:], ln, scale=1.0)
     assert buf[:, :9].abs().max().item() == 0
+    # the narrow-row kernel with the same remap: CAMA's media rows (N clips x 1 568 tokens x 1 024) land in front of the latent rows of the K / V concat buffer
+    N, T, Dm = 3, 523, 1024
+    xm = bf(torch.randn(N, T, Dm, generator=g) * 1.5 - 0.2)
+    wm, bm = bf(1 + 0.1 * torch.randn(Dm, generator=g)), bf(0.1 * torch.randn(Dm, generator=g))
+    cat = torch.zeros(N, T + 25, Dm, dtype=torch.bfloat16, device=DEV)
+    with ops.dispatched() as d:
+        ops.layernorm(xm.to(DEV), wm.to(DEV), bm.to(DEV), 1e-5, out_batched=cat[:, :T])
+    assert d.counts == {"LAYERNORM_ROWS": 1}, d.counts
+    close(cat[:, :T], torch.nn.functional.layer_norm(xm.float(), (Dm,), wm.float(), bm.float(), 1e-5), scale=1.0)
+    assert cat[:, T:].abs().max().item() == 0
+    assert torch.equal(cat[:, :T].reshape(N * T, Dm), ops.layernorm(xm.to(DEV).view(N * T, Dm), wm.to(DEV), bm.to(DEV), 1e-5))
 
 
 def test_qknorm_rope(hip):

@@ -1,7 +1,7 @@
 # round-5 final evidence: smoke(), the full GPU suite, the judged command under rocprofv3 (tools/run_final.sh) and unprofiled on the same box
 mkdir -p gpurun_out/r5_final
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee gpurun_out/r5_final/smoke.log
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/r5_final/tests.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -9 | tee gpurun_out/r5_final/tests.log
 bash tools/run_final.sh r5_final > gpurun_out/r5_final/run_final.log 2>&1
 timeout 900 python bench.py > gpurun_out/r5_final/bench_unprofiled.json 2> gpurun_out/r5_final/bench_unprofiled.err
 python - <<EOF2

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256 * WN) void topk_mfma_kernel(const TopkMP p) {
 }
 
 // the fan-out plan: queries per workgroup (32 TN), parts (workgroups along the table), rows per part
-struct MfmaPlan { int TN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
+struct MfmaPlan { int TN, WN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
 inline MfmaPlan plan_mfma(long long n_rows, int nq) {
   MfmaPlan pl;
   const int qtiles = (nq + 31) / 32;
@@ -800,6 +800,9 @@ inline MfmaPlan plan_mfma(long long n_rows, int nq) {
   parts = parts < 1 ? 1 : parts > blocks ? blocks : parts;
   const long long bpp = (blocks + parts - 1) / parts;
   pl.parts = (int)((blocks + bpp - 1) / bpp);
+  // waves: the 256-query workgroup is eight waves (two query groups of four tiles); so is the 128-query workgroup of a ONE-row-block plan (two groups of two tiles):
+  // its 64 MFMAs per slab and wave were the long pole of a 10 000-row search (42 us on 158 workgroups), and two waves per SIMD halve them
+  pl.WN = (pl.TN == 8 || (pl.TN == 4 && bpp == 1)) ? 2 : 1;
   pl.rows_per_part = (int)(bpp * pl.RB);
   pl.bytes = 2 * (((size_t)nq * sizeof(float) + 255) / 256 * 256) + (size_t)nq * pl.parts * 16 * sizeof(Cand);   // |q|^2, shared thresholds, per-workgroup lists
   return pl;
@@ -890,14 +893,14 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
     MRAG_LAUNCH_CHECK();
     const dim3 mgrid(pl.parts, pl.gy);
 #define MRAG_TOPK_MFMA(M, T, W)                                                                                        \
-    if (metric == M && pl.TN == T * W) {                                                                               \
+    if (metric == M && pl.TN == T * W && pl.WN == W) {                                                                 \
       auto kfn = topk_mfma_kernel<M, T, W>;                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
       if (e != hipSuccess) return (int)e;                                                                              \
       MRAG_LAUNCH(kfn, mgrid, dim3(256 * W), pl.lds, s, m);                                                            \
     }
-    MRAG_TOPK_MFMA(0, 1, 1) MRAG_TOPK_MFMA(0, 2, 1) MRAG_TOPK_MFMA(0, 4, 1) MRAG_TOPK_MFMA(0, 4, 2)   // (256 queries per workgroup: eight waves of four tiles)
-    MRAG_TOPK_MFMA(1, 1, 1) MRAG_TOPK_MFMA(1, 2, 1) MRAG_TOPK_MFMA(1, 4, 1) MRAG_TOPK_MFMA(1, 4, 2)
+    MRAG_TOPK_MFMA(0, 1, 1) MRAG_TOPK_MFMA(0, 2, 1) MRAG_TOPK_MFMA(0, 4, 1) MRAG_TOPK_MFMA(0, 4, 2) MRAG_TOPK_MFMA(0, 2, 2)   // (256 queries per workgroup: eight waves of four tiles)
+    MRAG_TOPK_MFMA(1, 1, 1) MRAG_TOPK_MFMA(1, 2, 1) MRAG_TOPK_MFMA(1, 4, 1) MRAG_TOPK_MFMA(1, 4, 2) MRAG_TOPK_MFMA(1, 2, 2)
 #undef MRAG_TOPK_MFMA
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_TOPK_MFMA);

@@ -706,6 +706,81 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
 #endif
     return;
   }
+  // ---- the 256x320 tile (TN = 5: 80 columns = 160 bytes per wave row; the UNets' level-0 convolutions and linears, N = 320 / 960): the same staging in two
+  // halves of 64 rows (8 waves x 64 x 176 B fit the operand stages; 128 rows would not).  In the row layout ten lanes hold a 160-byte row segment, so a store /
+  // residual-load instruction moves 6.4 whole segments instead of 8-byte pieces of 16 rows -- the direct form cost the residual convolutions ~100 us each at level 0.
+  constexpr bool STAGED5 = (TM == 8 && TN == 5 && WM == 2 && WN == 4 && !SK);
+  constexpr bool EPI5 = (EPI == MRAG_EPI_NONE || EPI == MRAG_EPI_GELU_TANH || EPI == MRAG_EPI_GELU_ERF || EPI == MRAG_EPI_SILU || EPI == MRAG_EPI_RESID);
+  if constexpr (STAGED5 && EPI5) {
+    if (p.staged) {
+      __syncthreads();   // every wave is done with the operand stages that the per-wave regions overlay
+      const long long n0w = bn0 + wn * 80;
+      if (n0w + 80 <= p.N) {
+        constexpr int ROWB5 = 176;                      // 160 + 16: the 8-byte writes of 16 rows spread over the banks
+        char* wbase = smem + wave * (64 * ROWB5);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              const long long n = n0w + j * 16 + frag_q * 4;
+              const f32x4 a4 = acc[half * 4 + i][j];
+              float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+              if (p.bias) {
+                const u32x2 bb = *(const u32x2*)(p.bias + n);
+                v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+                v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = epi_act<EPI>(v[e]);
+              if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.acc_scale;
+              }
+              u32x2 out;
+              out[0] = pack_bf2(v[0], v[1]);
+              out[1] = pack_bf2(v[2], v[3]);
+              *(u32x2*)(wbase + (i * 16 + frag_row) * ROWB5 + (j * 16 + frag_q * 4) * 2) = out;
+            }
+          }
+          // row layout: chunk index c = t * 64 + lane of the half's 64 x 10 sixteen-byte chunks
+          const long long mrow0 = bm0 + wm * 128 + half * 64;
+#pragma unroll
+          for (int tb = 0; tb < 10; tb += 5) {            // (five residual vectors in flight: ten cost the 160 accumulator registers a spill)
+            u32x4 rpre[5];
+            if constexpr (EPI == MRAG_EPI_RESID) {
+#pragma unroll
+              for (int t = 0; t < 5; ++t) {
+                const unsigned c = (unsigned)((tb + t) * 64 + lane), row = (c * 6554u) >> 16, ch = c - row * 10u;
+                const long long m = mrow0 + row;
+                rpre[t] = m < p.M ? *(const u32x4*)(p.resid + m * p.ldr + n0w + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+              const unsigned c = (unsigned)((tb + t) * 64 + lane), row = (c * 6554u) >> 16, ch = c - row * 10u;
+              const long long m = mrow0 + row;
+              u32x4 val = *(const u32x4*)(wbase + row * ROWB5 + ch * 16);
+              if constexpr (EPI == MRAG_EPI_RESID) {
+                const u32x4 rr = rpre[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float lo = __uint_as_float(val[e] << 16) + __uint_as_float(rr[e] << 16);
+                  const float hi = __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u);
+                  val[e] = pack_bf2(lo, hi);
+                }
+              }
+              if (m < p.M) *(u32x4*)(p.C + m * p.ldc + n0w + ch * 8) = val;
+            }
+          }
+        }
+      } else {
+        epilogue_direct<TM, TN, EPI>(p, acc, bm0, bn0, wm * TM * 16, wn * TN * 16, lane);
+      }
+      return;
+    }
+  }
   if constexpr (is_geglu<EPI> && TN % 2 != 0) {
     return;   // never dispatched: the value / gate pairing needs an even number of 16-column tiles per wave
   } else if constexpr (is_geglu<EPI>) {

@@ -66,6 +66,7 @@ struct GemmP {
   float acc_scale;    // MRAG_EPI_RESID: C = resid + acc_scale * (acc + bias) (1 unless the caller blends: AlphaBlender folded into a residual branch)
   float* sk_part; unsigned* sk_ticket;
   int sk_main, sk_rem, sk_units, sk_maxparts;
+  int cv_lds;         // CONV != 0: byte offset of the parked per-lane tap state in LDS (behind the operand stages / staged-epilogue region)
   int cv_tf;          // CONV == 1 with three temporal taps (causal 3x3x3): output frames per sample (input holds cv_tf + 2 frames per sample); 0 = 2-D
   long long cv_fs;    // elements between consecutive input frames
 };
@@ -232,11 +233,32 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
   const int tile_m = first_m + (wg % gw) % gsz, tile_n = (wg % gw) / gsz;
   const long long bm0 = (long long)tile_m * BM, bn0 = (long long)tile_n * BN;
 
-  // ---- per-lane DMA source pointers (k = 0), one per piece this wave stages
-  const bf16_t* gsrc[PPW];
+  // ---- per-lane DMA sources (k = 0), one per piece this wave stages.
+  // Plain GEMM: a 64-bit row pointer per piece.  Convolutions keep NO pointer: the 8-wave 256x256 tile runs at exactly 256 VGPRs (128 accumulators, two sets
+  // of 48 fragment registers), and the 36 registers of row pointers + tap cursors the first form kept per lane (gsrc, cv_y, cv_x, cv_src, cv_step) were
+  // 44-51 spilled VGPRs: two scratch reloads per K-tile, each behind an `s_waitcnt vmcnt(0)` that also drains the LDS-DMA ring (round-5 review;
+  // tools/check_scratch.py).  Now, per A piece: the current tap's source as ONE 32-bit offset in 16-byte units relative to a workgroup-uniform base
+  // (`cv_base`, an SGPR pair), and per W piece a 32-bit byte offset for the scalar-base form of the DMA: 8 registers.  What a tap change needs to recompute
+  // the offsets -- the tap-independent position (y << 16 | x, or the frame index) and the sample's offset, two words per piece -- is parked in LDS
+  // (lane-linear words behind the operand stages, GemmP::cv_lds): read back once per tap by ds_read, which counts on lgkmcnt and leaves the DMA ring alone.
   constexpr int APW = BM / 8 / NW;          // a wave's first APW pieces are A rows (piece = wave + i * NW < BM / 8)
   static_assert((BM / 8) % NW == 0, "A pieces split evenly over the waves");
-  int cv_y[APW], cv_x[APW];                 // conv modes: per A piece
+  static_assert(CONV == 0 || APW <= 4, "the parked conv state is read back by four hand-written statements");
+  constexpr int CV_NONE = (int)0x80000000;  // cv_cur: the tap falls outside the image / clip -> the zero row
+  const bf16_t* gsrc[CONV == 0 ? PPW : 1];
+  int cv_cur[CONV != 0 ? APW : 1];
+  const unsigned cv_park = (unsigned)(size_t)smem + (unsigned)p.cv_lds + (unsigned)tid * 4u;   // word k of this lane at + k * NW * 256: k = 2 i (position), 2 i + 1 (sample offset)
+  auto cv_put = [&](int k, int v) { *(int*)(smem + p.cv_lds + (k * NW * 64 + tid) * 4) = v; };
+  unsigned cv_woff[CONV != 0 ? PPW - APW : 1];
+  const bf16_t* cv_base = p.A;              // workgroup-uniform
+  const int cv_c8 = (int)(p.cv_C >> 3);     // 16-byte units per pixel
+  if constexpr (CONV == 1) {                // the sample (input frame stack position) of the tile's first row
+    const long long n0 = bm0 / ((long long)p.cv_Wo * p.cv_Ho);
+    const long long n0_in = p.cv_tf ? n0 + 2 * (n0 / p.cv_tf) : n0;
+    cv_base = p.A + n0_in * p.cv_H * p.cv_W * p.cv_C;
+  } else if constexpr (CONV == 2) {
+    cv_base = p.A + bm0 * p.cv_C;
+  }
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int piece = wave + i * NW;  // pieces [0, BM/8) are A rows, the rest W rows
@@ -245,25 +267,27 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
     if (piece < BM / 8) {
       long long row = bm0 + r;
       row = row < p.M ? row : p.M - 1;  // clamp: tail rows re-read a valid row, stores are masked
-      if constexpr (CONV == 1) {         // row = (n, yo, xo) of the output image: keep (n base, yo*stride - 1, xo*stride - 1)
+      if constexpr (CONV == 1) {         // row = (n, yo, xo) of the output image: keep (yo*stride - pad, xo*stride - pad) and the sample's offset
         const int xo = (int)(row % p.cv_Wo);
         const long long r2 = row / p.cv_Wo;
         const int yo = (int)(r2 % p.cv_Ho);
         const long long n = r2 / p.cv_Ho;
         const long long n_in = p.cv_tf ? n + 2 * (n / p.cv_tf) : n;   // 3-D: sample s's output frame t reads input frames s (T + 2) + t + {0, 1, 2}
-        gsrc[i] = p.A + n_in * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
-        cv_y[i] = yo * p.cv_stride - p.cv_pad;
-        cv_x[i] = xo * p.cv_stride - p.cv_pad;
-      } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row pointer and t
-        gsrc[i] = p.A + row * p.cv_C + chunk * 8;
-        cv_y[i] = (int)((row / p.cv_HW) % p.cv_T);
+        const long long n0 = bm0 / ((long long)p.cv_Wo * p.cv_Ho);
+        const long long n0_in = p.cv_tf ? n0 + 2 * (n0 / p.cv_tf) : n0;
+        cv_put(2 * i, (int)(((unsigned)(yo * p.cv_stride - p.cv_pad) << 16) | ((unsigned)(xo * p.cv_stride - p.cv_pad) & 0xffffu)));
+        cv_put(2 * i + 1, (int)(n_in - n0_in) * (p.cv_H * p.cv_W * cv_c8) + chunk);
+      } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row's offset and t
+        cv_put(2 * i, (int)((row / p.cv_HW) % p.cv_T));
+        cv_put(2 * i + 1, (int)(row - bm0) * cv_c8 + chunk);
       } else {
         gsrc[i] = p.A + row * p.lda + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
       }
     } else {
       long long row = bn0 + (r - BM);
       row = row < p.N ? row : p.N - 1;
-      gsrc[i] = p.W + row * p.ldw + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
+      if constexpr (CONV != 0) cv_woff[i >= APW ? i - APW : 0] = (unsigned)((row * p.ldw + chunk * 8) * 2);   // (< 4 GiB: checked by mrag_conv_bf16)
+      else gsrc[i] = p.W + row * p.ldw + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
     }
   }
 
@@ -280,11 +304,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
 
   // DMA source of piece i for K-tile kt.  Plain GEMM: the row pointer advanced by kt * 64.  Convolutions: K-tile kt is channel
   // block (kt % ctiles) of tap (kt / ctiles); the lane's row is the tap-shifted pixel (or frame), or the zero row outside.
-  // The K-tiles are requested in order (0, 1, 2, ...), so the (tap, channel block) pair is WALKED: per K-tile a piece costs one pointer
-  // increment, and the tap geometry (bounds test, pixel offset, 64-bit multiply) is redone only when the tap changes -- every Cin / 64
-  // K-tiles -- instead of a division by ctiles plus the whole address computation per piece and K-tile.
-  const bf16_t* cv_src[CONV != 0 ? APW : 1];   // per A piece: this lane's source at the current (tap, channel block)
-  int cv_step[CONV != 0 ? APW : 1];            // 64 elements per channel block inside the image, 0 on the zero row
+  // The K-tiles are requested in order (0, 1, 2, ...), so the (tap, channel block) pair is WALKED: the tap geometry (bounds test, pixel
+  // offset) is redone only when the tap changes -- every Cin / 64 K-tiles -- and leaves one 32-bit offset per piece (cv_cur); a K-tile's
+  // request adds the channel block and the workgroup's base to it (a handful of vector instructions per piece, no persistent pointer).
   int cv_kt = -1, cv_tap = 0, cv_cblk = -1;
   auto cv_prepare = [&](int kt) {
     if constexpr (CONV != 0) {
@@ -296,43 +318,47 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
           bool ok;
-          long long off;
+          int off, yx, nb;
+          // (hand-written reads: a compiler-made LDS load would be ordered behind the LDS-DMA pieces in flight -- `s_waitcnt vmcnt(0)`, the drain this form removes)
+          if (i == 0) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(NW * 256) : "memory");
+          else if (i == 1) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(2 * NW * 256), "n"(3 * NW * 256) : "memory");
+          else if (i == 2) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(4 * NW * 256), "n"(5 * NW * 256) : "memory");
+          else asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(6 * NW * 256), "n"(7 * NW * 256) : "memory");
           if constexpr (CONV == 1) {
             const int kt3 = p.cv_tf ? cv_tap / 9 : 0, tap9 = cv_tap - 9 * kt3;   // taps in (kt, ky, kx) order; kt3 = 0 for the 2-D convolution
             const int ky = tap9 / 3, kx = tap9 - 3 * ky;
-            const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
+            const int yi = (yx >> 16) + ky, xi = (int)(short)(yx & 0xffff) + kx;
             ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
-            off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C + kt3 * p.cv_fs;
+            off = nb + ((yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * cv_c8 + kt3 * (int)(p.cv_fs >> 3);
           } else {
-            const int t = cv_y[i] + cv_tap - 1;
+            const int t = yx + cv_tap - 1;
             ok = (unsigned)t < (unsigned)p.cv_T;
-            off = (long long)(cv_tap - 1) * p.cv_HW * p.cv_C;
+            off = nb + (cv_tap - 1) * (int)p.cv_HW * cv_c8;
           }
-          cv_src[i] = ok ? gsrc[i] + off : g_zero_row + (lane & 7) * 8;
-          cv_step[i] = ok ? 64 : 0;
+          cv_cur[i] = ok ? off : CV_NONE;
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < APW; ++i) cv_src[i] += cv_step[i];
       }
     }
   };
-  auto src = [&](int i, int kt) -> const bf16_t* {
+  // request piece i of K-tile kt into `dst` (the piece's 1-KiB slot of a stage).  Convolutions: cv_prepare(kt) ran for this K-tile.
+  auto dma_piece = [&](int i, int kt, char* dst) {
     if constexpr (CONV == 0) {
-      return gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP;
+      glds16(gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP, dst);
     } else {
-      if (i >= APW) return gsrc[i] + (long long)kt * BK;       // weight rows [Cout, taps * Cin] are plain
-      return cv_src[i];                                        // cv_prepare(kt) ran once for this K-tile (issue / the pipelined loop)
+      if (i >= APW) {                                          // weight rows [Cout, taps * Cin] are plain: scalar base + the lane's byte offset
+        glds16_sbase(p.W + (long long)kt * BK, cv_woff[i - APW], (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dst));   // (wave-uniform by construction; the asm wants it in an SGPR)
+      } else {
+        const int c = cv_cur[i];
+        const bf16_t* in_img = cv_base + ((long long)(c + cv_cblk * 8) << 3);
+        glds16(c == CV_NONE ? g_zero_row + (lane & 7) * 8 : in_img, dst);
+      }
     }
   };
   auto issue = [&](int stage, int kt) {
     char* base = smem + stage * STAGE_BYTES;
     cv_prepare(kt);
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wave + i * NW;
-      glds16(src(i, kt), base + piece * 1024);  // wave-uniform base (+ lane*16 by HW)
-    }
+    for (int i = 0; i < PPW; ++i) dma_piece(i, kt, base + (wave + i * NW) * 1024);  // wave-uniform base (+ lane*16 by HW)
   };
 
   issue(0, 0);
@@ -411,7 +437,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
       // the 8 LDS-DMA pieces of tile t+2 go into stage t, ONE PER ROW GROUP between the MFMAs (a burst of 8 costs ~100 cycles
       // each at issue, measured with s_memtime stamps)
       char* nbase = smem + (kt & 1) * STAGE_BYTES;
-#define MRAG_PIECE(I) if (more2) glds16(src(I, kt + 2), nbase + (wave + (I) * NW) * 1024)
+#define MRAG_PIECE(I) if (more2) dma_piece(I, kt + 2, nbase + (wave + (I) * NW) * 1024)
       MRAG_ROW(0, w1, a1[0]);
       if (more) {
         const unsigned sn = smem_u + ((kt + 1) & 1) * STAGE_BYTES;
@@ -1768,7 +1794,11 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
   if ((p.tuning & MRAG_GEMM_TUNE_NO_STAGED) || ((epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) && (p.N % 32 != 0 || (p.tuning & MRAG_GEMM_TUNE_GEGLU_NO_STAGED)))) p.staged = 0;
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
-  const size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
+  size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
+  if constexpr (CONV != 0) {   // eight parked words per lane (gemm_tile: cv_park)
+    p.cv_lds = (int)lds;
+    lds += (size_t)WM * WN * 64 * 32;
+  }
   bool sk_ok = false;
   if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) sk_ok = sk != nullptr;
   if (sk && !sk_ok) return MRAG_ENOTSUP;
@@ -1941,6 +1971,9 @@ extern "C" int mrag_conv_bf16(void* stream, const mrag_conv_args* a) {
   p.N = a->Cout; p.ldc = a->Cout; p.ldr = a->Cout; p.cv_C = a->Cin; p.cv_ctiles = a->Cin / 64;
   p.acc_scale = a->acc_scale == 0.0f ? 1.0f : a->acc_scale;
   hipStream_t s = (hipStream_t)stream;
+  // the implicit GEMM walks its sources with 32-bit offsets (gemm_tile): positions in 16-byte units relative to the first sample a workgroup touches
+  // (at most a few frames apart), weight rows in bytes relative to W
+  if ((long long)a->H * a->Wd * (a->Cin / 8) * 6 >= (1LL << 31) || (long long)a->Cout * 27 * a->Cin * 2 >= (1LL << 32)) return MRAG_ENOTSUP;
   if (a->mode == MRAG_CONV_3X3) {
     if ((a->stride != 1 && a->stride != 2) || (a->upsample != 0 && a->upsample != 1)) return MRAG_EINVAL;
     p.cv_H = a->H; p.cv_W = a->Wd; p.cv_up = a->upsample; p.cv_stride = a->stride;

@@ -483,14 +483,22 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       fp32 matrix product on v_mfma_f32_32x32x2_f32, the table streamed ONCE  */
 /*       per 256 queries.  dist = one fmaf chain per (query, row) over the       */
 /*       features in the order 8c, 8c+4, 8c+1, 8c+5, 8c+2, 8c+6, 8c+3, 8c+7;     */
-/*       "l2" through fmaf(-2, q.x, |q|^2 + |x|^2) with the squared norms as two */
-/*       half-block chains (mode 2 of the oracle).  n_queries >= 16, k <= 16,    */
-/*       else MRAG_ENOTSUP;                                                      */
+/*       "l2": the matrix product SELECTS through fmaf(-2, q.x, |q|^2 + |x|^2)   */
+/*       (squared norms as two half-block chains) -- an expansion whose absolute */
+/*       error is an ulp of |q|^2 + |x|^2 (~1e-4 on unnormalised 768-d data: a   */
+/*       row's distance to itself is noise) -- and the merge step then scores    */
+/*       the 16 nearest candidates AGAIN in the order-1 form (direct sum of      */
+/*       (q - x)^2) and re-ranks them: the distances returned are order 1's bit  */
+/*       for bit, whatever the call shape (round 6; mode 2 of the oracle restates */
+/*       selection + second scoring).  "dot": 1 - chain, no second scoring.       */
+/*       n_queries >= 16, k <= 16, else MRAG_ENOTSUP;                            */
 /*   0 = automatic: 2 where it applies (faster at every table size measured,     */
-/*       1 000 to 10^6 rows), else 1 -- a batch of 16 or more and a single query */
-/*       may therefore differ in the last bits of a distance (never in a rank    */
-/*       whose gap exceeds the fp32 rounding of the sum: tests compare both with */
-/*       the float64 oracle).                                                    */
+/*       1 000 to 10^6 rows), else 1.  "l2": a row gets the same distance from   */
+/*       both; WHICH rows make the list can differ only where the k-th and a     */
+/*       later candidate are closer than the expansion's error AND the later one */
+/*       ranks beyond 16 under it.  "dot": the two orders may differ in the last */
+/*       bits of a distance (never in a rank whose gap exceeds the fp32 rounding */
+/*       of the sum: tests compare both with the float64 oracle).                */
 /* ------------------------------------------------------------------------ */
 /* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
  * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a

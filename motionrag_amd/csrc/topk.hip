@@ -90,6 +90,7 @@ struct TopkP {
   const int* post_group;  // postfilter: group ids consulted AFTER selection (then `group` above is null and the scan excludes nothing)
   unsigned* tickets;    // FUSED: one arrival counter per query tile (zero between calls)
   int wpb;              // waves per workgroup: always 4 (small databases spread by giving each WAVE 16 rows instead of 64: small_db())
+  int rescore;          // merge (LIST = 16, metric l2 of the fan-out form): the 16 nearest candidates are re-scored with the direct sum of (q - x)^2 and re-ranked
 };
 
 // Distance of one (query, row) pair = 16 interleaved fp32 fmaf chains + a fixed 4-level pairwise tree (the definition
@@ -355,8 +356,42 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
   __syncthreads();
   sh[wave * 64 + lane] = run;
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0)
     for (int w = 1; w < nw; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
+  if (p.rescore) {
+    // The fan-out form scores "l2" through |q|^2 + |x|^2 - 2 q.x: good for SELECTING neighbours, but its absolute error is an ulp of |q|^2 + |x|^2
+    // (~1e-4 on unnormalised 768-d embeddings) -- a row's distance to itself came out as 1e-3, near-duplicates as noise or negative, and `_distance`
+    // feeds condition_fusion's weights (src/projects/condition/utils.py:7-36).  So the 16 nearest candidates under that score (always
+    // inside the union of the per-workgroup top-16 lists, whatever the plan) are scored AGAIN here with the scan kernel's definition -- the direct
+    // sum of (q - x)^2 on 16 interleaved fmaf chains + the fixed tree, oracle mode 0 -- and re-ranked: the distances a row gets no longer depend on
+    // the call shape, and ranks among near neighbours follow the exact form.  16 lanes per candidate, 16 candidates per pass of the workgroup.
+    __syncthreads();
+    if (wave == 0) sh[lane] = run;
+    __syncthreads();
+    const int c = tid >> 4, s16 = tid & 15;
+    const Cand cc = sh[c];                                  // (blockDim.x == 256: c < 16)
+    float acc = 0.f;
+    if (cc.r != INT_MAX) {
+      const float* x = p.db + (long long)cc.r * p.dim;
+      const float* qv = p.q + (long long)q * p.dim;
+      for (int k0 = 4 * s16; k0 < p.dim; k0 += 64) {        // chain s16: features 64 j + 4 s16 + {0, 1, 2, 3} (dim % 4 == 0)
+        const float4 xv = *(const float4*)(x + k0), q4 = *(const float4*)(qv + k0);
+        float df = q4.x - xv.x; acc = __builtin_fmaf(df, df, acc);
+        df = q4.y - xv.y; acc = __builtin_fmaf(df, df, acc);
+        df = q4.z - xv.z; acc = __builtin_fmaf(df, df, acc);
+        df = q4.w - xv.w; acc = __builtin_fmaf(df, df, acc);
+      }
+    }
+    acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);   // p[l] += p[l ^ 8], ^ 4, ^ 2, ^ 1
+    __syncthreads();
+    if (s16 == 0 && cc.r != INT_MAX) sh[c].d = acc;
+    __syncthreads();
+    if (wave == 0) {
+      run = lane < 16 ? sh[lane] : inf;
+      run = wave_sort(run, lane);
+    }
+  }
+  if (wave == 0) {
     if (p.post_group) {
       // lancedb's postfilter: the k nearest are final; rows of the excluded group leave the list, the rest keep their order and move up
       const bool ok = lane < p.k && run.r != INT_MAX;
@@ -904,7 +939,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
 #undef MRAG_TOPK_MFMA
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_TOPK_MFMA);
-    p.ws = m.lists; p.slices = pl.parts; p.wpb = 1;
+    p.ws = m.lists; p.slices = pl.parts; p.wpb = 1; p.rescore = metric == 0 ? 1 : 0;
     MRAG_LAUNCH(topk_merge_kernel<16>, dim3(n_queries), dim3(256), 0, s, p);
     MRAG_LAUNCH_CHECK();
     MRAG_COUNT(MRAG_K_TOPK_MERGE);

@@ -25,7 +25,13 @@
  *           features in the order 8c, 8c+4, 8c+1, 8c+5, 8c+2, 8c+6, 8c+3, 8c+7 (c = 0, 1, ..: an MFMA takes one feature from
  *           each half of a 32-byte block); metric "dot": 1 - dot; metric "l2" through the expansion
  *           |q - x|^2 = (|q|^2 + |x|^2) - 2 q.x = fmaf(-2, dot, qq + xx), the squared norms as TWO chains (features 8c + t and
- *           8c + 4 + t, t = 0..3, c ascending) added once (mfma_dot / mfma_sq below).  BIT-EXACT comparable as well.
+ *           8c + 4 + t, t = 0..3, c ascending) added once (mfma_dot / mfma_sq below).  The expansion SELECTS only: its absolute error is
+ *           an ulp of |q|^2 + |x|^2 (a row's distance to itself comes out as ~1e-3 on unnormalised 768-d data, near-duplicates as noise
+ *           or negative), so for metric "l2" the kernel's merge step scores the 16 nearest candidates under the expansion (ties by row;
+ *           fewer when fewer rows pass a prefilter) AGAIN in the mode-0 form and re-ranks them by (mode-0 distance, row); the first k
+ *           are the result (round 6).  Mode 2 restates exactly that; BIT-EXACT comparable as well.
+ *   mode 3: the expansion alone (mode 2 without the second scoring) -- what the fan-out kernel returned in round 5; kept so that a test can show
+ *           what the second scoring removes.
  * Ties: (distance asc, row asc).  Missing results: row = -1, dist = +inf.
  */
 #include <math.h>
@@ -87,7 +93,7 @@ static double score(const float* q, const float* x, int dim, int metric, int mod
   if (mode == 0) {
     const float acc = chain16(q, x, dim, metric);
     return metric == 0 ? (double)acc : (double)(1.0f - acc);
-  } else if (mode == 2) {
+  } else if (mode == 2 || mode == 3) {
     const float dot = mfma_dot(q, x, dim);
     if (metric != 0) return (double)(1.0f - dot);
     const float t = mfma_sq(q, dim) + mfma_sq(x, dim);
@@ -104,7 +110,9 @@ static double score(const float* q, const float* x, int dim, int metric, int mod
 int topk_oracle(const float* db, const int32_t* group, int64_t n_rows, int dim, const float* queries, const int32_t* exclude,
                 int nq, int k, int metric, int mode, int postfilter, int32_t* out_rows, double* out_dist) {
   if (k <= 0 || n_rows <= 0 || nq <= 0) return -1;
-  cand_t* best = (cand_t*)malloc(sizeof(cand_t) * (size_t)k);
+  const int rescore = mode == 2 && metric == 0;      /* the fan-out form's second scoring (header, mode 2) */
+  const int keep = rescore && k < 16 ? 16 : k;       /* candidates selected by the first score */
+  cand_t* best = (cand_t*)malloc(sizeof(cand_t) * (size_t)keep);
   if (!best) return -2;
   for (int qi = 0; qi < nq; ++qi) {
     int nb = 0;
@@ -112,11 +120,21 @@ int topk_oracle(const float* db, const int32_t* group, int64_t n_rows, int dim, 
     for (int64_t r = 0; r < n_rows; ++r) {
       if (!postfilter && exclude && group && group[r] == exclude[qi]) continue;
       cand_t c; c.d = score(q, db + (size_t)r * dim, dim, metric, mode); c.r = (int32_t)r;
-      if (nb == k && !cand_less(c, best[k - 1])) continue;
-      int pos = nb < k ? nb : k - 1;           /* insertion into the sorted list */
+      if (nb == keep && !cand_less(c, best[keep - 1])) continue;
+      int pos = nb < keep ? nb : keep - 1;     /* insertion into the sorted list */
       while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
       best[pos] = c;
-      if (nb < k) ++nb;
+      if (nb < keep) ++nb;
+    }
+    if (rescore) {                               /* mode-0 distances of the selected candidates, re-ranked by (distance, row); the first k stay */
+      for (int j = 0; j < nb; ++j) best[j].d = (double)chain16(q, db + (size_t)best[j].r * dim, dim, 0);
+      for (int j = 1; j < nb; ++j) {
+        const cand_t c = best[j];
+        int pos = j;
+        while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
+        best[pos] = c;
+      }
+      if (nb > k) nb = k;
     }
     if (postfilter && exclude && group) {        /* drop the excluded rows from the selected list; survivors keep their order */
       int w = 0;

@@ -22,7 +22,8 @@ def build() -> str:
 def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=None, exclude=None, mode: str = "f32chain",
          postfilter: bool = False):
     """returns (rows int32 [Q, k], dist float64 [Q, k]); mode 'f32chain' (bit-comparable with the HIP scan kernel: fewer than 16 queries per
-    call), 'f32mfma' (bit-comparable with the HIP fan-out kernel: 16 or more queries per call) or 'f64'.
+    call), 'f32mfma' (bit-comparable with the HIP fan-out kernel: 16 or more queries per call; metric l2: selection by the expansion, then the 16
+    nearest candidates scored again in the f32chain form), 'f32mfma_raw' (the expansion alone: what round 5's kernel returned) or 'f64'.
     `postfilter`: lancedb's `where(..., prefilter=False)` order (topk_oracle.c header)."""
     lib = ctypes.CDLL(build())
     db = np.ascontiguousarray(db, dtype=np.float32)
@@ -39,7 +40,7 @@ def topk(db: np.ndarray, queries: np.ndarray, k: int, metric: str = "l2", group=
     lib.topk_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     rc = lib.topk_oracle(db.ctypes.data_as(ctypes.c_void_p), gp, n, d, queries.ctypes.data_as(ctypes.c_void_p), ep, q, k,
-                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1, "f32mfma": 2}[mode], int(bool(postfilter)), rows.ctypes.data_as(ctypes.c_void_p),
+                         {"l2": 0, "dot": 1}[metric], {"f32chain": 0, "f64": 1, "f32mfma": 2, "f32mfma_raw": 3}[mode], int(bool(postfilter)), rows.ctypes.data_as(ctypes.c_void_p),
                          dist.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
         raise RuntimeError(f"topk_oracle rc={rc}")

@@ -189,6 +189,27 @@ def test_topk_oracle_c_vs_numpy(metric):
     np.testing.assert_array_equal(di, dc)
 
 
+def test_topk_fanout_l2_second_scoring_removes_the_cancellation():
+    """the fan-out form scores l2 as |q|^2 + |x|^2 - 2 q.x -- on unnormalised 768-d N(0, 1) embeddings a row's distance to itself came
+    out as ~1e-3, near-duplicates as noise or negative.  Mode f32mfma_raw keeps that arithmetic; mode f32mfma (= the kernel since round 6) scores the 16
+    selected candidates again in the direct form: self-distance exactly 0, nothing negative, the distances of the scan form (f32chain) bit for bit."""
+    rng = np.random.default_rng(11)
+    db = rng.standard_normal((400, 768)).astype(np.float32)
+    db[1] = db[0] + np.float32(9.2e-5) * rng.standard_normal(768).astype(np.float32)     # a near-duplicate: true distance ~6.5e-6
+    q = db[:8].copy()
+    raw_r, raw_d = topk_ref.topk(db, q, 12, "l2", mode="f32mfma_raw")
+    new_r, new_d = topk_ref.topk(db, q, 12, "l2", mode="f32mfma")
+    ch_r, ch_d = topk_ref.topk(db, q, 12, "l2", mode="f32chain")
+    f64_r, f64_d = topk_ref.topk(db, q, 12, "l2", mode="f64")
+    assert np.abs(raw_d[:, 0]).max() > 1e-5                       # the expansion: self-distance is rounding noise of |q|^2 + |x|^2 ...
+    assert np.all(new_d[:, 0] == 0.0) and np.all(new_r[:, 0] == np.arange(8))   # ... the second scoring: exactly 0, the row itself first
+    assert np.all(new_d >= 0.0)
+    np.testing.assert_array_equal(new_r, ch_r)                    # well-separated neighbours: the same rows as the scan form ...
+    np.testing.assert_array_equal(new_d, ch_d)                    # ... and the same bits (one definition of a row's distance whatever the call shape)
+    np.testing.assert_array_equal(new_r, f64_r)
+    assert abs(new_d[0, 1] - f64_d[0, 1]) < 1e-9 and abs(raw_d[0, 1] - f64_d[0, 1]) > 1e-6   # the near-duplicate: 6.5e-6 exact vs noise
+
+
 def multi_clip_db(rng, n_videos=50, clips=6, dim=64, spread=0.05):
     """a database in which every video contributes `clips` near-duplicate clips (the multi-clip-per-video datasets MotionRAG retrieves from):
     a query built from one clip has its own video's other clips among its nearest rows, so lancedb's post-filter and a pre-filter disagree"""

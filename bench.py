@@ -158,12 +158,13 @@ def profiler_attached() -> bool:
 def measured_ceilings(dev, seconds: float = 1.0):
     """What THIS box sustains, measured after the timed region (same power state), printed beside the nominal peaks as `roofline.ceilings`:
       mfma_bf16_sustained_tflops  the library's register-resident 16x16x32 MFMA loop on random operand bits (csrc/probe.hip; no memory traffic)
-      d2d_copy_TBps               a device-to-device copy of 1 GiB, bytes read + bytes written per second
+      stream_copy_TBps            the library's grid-stride 16-byte copy of 1 GiB (csrc/probe.hip), bytes read + bytes written per second: the HBM ceiling
+      d2d_copy_TBps               torch's `dst.copy_(src)` on the same buffers (what round 5 quoted; slower than the library's own streaming kernels)
       library_gemm_tflops         torch.mm (hipBLASLt / rocBLAS: a measured LIBRARY ceiling, NOT the product path) at the DiT's four GEMM shapes
     None for a leg that failed; never fatal for the headline line."""
     import ctypes
     from motionrag_amd import _lib
-    out = {"mfma_bf16_sustained_tflops": None, "d2d_copy_TBps": None, "library_gemm_tflops": None}
+    out = {"mfma_bf16_sustained_tflops": None, "stream_copy_TBps": None, "d2d_copy_TBps": None, "library_gemm_tflops": None}
 
     def timed(fn, reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -195,7 +196,13 @@ def measured_ceilings(dev, seconds: float = 1.0):
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
         dst = torch.empty_like(src)
         dt = timed(lambda: dst.copy_(src), 10)
-        out["d2d_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)
+        out["d2d_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)                          # torch's uint8 copy kernel: reported for continuity, NOT a ceiling (round-5 review)
+        L = _lib.lib()
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        copy = lambda: _lib.check(L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel()), "mrag_probe_stream_copy")  # noqa: E731
+        dt = timed(copy, 20)
+        out["stream_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)                       # the library's 16-byte grid-stride copy (csrc/probe.hip): the HBM ceiling of a 1 : 1 stream
+        assert torch.equal(src[-4096:], dst[-4096:]) and torch.equal(src[:4096], dst[:4096])
         del src, dst
     except Exception as e:                           # noqa: BLE001
         out["d2d_copy"] = f"failed: {type(e).__name__}: {e}"[:200]

@@ -62,12 +62,13 @@ enum mrag_kernel_id {
   MRAG_K_GEMM_256x128,
   MRAG_K_GEMM_128x128,         /* the small-problem tile (< 192 tiles of 256x256)                                           */
   MRAG_K_GEMM_STREAMK_TAIL,
-  MRAG_K_GEMM_N320K320,        /* gemm_k320_kernel: K = 320, N = 320 .. 2 560 with a 320-column weight slice resident in registers (the UNets' level-0 linears) */
+  MRAG_K_GEMM_N320K320,        /* gemm_k320_kernel: K = 320, N = 320 / 640 / 960 (k320_applies) with a 320-column weight slice resident in registers (the UNets' level-0 linears) */
   MRAG_K_GEMM_192x256,         /* 8-wave 192x256 tile: long-K problems whose 256-row tile grid leaves the last round mostly empty */
   MRAG_K_CONV3_W4,             /* 3x3 (and causal 3x3x3) implicit-GEMM convolution on the persistent four-wave kernel       */
   MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128, MRAG_K_CONV3_192x256,
   MRAG_K_CONVT_W4,             /* (3,1,1) temporal convolution on the persistent four-wave kernel                           */
   MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_128x128, MRAG_K_CONVT_192x256,
+  MRAG_K_CONVT_256x128,        /* (never dispatched today: mrag_conv_bf16 takes the 256x128 tile for 3x3 convolutions only; the id keeps launch_cfg's table one-to-one) */
   MRAG_K_ATTN16,               /* attn16_kernel, whole query tiles                                                          */
   MRAG_K_ATTN16_KSPLIT,        /* attn16_kernel with the key-split ragged tail (+ MRAG_K_ATTN_COMBINE)                      */
   MRAG_K_ATTN_FLASH,           /* attn_fwd_kernel (32x32x16): masked / biased / short launches                              */
@@ -79,7 +80,11 @@ enum mrag_kernel_id {
   MRAG_K_IP_ATTN_FOLDED,       /* ip_attn_folded_kernel                                                                     */
   MRAG_K_LAYERNORM, MRAG_K_LAYERNORM_ROWS /* several narrow rows per wave (C = 320 / 640 / 1 280) */, MRAG_K_QKNORM_ROPE,
   MRAG_K_GN_STATS, MRAG_K_GN_FOLD, MRAG_K_GN_APPLY, MRAG_K_GN_APPLY_MOD,
+  MRAG_K_LAYERNORM_STREAM,     /* layernorm_stream_kernel: persistent waves, AdaLN factors folded into registers (D = 3 072, >= 8 192 rows) */
+  MRAG_K_GN_STATS_FOLD,        /* gn_stats_kernel<true>: statistics + the fold by the sample's last-arriving workgroup (<= 128 chunks) */
   MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
+  MRAG_K_GEMM_W4_TAIL_RECT,    /* the 128x128-tile launch behind a persistent launch whose last round would be nearly empty (<= 32 tiles) */
+  MRAG_K_GEMM_W4_BATCHED_W,    /* gemm_w4_kernel<NONE, true>: per-sample weights (w_batch_stride) */
   MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
   MRAG_K_COUNT
 };
@@ -99,6 +104,9 @@ int mrag_probe_mfma_bf16(void* stream, const void* operands, int64_t operand_byt
  * 4-byte aligned; out: 256 * 256 floats.                                                                                                            */
 int64_t mrag_probe_mfma_f32_flops(int32_t iters);
 int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
+/* the HBM stream every "HBM-bound" kernel is priced against (`roofline.ceilings.stream_copy_TBps`: bytes read + bytes written per second): a grid-stride copy
+ * of `bytes` (a multiple of 16; both pointers 16-byte aligned) with 16-byte loads and stores, four of each in flight per lane, 8 workgroups per CU.          */
+int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])     bf16 in/out      */
@@ -171,11 +179,16 @@ typedef struct mrag_gemm_args {
                               launch -- its K-tiles dealt evenly over the CUs, partial sums exchanged through the workspace and summed in
                               K order by the last arriver (bit-reproducible run to run; differs from the plain launch by fp32 summation
                               order only).  OPT-IN: measured slower than the partial round on MI355X               */
+  int64_t w_batch_stride;  /* != 0: PER-SAMPLE weights -- the rows of sample b = m / rows_per_batch multiply W + b * w_batch_stride (elements, a multiple of 8).
+                              The motion branch's folded score GEMM (attn_processor.py:250-256: `to_q_ip` folded into each CFG sample's own motion keys) as ONE
+                              launch for both samples.  MRAG_EPI_NONE, N % 128 == 0, K >= 320, M % rows_per_batch == 0, 16-byte aligned rows of C; any other
+                              shape returns MRAG_ENOTSUP (the caller then loops over the samples).                                                          */
 } mrag_gemm_args;
 enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8,
        MRAG_GEMM_TUNE_NO_W4 = 1 << 16, /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */
        MRAG_GEMM_TUNE_NO_SKINNY = 1 << 17, /* keep few-row problems (M <= 256) on the 128x128 tile instead of the K-split few-row kernel */
-       MRAG_GEMM_TUNE_SKINNY_8 = 1 << 18 /* few-row kernel: eight waves x 64 columns also for K >= 2 048 (shipped there: sixteen waves x 32 columns) */ };
+       MRAG_GEMM_TUNE_SKINNY_8 = 1 << 18, /* few-row kernel: eight waves x 64 columns also for K >= 2 048 (shipped there: sixteen waves x 32 columns) */
+       MRAG_GEMM_TUNE_NO_TAIL_RECT = 1 << 19 /* persistent kernel: a small partial last round stays in the launch (shipped: its own launch of 128x128 tiles) */ };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */
@@ -258,13 +271,18 @@ int mrag_attn_fwd_fp8(void* stream, const mrag_attn_args* args);
 /* [S, D] x [D, D] projection becomes a [S, D] x [D, 32 H] GEMM (mrag_gemm_bf16) */
 /* and this kernel finishes: softmax over the `keys` valid scores of every      */
 /* (row, head) times `scale`, times V_ip, added into `hidden` in place.         */
-/*   scores [B*S, scores_ld] bf16, key k of head h at column 32 h + k;          */
+/*   scores [B*S, scores_ld] bf16, key k of head h at column key_stride h + k   */
+/*   (key_stride 0 = 32: 64-byte aligned blocks; an even value in [keys, 32]    */
+/*   packs the heads -- 26 puts 48 heads x 25 keys into 1 280 columns, five      */
+/*   instead of six 256-column tiles of the score GEMM; scores_ld >=             */
+/*   (H - 1) key_stride + 32: a lane group reads 32 elements from a block's      */
+/*   start);                                                                     */
 /*   v: element (kv batch, key, h, d) at v + kb*v_batch_stride + key*v_key_stride + 64 h + d; */
 /*   hidden [B*S, hidden_ld] bf16; q batch b uses K/V batch b / kv_batch_div.   */
 /* ------------------------------------------------------------------------ */
 int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const void* v, void* hidden, int32_t B, int64_t S, int32_t H, int32_t keys,
                              int32_t kv_batch_div, int64_t scores_ld, int64_t hidden_ld, int64_t v_batch_stride, int64_t v_key_stride,
-                             float scale, float out_scale);
+                             float scale, float out_scale, int32_t key_stride);
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm (+ optional AdaLN modulation): y = LN(x)*gamma+beta, then       */
@@ -516,7 +534,11 @@ int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n
 /* nn.GroupNorm(G, C) over (HW x C/G) per (n, group) [+ per-(n,c) embedding   */
 /* pre-add: `h + emb_out` of ResBlock._forward, openaimodel3d.py:216-229]     */
 /* [+ SiLU].  lvdm/basics.py:81-88; openaimodel3d.py:152-181,258-268;         */
-/* lvdm/modules/attention.py:286,357.  workspace: fp32 partial sums.          */
+/* lvdm/modules/attention.py:286,357.  workspace: 16-byte aligned; its first  */
+/* 16 KiB are per-sample arrival counters (<= 128 chunks: the sample's last    */
+/* statistics workgroup also folds the partial sums -- one launch less): they  */
+/* must be ZERO before the first call on a workspace; every call leaves them   */
+/* zero.  Behind them: fp32 partial sums and per-(n, c) scale / shift.         */
 typedef struct mrag_groupnorm_args {
   const void* x; void* y;          /* [N, HW, C] bf16                           */
   const void* gamma; const void* beta;   /* [C] bf16 or NULL                    */

@@ -17,14 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MRAG_HIP_LIB", os.path.join(_HERE, "libmrag_hip.so"))   # env override: A/B builds in tools/
 SOURCES = ["api.hip", "gemm_bf16.hip", "attn_flash.hip", "attn16.hip", "attn_fp8.hip", "comm.hip", "norm.hip", "pointwise.hip", "preprocess.hip", "topk.hip", "unet_ops.hip", "cama_seq.hip", "attn_small.hip", "probe.hip"]
-ABI_VERSION = 9
+ABI_VERSION = 10
 # per-file flags: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 + shuffles (slower beside MFMAs)
 EXTRA_FLAGS = {"attn_flash.hip": ["-fno-slp-vectorize"],
                "attn16.hip": ["-fno-slp-vectorize"], "attn_fp8.hip": ["-fno-slp-vectorize"]}
 
 # every symbol include/mrag_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mrag_abi_version", "mrag_target_arch", "mrag_source_hash", "mrag_dispatch_counts", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_bf16", "mrag_probe_mfma_f32_flops", "mrag_probe_mfma_f32", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
+    "mrag_abi_version", "mrag_target_arch", "mrag_source_hash", "mrag_dispatch_counts", "mrag_dispatch_name", "mrag_probe_mfma_flops", "mrag_probe_mfma_bf16", "mrag_probe_mfma_f32_flops", "mrag_probe_mfma_f32", "mrag_probe_stream_copy", "mrag_gemm_bf16", "mrag_gemm_workspace_bytes", "mrag_attn_fwd_bf16", "mrag_attn_workspace_bytes", "mrag_layernorm_bf16",
     "mrag_qknorm_rope_bf16", "mrag_timestep_embedding_bf16", "mrag_silu_bf16", "mrag_add_rows_bf16", "mrag_add_bf16", "mrag_add_bcast_bf16", "mrag_axpby_bf16", "mrag_cfg_euler_step_bf16", "mrag_conv_bf16", "mrag_ip_attn_folded_bf16",
     "mrag_patchify_bf16", "mrag_unpatchify_bf16", "mrag_cfg_ddim_step_bf16", "mrag_topk_workspace_bytes", "mrag_topk_f32",
     "mrag_groupnorm_workspace_bytes", "mrag_groupnorm_bf16", "mrag_im2col3x3_bf16", "mrag_unfold_t3_bf16", "mrag_geglu_bf16",
@@ -54,7 +54,7 @@ class GemmArgs(Structure):
         ("epilogue", c_int32), ("rope_text_len", c_int32),
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
         ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32), ("geglu_act", c_int32),
-        ("workspace", c_void_p), ("acc_scale", c_float), ("workspace_bytes", c_int64),
+        ("workspace", c_void_p), ("acc_scale", c_float), ("workspace_bytes", c_int64), ("w_batch_stride", c_int64),
     ]
 
 
@@ -261,6 +261,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_probe_mfma_f32_flops.argtypes = [c_int32]
     L.mrag_probe_mfma_f32_flops.restype = c_int64
     L.mrag_probe_mfma_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int32]
+    L.mrag_probe_stream_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
     L.mrag_gemm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
@@ -283,7 +284,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_add_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
     L.mrag_conv_bf16.argtypes = [c_void_p, POINTER(ConvArgs)]
     L.mrag_ip_attn_folded_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64,
-                                           c_int64, c_float, c_float]
+                                           c_int64, c_float, c_float, c_int32]
     L.mrag_add_bcast_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64]
     L.mrag_axpby_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float]
     L.mrag_cfg_euler_step_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_float, c_float]

@@ -156,9 +156,16 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
         wkv = fw.get(("ipkv", _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight)), lambda: _cat_weights([proc.to_k_ip[0], proc.to_v_ip[0]]))
         if FOLD_IP_QUERY and ip.size(1) <= 32:
             # The motion tokens are fixed for a clip, so to_q_ip is folded into the keys ONCE per clip:
-            #   to_q_ip(o)_h . K_h^T = o . (K_h . Wq_h)^T = o . M_h^T,  M [B', H*32, D]  (25 keys per head padded to 32)
-            # and every step runs a [S, D] x [D, 32 H] GEMM instead of the [S, D] x [D, D] projection (half the flops of :250) plus one
-            # kernel that finishes softmax . V_ip and the `o + scale * ip` update (:264-273) in place.
+            #   to_q_ip(o)_h . K_h^T = o . (K_h . Wq_h)^T = o . M_h^T,  M [B', NW, D]: head h's nk keys in rows KS h .. KS h + nk - 1
+            # and every step runs a [S, D] x [D, NW] GEMM instead of the [S, D] x [D, D] projection (less than half the flops of :250) plus one
+            # kernel that finishes softmax . V_ip and the `o + scale * ip` update (:264-273) in place.  KS = the heads' row pitch: the smallest even
+            # value >= nk that lets the GEMM drop a 256-column tile (25 keys x 48 heads: KS = 26, NW = 1 280 = five tiles instead of the six of
+            # KS = 32), else 32.  Both CFG samples' score GEMMs are ONE launch with per-sample weights (ops.linear_per_sample): 700 tiles = 3 rounds of
+            # the persistent grid where two launches of 420 paid 2 + 2 (round 6).
+            nk = ip.size(1)
+            KS = next((c for c in range(nk + (nk & 1), 32, 2) if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256)), 32)
+            NW = -(-((H - 1) * KS + 32) // 256) * 256 if KS != 32 else H * 32
+
             def build():
                 kv0 = ops.linear(ip, wkv)                                         # :251-252 (one GEMM)
                 Bp, nk = ip.size(0), ip.size(1)
@@ -167,13 +174,14 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
                 # 64 h..; zeros elsewhere add exact zeros to the fp32 accumulators, so every M_h is what its own [nk, 64] x [64, D] product
                 # gives) -- 48x the flops of the per-head products, 2.5 ms per clip on the DiT, instead of 96 launches per layer
                 k4 = kv0[..., :D].unflatten(-1, (H, 64))                          # [B', nk, H, 64]
-                A = torch.zeros(Bp, H, 32, H, 64, dtype=torch.bfloat16, device=ip.device)
+                A = torch.zeros(Bp, NW, H, 64, dtype=torch.bfloat16, device=ip.device)
                 hidx = torch.arange(H, device=ip.device)
-                A[:, hidx, :nk, hidx] = k4.permute(2, 0, 1, 3)                    # advanced indices split by a slice come first: [H, B', nk, 64]
-                M = torch.empty(Bp, H * 32, D, dtype=torch.bfloat16, device=ip.device)
+                rows = (hidx[:, None] * KS + torch.arange(nk, device=ip.device)[None, :])   # [H, nk]: row of (head, key)
+                A[:, rows, hidx[:, None]] = k4.permute(0, 2, 1, 3)                # [B', H, nk, 64] into rows KS h + k, head block h
+                M = torch.empty(Bp, NW, D, dtype=torch.bfloat16, device=ip.device)
                 for bp in range(Bp):
-                    ops.linear(A[bp].view(H * 32, D), wq_t, out=M[bp])
-                return M, kv0[..., D:]
+                    ops.linear(A[bp].view(NW, D), wq_t, out=M[bp])
+                return M, kv0[..., D:], KS
             # cache hit only for the SAME tensor object at the same version: the entry keeps a reference to `ip`, so its address cannot be
             # recycled for another clip's tokens while the entry lives (a data_ptr key alone would go stale silently)
             ent = fw._cache.get("ipfold")
@@ -181,10 +189,8 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
                 ent = (ip, ip._version, (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight))) + build()
                 fw._cache["ipfold"] = ent
             M, v_ip = ent[3], ent[4]
-            sc = torch.empty(B, S, H * 32, dtype=torch.bfloat16, device=o.device)
-            for b in range(B):
-                ops.linear(o[b], M[b // r], out=sc[b])
-            ops.ip_attn_folded_(sc, v_ip, o, H, ip.size(1), kv_batch_div=r, scale=0.125, out_scale=float(scale))
+            sc = ops.linear_per_sample(o, M, samples_per_weight=r)                # [B, S, NW]
+            ops.ip_attn_folded_(sc, v_ip, o, H, ip.size(1), kv_batch_div=r, scale=0.125, out_scale=float(scale), key_stride=ent[5])
         else:
             ip_q = ops.linear(o, proc.to_q_ip[0].weight)                          # :250  (text tokens included)
             kv = ops.linear(ip, wkv)                                              # :251-252 (one GEMM)

@@ -6,7 +6,7 @@
 #define MRAG_SOURCE_HASH "unstamped"
 #endif
 
-extern "C" int mrag_abi_version(void) { return 9; }
+extern "C" int mrag_abi_version(void) { return 10; }
 extern "C" const char* mrag_target_arch(void) { return "gfx950"; }
 // "MRAG_SOURCE_HASH=<hex>" is also findable in the file's bytes, so the build can read a binary's stamp without loading it
 static const char k_source_stamp[] = "MRAG_SOURCE_HASH=" MRAG_SOURCE_HASH;
@@ -25,10 +25,10 @@ extern "C" const char* mrag_dispatch_name(int32_t id) {
   static const char* const names[MRAG_K_COUNT] = {
       "GEMM_W4", "GEMM_W4_QKNORM_ROPE", "GEMM_W4_GEGLU", "GEMM_256x256", "GEMM_256x320", "GEMM_256x128", "GEMM_128x128", "GEMM_STREAMK_TAIL", "GEMM_N320K320", "GEMM_192x256",
       "CONV3_W4", "CONV3_256x256", "CONV3_256x320", "CONV3_256x128", "CONV3_128x128", "CONV3_192x256",
-      "CONVT_W4", "CONVT_256x256", "CONVT_256x320", "CONVT_128x128", "CONVT_192x256",
+      "CONVT_W4", "CONVT_256x256", "CONVT_256x320", "CONVT_128x128", "CONVT_192x256", "CONVT_256x128",
       "ATTN16", "ATTN16_KSPLIT", "ATTN_FLASH", "ATTN_FLASH_KSPLIT", "ATTN_COMBINE", "ATTN_TINY", "ATTN_SMALL", "ATTN_FP8", "IP_ATTN_FOLDED",
-      "LAYERNORM", "LAYERNORM_ROWS", "QKNORM_ROPE", "GN_STATS", "GN_FOLD", "GN_APPLY", "GN_APPLY_MOD",
-      "TOPK_SCAN", "TOPK_SCAN_FUSED_MERGE", "TOPK_MERGE", "TOPK_MFMA", "GEMM_SKINNY"};
+      "LAYERNORM", "LAYERNORM_ROWS", "QKNORM_ROPE", "GN_STATS", "GN_FOLD", "GN_APPLY", "GN_APPLY_MOD", "LAYERNORM_STREAM", "GN_STATS_FOLD",
+      "TOPK_SCAN", "TOPK_SCAN_FUSED_MERGE", "TOPK_MERGE", "TOPK_MFMA", "GEMM_W4_TAIL_RECT", "GEMM_W4_BATCHED_W", "GEMM_SKINNY"};
   static_assert(sizeof(names) / sizeof(names[0]) == MRAG_K_COUNT, "one name per enum mrag_kernel_id");
   return (id >= 0 && id < (int)MRAG_K_COUNT) ? names[id] : nullptr;
 }

@@ -845,9 +845,10 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(const AttnP p) {
 struct IpFoldP {
   const bf16_t* scores; const bf16_t* v; bf16_t* o;
   long long rows, s_ld, o_ld, v_bs, v_ks, rows_per_batch;
-  int H, keys, kv_div;
+  int H, keys, kv_div, ks;   // ks: elements between the heads' score blocks (32: 64-byte aligned blocks; 26: the packed form of the one-launch score GEMM)
   float qscale, out_scale;
 };
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;   // a 16-byte load from a 4-byte aligned address (the packed score blocks start every 52 bytes)
 
 #ifndef MRAG_IPFOLD_HG
 #define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
     const long long row = g0 + r16;
     const long long rc = row < row_hi ? row : row_hi - 1;
     // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
-    u32x4 raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + h0 * 32 + kq * 8);
+    u32x4 raw_n = *(const u32x4_a4*)(p.scores + rc * p.s_ld + h0 * p.ks + kq * 8);
     u32x4 old_n[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(p.o + rc * p.o_ld + h0 * 64 + 32 * hf + 8 * kq);
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
       bf16_t* op = p.o + rc * p.o_ld + h * 64;
       const u32x4 old[2] = {old_n[0], old_n[1]};
       if (hl + 1 < nh) {
-        raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + (h + 1) * 32 + kq * 8);
+        raw_n = *(const u32x4_a4*)(p.scores + rc * p.s_ld + (h + 1) * p.ks + kq * 8);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(op + 64 + 32 * hf + 8 * kq);
       }
@@ -936,14 +937,16 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
 
 extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const void* v, void* hidden, int32_t B, int64_t S, int32_t H, int32_t keys,
                                         int32_t kv_batch_div, int64_t scores_ld, int64_t hidden_ld, int64_t v_batch_stride, int64_t v_key_stride,
-                                        float scale, float out_scale) {
+                                        float scale, float out_scale, int32_t key_stride) {
   if (!scores || !v || !hidden || B <= 0 || S <= 0 || H <= 0 || keys <= 0 || keys > 32 || kv_batch_div <= 0 || B % kv_batch_div) return MRAG_EINVAL;
-  if (scores_ld % 8 || hidden_ld % 8 || scores_ld < (int64_t)H * 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;
+  const int ks = key_stride == 0 ? 32 : key_stride;
+  if (ks < keys || ks > 32 || (ks & 1)) return MRAG_EINVAL;                       // (score blocks start on 4-byte boundaries)
+  if (scores_ld % 8 || hidden_ld % 8 || scores_ld < (int64_t)(H - 1) * ks + 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;   // a lane group reads 32 elements from a block's start
   if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 15) || ((uintptr_t)v & 15) || v_batch_stride % 8 || v_key_stride % 8) return MRAG_EINVAL;
   IpFoldP p{};
   p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;
   p.rows = (long long)B * S; p.s_ld = scores_ld; p.o_ld = hidden_ld; p.v_bs = v_batch_stride; p.v_ks = v_key_stride; p.rows_per_batch = S;
-  p.H = H; p.keys = keys; p.kv_div = kv_batch_div; p.qscale = scale * 1.4426950408889634f; p.out_scale = out_scale;
+  p.H = H; p.keys = keys; p.kv_div = kv_batch_div; p.ks = ks; p.qscale = scale * 1.4426950408889634f; p.out_scale = out_scale;
   constexpr int HG = MRAG_IPFOLD_HG;
   const size_t lds = HG * 64 * 32 * sizeof(bf16_t);
   const long long groups = ((long long)kv_batch_div * S + 63) / 64;

@@ -66,6 +66,9 @@ struct GemmP {
   float acc_scale;    // MRAG_EPI_RESID: C = resid + acc_scale * (acc + bias) (1 unless the caller blends: AlphaBlender folded into a residual branch)
   float* sk_part; unsigned* sk_ticket;
   int sk_main, sk_rem, sk_units, sk_maxparts;
+  int tile_limit;     // gemm_w4_kernel: tiles [0, tile_limit) of the logical order (all of them, or the whole rounds in front of a tail launch: launch_w4)
+  int wb_tiles_m;     // gemm_w4_kernel<EPI, true> (per-sample weights): 256-row tiles per sample -- the row-tile grid restarts at every sample; 0 otherwise
+  long long w_bstride;   // elements between the samples' weight matrices
   int cv_lds;         // CONV != 0: byte offset of the parked per-lane tap state in LDS (behind the operand stages / staged-epilogue region)
   int cv_tf;          // CONV == 1 with three temporal taps (causal 3x3x3): output frames per sample (input holds cv_tf + 2 frames per sample); 0 = 2-D
   long long cv_fs;    // elements between consecutive input frames
@@ -234,29 +237,32 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
   const long long bm0 = (long long)tile_m * BM, bn0 = (long long)tile_n * BN;
 
   // ---- per-lane DMA sources (k = 0), one per piece this wave stages.
-  // Plain GEMM: a 64-bit row pointer per piece.  Convolutions keep NO pointer: the 8-wave 256x256 tile runs at exactly 256 VGPRs (128 accumulators, two sets
-  // of 48 fragment registers), and the 36 registers of row pointers + tap cursors the first form kept per lane (gsrc, cv_y, cv_x, cv_src, cv_step) were
-  // 44-51 spilled VGPRs: two scratch reloads per K-tile, each behind an `s_waitcnt vmcnt(0)` that also drains the LDS-DMA ring (round-5 review;
-  // tools/check_scratch.py).  Now, per A piece: the current tap's source as ONE 32-bit offset in 16-byte units relative to a workgroup-uniform base
-  // (`cv_base`, an SGPR pair), and per W piece a 32-bit byte offset for the scalar-base form of the DMA: 8 registers.  What a tap change needs to recompute
-  // the offsets -- the tap-independent position (y << 16 | x, or the frame index) and the sample's offset, two words per piece -- is parked in LDS
-  // (lane-linear words behind the operand stages, GemmP::cv_lds): read back once per tap by ds_read, which counts on lgkmcnt and leaves the DMA ring alone.
+  // Plain GEMM, and the convolutions on every tile but 256x256: a 64-bit row pointer per piece (+ per A piece of a convolution the tap-independent position and
+  // the walked tap cursor: cv_y, cv_x, cv_src, cv_step).  The 8-wave 256x256 tile runs at exactly 256 VGPRs (128 accumulators, two sets of 48 fragment
+  // registers): there those 36 registers were 44-51 SPILLED VGPRs -- two scratch reloads per K-tile, each behind an `s_waitcnt vmcnt(0)` that also drains the
+  // LDS-DMA ring (round-5 review; tools/check_scratch.py).  SLIM form (256x256 convolutions only; the other tiles have the registers and measured 1 % slower on
+  // it: profiles/r6_conv_scratch_ab.txt): per A piece the current tap's source as ONE 32-bit offset in 16-byte units relative to a workgroup-uniform base
+  // (`cv_base`, an SGPR pair), per W piece a 32-bit byte offset for the scalar-base form of the DMA: 8 registers.  What a tap change needs to recompute the
+  // offsets -- the tap-independent position (y << 16 | x, or the frame index) and the sample's offset, two words per piece -- is parked in LDS (lane-linear
+  // words behind the operand stages, GemmP::cv_lds): read back once per tap by ds_read, which counts on lgkmcnt and leaves the DMA ring alone.
   constexpr int APW = BM / 8 / NW;          // a wave's first APW pieces are A rows (piece = wave + i * NW < BM / 8)
   static_assert((BM / 8) % NW == 0, "A pieces split evenly over the waves");
-  static_assert(CONV == 0 || APW <= 4, "the parked conv state is read back by four hand-written statements");
+  constexpr bool SLIM = CONV != 0 && TM == 8 && TN == 4 && WM == 2 && WN == 4;
+  static_assert(!SLIM || APW <= 4, "the parked conv state is read back by four hand-written statements");
   constexpr int CV_NONE = (int)0x80000000;  // cv_cur: the tap falls outside the image / clip -> the zero row
-  const bf16_t* gsrc[CONV == 0 ? PPW : 1];
-  int cv_cur[CONV != 0 ? APW : 1];
+  const bf16_t* gsrc[SLIM ? 1 : PPW];
+  int cv_y[(CONV != 0 && !SLIM) ? APW : 1], cv_x[(CONV != 0 && !SLIM) ? APW : 1];      // legacy conv form: per A piece
+  int cv_cur[SLIM ? APW : 1];
   const unsigned cv_park = (unsigned)(size_t)smem + (unsigned)p.cv_lds + (unsigned)tid * 4u;   // word k of this lane at + k * NW * 256: k = 2 i (position), 2 i + 1 (sample offset)
   auto cv_put = [&](int k, int v) { *(int*)(smem + p.cv_lds + (k * NW * 64 + tid) * 4) = v; };
-  unsigned cv_woff[CONV != 0 ? PPW - APW : 1];
+  unsigned cv_woff[SLIM ? PPW - APW : 1];
   const bf16_t* cv_base = p.A;              // workgroup-uniform
   const int cv_c8 = (int)(p.cv_C >> 3);     // 16-byte units per pixel
-  if constexpr (CONV == 1) {                // the sample (input frame stack position) of the tile's first row
+  if constexpr (SLIM && CONV == 1) {        // the sample (input frame stack position) of the tile's first row
     const long long n0 = bm0 / ((long long)p.cv_Wo * p.cv_Ho);
     const long long n0_in = p.cv_tf ? n0 + 2 * (n0 / p.cv_tf) : n0;
     cv_base = p.A + n0_in * p.cv_H * p.cv_W * p.cv_C;
-  } else if constexpr (CONV == 2) {
+  } else if constexpr (SLIM && CONV == 2) {
     cv_base = p.A + bm0 * p.cv_C;
   }
 #pragma unroll
@@ -267,26 +273,37 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
     if (piece < BM / 8) {
       long long row = bm0 + r;
       row = row < p.M ? row : p.M - 1;  // clamp: tail rows re-read a valid row, stores are masked
-      if constexpr (CONV == 1) {         // row = (n, yo, xo) of the output image: keep (yo*stride - pad, xo*stride - pad) and the sample's offset
+      if constexpr (CONV == 1) {         // row = (n, yo, xo) of the output image: keep (yo*stride - pad, xo*stride - pad) and the sample's position
         const int xo = (int)(row % p.cv_Wo);
         const long long r2 = row / p.cv_Wo;
         const int yo = (int)(r2 % p.cv_Ho);
         const long long n = r2 / p.cv_Ho;
         const long long n_in = p.cv_tf ? n + 2 * (n / p.cv_tf) : n;   // 3-D: sample s's output frame t reads input frames s (T + 2) + t + {0, 1, 2}
-        const long long n0 = bm0 / ((long long)p.cv_Wo * p.cv_Ho);
-        const long long n0_in = p.cv_tf ? n0 + 2 * (n0 / p.cv_tf) : n0;
-        cv_put(2 * i, (int)(((unsigned)(yo * p.cv_stride - p.cv_pad) << 16) | ((unsigned)(xo * p.cv_stride - p.cv_pad) & 0xffffu)));
-        cv_put(2 * i + 1, (int)(n_in - n0_in) * (p.cv_H * p.cv_W * cv_c8) + chunk);
-      } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row's offset and t
-        cv_put(2 * i, (int)((row / p.cv_HW) % p.cv_T));
-        cv_put(2 * i + 1, (int)(row - bm0) * cv_c8 + chunk);
+        if constexpr (SLIM) {
+          const long long n0 = bm0 / ((long long)p.cv_Wo * p.cv_Ho);
+          const long long n0_in = p.cv_tf ? n0 + 2 * (n0 / p.cv_tf) : n0;
+          cv_put(2 * i, (int)(((unsigned)(yo * p.cv_stride - p.cv_pad) << 16) | ((unsigned)(xo * p.cv_stride - p.cv_pad) & 0xffffu)));
+          cv_put(2 * i + 1, (int)(n_in - n0_in) * (p.cv_H * p.cv_W * cv_c8) + chunk);
+        } else {
+          gsrc[i] = p.A + n_in * p.cv_H * p.cv_W * p.cv_C + chunk * 8;
+          cv_y[i < APW ? i : 0] = yo * p.cv_stride - p.cv_pad;
+          cv_x[i < APW ? i : 0] = xo * p.cv_stride - p.cv_pad;
+        }
+      } else if constexpr (CONV == 2) {  // row = (b, t, hw): keep the row's position and t
+        if constexpr (SLIM) {
+          cv_put(2 * i, (int)((row / p.cv_HW) % p.cv_T));
+          cv_put(2 * i + 1, (int)(row - bm0) * cv_c8 + chunk);
+        } else {
+          gsrc[i] = p.A + row * p.cv_C + chunk * 8;
+          cv_y[i < APW ? i : 0] = (int)((row / p.cv_HW) % p.cv_T);
+        }
       } else {
         gsrc[i] = p.A + row * p.lda + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
       }
     } else {
       long long row = bn0 + (r - BM);
       row = row < p.N ? row : p.N - 1;
-      if constexpr (CONV != 0) cv_woff[i >= APW ? i - APW : 0] = (unsigned)((row * p.ldw + chunk * 8) * 2);   // (< 4 GiB: checked by mrag_conv_bf16)
+      if constexpr (SLIM) cv_woff[i >= APW ? i - APW : 0] = (unsigned)((row * p.ldw + chunk * 8) * 2);   // (< 4 GiB: checked by mrag_conv_bf16)
       else gsrc[i] = p.W + row * p.ldw + chunk * 8 + (SK ? (long long)kt0 * BK : 0);
     }
   }
@@ -307,6 +324,8 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
   // The K-tiles are requested in order (0, 1, 2, ...), so the (tap, channel block) pair is WALKED: the tap geometry (bounds test, pixel
   // offset) is redone only when the tap changes -- every Cin / 64 K-tiles -- and leaves one 32-bit offset per piece (cv_cur); a K-tile's
   // request adds the channel block and the workgroup's base to it (a handful of vector instructions per piece, no persistent pointer).
+  const bf16_t* cv_src[(CONV != 0 && !SLIM) ? APW : 1];   // legacy form, per A piece: this lane's source at the current (tap, channel block)
+  int cv_step[(CONV != 0 && !SLIM) ? APW : 1];            // 64 elements per channel block inside the image, 0 on the zero row
   int cv_kt = -1, cv_tap = 0, cv_cblk = -1;
   auto cv_prepare = [&](int kt) {
     if constexpr (CONV != 0) {
@@ -318,25 +337,45 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
           bool ok;
-          int off, yx, nb;
-          // (hand-written reads: a compiler-made LDS load would be ordered behind the LDS-DMA pieces in flight -- `s_waitcnt vmcnt(0)`, the drain this form removes)
-          if (i == 0) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(NW * 256) : "memory");
-          else if (i == 1) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(2 * NW * 256), "n"(3 * NW * 256) : "memory");
-          else if (i == 2) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(4 * NW * 256), "n"(5 * NW * 256) : "memory");
-          else asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(6 * NW * 256), "n"(7 * NW * 256) : "memory");
-          if constexpr (CONV == 1) {
-            const int kt3 = p.cv_tf ? cv_tap / 9 : 0, tap9 = cv_tap - 9 * kt3;   // taps in (kt, ky, kx) order; kt3 = 0 for the 2-D convolution
-            const int ky = tap9 / 3, kx = tap9 - 3 * ky;
-            const int yi = (yx >> 16) + ky, xi = (int)(short)(yx & 0xffff) + kx;
-            ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
-            off = nb + ((yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * cv_c8 + kt3 * (int)(p.cv_fs >> 3);
+          if constexpr (SLIM) {
+            int off, yx, nb;
+            // (hand-written reads: a compiler-made LDS load would be ordered behind the LDS-DMA pieces in flight -- `s_waitcnt vmcnt(0)`, the drain this form removes)
+            if (i == 0) asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(NW * 256) : "memory");
+            else if (i == 1) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(2 * NW * 256), "n"(3 * NW * 256) : "memory");
+            else if (i == 2) asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(4 * NW * 256), "n"(5 * NW * 256) : "memory");
+            else asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(yx), "=&v"(nb) : "v"(cv_park), "n"(6 * NW * 256), "n"(7 * NW * 256) : "memory");
+            if constexpr (CONV == 1) {
+              const int kt3 = p.cv_tf ? cv_tap / 9 : 0, tap9 = cv_tap - 9 * kt3;   // taps in (kt, ky, kx) order; kt3 = 0 for the 2-D convolution
+              const int ky = tap9 / 3, kx = tap9 - 3 * ky;
+              const int yi = (yx >> 16) + ky, xi = (int)(short)(yx & 0xffff) + kx;
+              ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
+              off = nb + ((yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * cv_c8 + kt3 * (int)(p.cv_fs >> 3);
+            } else {
+              const int t = yx + cv_tap - 1;
+              ok = (unsigned)t < (unsigned)p.cv_T;
+              off = nb + (cv_tap - 1) * (int)p.cv_HW * cv_c8;
+            }
+            cv_cur[i] = ok ? off : CV_NONE;
           } else {
-            const int t = yx + cv_tap - 1;
-            ok = (unsigned)t < (unsigned)p.cv_T;
-            off = nb + (cv_tap - 1) * (int)p.cv_HW * cv_c8;
+            long long off;
+            if constexpr (CONV == 1) {
+              const int kt3 = p.cv_tf ? cv_tap / 9 : 0, tap9 = cv_tap - 9 * kt3;
+              const int ky = tap9 / 3, kx = tap9 - 3 * ky;
+              const int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
+              ok = (unsigned)yi < (unsigned)p.cv_Hi && (unsigned)xi < (unsigned)p.cv_Wi;
+              off = ((long long)(yi >> p.cv_up) * p.cv_W + (xi >> p.cv_up)) * p.cv_C + kt3 * p.cv_fs;
+            } else {
+              const int t = cv_y[i] + cv_tap - 1;
+              ok = (unsigned)t < (unsigned)p.cv_T;
+              off = (long long)(cv_tap - 1) * p.cv_HW * p.cv_C;
+            }
+            cv_src[i] = ok ? gsrc[i] + off : g_zero_row + (lane & 7) * 8;
+            cv_step[i] = ok ? 64 : 0;
           }
-          cv_cur[i] = ok ? off : CV_NONE;
         }
+      } else if constexpr (!SLIM) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) cv_src[i] += cv_step[i];
       }
     }
   };
@@ -344,8 +383,10 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int wg, const in
   auto dma_piece = [&](int i, int kt, char* dst) {
     if constexpr (CONV == 0) {
       glds16(gsrc[i] + (long long)kt * MRAG_DIAG_KSTEP, dst);
+    } else if constexpr (!SLIM) {
+      glds16(i >= APW ? gsrc[i] + (long long)kt * BK : cv_src[i < APW ? i : 0], dst);      // weight rows [Cout, taps * Cin] are plain
     } else {
-      if (i >= APW) {                                          // weight rows [Cout, taps * Cin] are plain: scalar base + the lane's byte offset
+      if (i >= APW) {                                          // weight rows: scalar base + the lane's byte offset
         glds16_sbase(p.W + (long long)kt * BK, cv_woff[i - APW], (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dst));   // (wave-uniform by construction; the asm wants it in an SGPR)
       } else {
         const int c = cv_cur[i];
@@ -989,7 +1030,7 @@ inline SkPlan plan_streamk(long long M, long long N, long long K) {
 // General path (edge tiles, a sample or text / video boundary inside the wave's rows, unaligned C): 8-byte predicated stores from the accumulator layout.
 template <int EPI>
 __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&acc)[8][8], const long long bm0, const long long bn0, const int wave, const int wrow0,
-                                            const int wcol0, const int lane_in) {
+                                            const int wcol0, const int lane_in, const long long Mend) {   // Mend: rows [.., Mend) exist (p.M, or the end of the tile's sample)
   constexpr bool HAS_R = (EPI == MRAG_EPI_GATE_RESID || EPI == MRAG_EPI_RESID), HAS_G = (EPI == MRAG_EPI_GATE_RESID), QK = (EPI == MRAG_EPI_QKNORM_ROPE);
   // the lane id is laundered through an empty asm: everything below that depends on the lane only (LDS addresses, column offsets, row pointers) would
   // otherwise be hoisted out of the tile loop and kept in registers ACROSS the K loop, whose 128 fragment registers leave no room -- hipcc then spills
@@ -1006,8 +1047,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
     g_b = m0 / p.rows_per_batch;
     g_pos = m0 - g_b * p.rows_per_batch;
   }
-  if (m0 >= p.M || bn0 + wcol0 >= p.N) return;                         // (a wave tile outside the matrix: nothing to store)
-  const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);            // the wave's valid rows (wave-uniform): < 128 in the last row of tiles only
+  if (m0 >= Mend || bn0 + wcol0 >= p.N) return;                         // (a wave tile outside the matrix: nothing to store)
+  const int mrows = (int)(Mend - m0 < 128 ? Mend - m0 : 128);            // the wave's valid rows (wave-uniform): < 128 in the last row of tiles only
   bool fast = p.staged && bn0 + wcol0 + 128 <= p.N;
   if constexpr (HAS_G) fast = fast && g_pos + mrows - 1 < p.rows_per_batch && ((g_pos < p.split) == (g_pos + mrows - 1 < p.split));
   auto add_resid = [&](u32x2 out, const u32x2 r2) __attribute__((always_inline)) -> u32x2 {
@@ -1152,8 +1193,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmP& p, char* smem, f32x4 (&
   for (int i = 0; i < 8; ++i) {                                         // (fully unrolled: the accumulators are registers, never indexed at run time)
     __builtin_amdgcn_sched_barrier(0);
     const long long m = m0 + i * 16 + frag_row;
-    const bool mok = m < p.M;
-    const long long mc = mok ? m : p.M - 1;
+    const bool mok = m < Mend;
+    const long long mc = mok ? m : Mend - 1;
     const bf16_t* gate = nullptr;
     if constexpr (HAS_G) {
       long long b = g_b, pos = g_pos + (mc - m0);
@@ -1263,13 +1304,28 @@ __device__ __forceinline__ void tile_coords(const GemmP& p, const int L, int& ti
 // LDS: two 64-KB stages [A rows 0..255 | W rows 0..255], 128-byte rows, 16-byte chunk c of row r at ((c ^ (r & 7)) * 16).
 // K-tile g of the stream (stage s = g & 1):  k-step 0 MFMAs | reads of (g, k-step 1) .. lgkmcnt(0), BARRIER (stage s is free) .. DMA of K-tile g + 2 -> stage s
 //                                            k-step 1 MFMAs | vmcnt (K-tile g + 1 landed), BARRIER .. reads of (g + 1, k-step 0) .. rest of the DMA
-template <int EPI>
+// WB (per-sample weights; EPI_NONE): sample b's rows [b rows_per_batch, (b + 1) rows_per_batch) multiply W + b w_bstride -- the motion branch's folded score GEMM, whose
+// weights are built from each CFG sample's own motion tokens (attn_processor.py:250-256).  The row-tile grid restarts at every sample (no tile straddles
+// two weight matrices; a sample's last tile is clamped / masked at the sample's end), so both samples ride ONE persistent launch: 700 tiles = 2.73 -> 3
+// rounds where two launches of 350 paid 2 + 2.
+template <int EPI, bool WB = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned STAGE = 65536, WOFF = 32768;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const int tiles = p.tiles_m * p.tiles_n, nk = (int)(p.K / 64), G = (int)gridDim.x;
+  const int tiles = p.tile_limit, nk = (int)(p.K / 64), G = (int)gridDim.x;
+  // origin of logical tile (tm, tn): first row, one past the last row that exists for it, element offset of its weight matrix
+  auto tile_origin = [&](const int tm, long long& bm0, long long& m_end, long long& w_off) __attribute__((always_inline)) {
+    if constexpr (WB) {
+      const int b = tm / p.wb_tiles_m;
+      bm0 = (long long)b * p.rows_per_batch + (long long)(tm - b * p.wb_tiles_m) * 256;
+      m_end = (long long)(b + 1) * p.rows_per_batch;
+      w_off = (long long)b * p.w_bstride;
+    } else {
+      bm0 = (long long)tm * 256; m_end = p.M; w_off = 0;
+    }
+  };
   const int slot = xcd_remap((int)blockIdx.x, G);   // this workgroup's tiles: slot, slot + G, ... (round r of the grid = what a one-tile-per-workgroup launch dispatches)
   // ---- DMA cursor: (tile d_r of this workgroup, K-tile d_kt).  Piece q = wave + 4 i, i = 0..15 (i < 8: A rows 8 q .. 8 q + 7, else W rows 8 (q - 32) ..);
   // lane -> row (lane >> 3) of the piece, source chunk (lane & 7) ^ row
@@ -1283,7 +1339,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     if (!d_valid) return;                 // the stream has ended: the cursor stays where it is (see `advance`)
     int tm, tn;
     tile_coords(p, L, tm, tn);
-    const long long bm0 = (long long)tm * 256, bn0 = (long long)tn * 256;
+    long long bm0, m_end, w_off;
+    tile_origin(tm, bm0, m_end, w_off);
+    const long long bn0 = (long long)tn * 256;
     int lane_c = lane;                      // laundered (see epilogue_w4): nothing lane-derived of this block may stay live across the K loop
     asm volatile("" : "+v"(lane_c));
     const int prow = lane_c >> 3, pchk = (lane_c & 7) ^ prow;
@@ -1291,12 +1349,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     for (int i = 0; i < 16; ++i) {
       const int q = wave_s + 4 * i;
       long long r8 = (i < 8) ? 8 * q + prow : 8 * (q - 32) + prow;
-      const long long lim = (i < 8) ? p.M - bm0 : p.N - bn0;          // clamp: tail rows re-read the tile's last valid row, stores are masked
+      const long long lim = (i < 8) ? m_end - bm0 : p.N - bn0;        // clamp: tail rows re-read the tile's last valid row, stores are masked
       r8 = r8 < lim ? r8 : lim - 1;
       voff[i] = (unsigned)((r8 * ((i < 8) ? p.lda : p.ldw) + pchk * 8) * 2);
     }
     baseA = p.A + bm0 * p.lda;
-    baseW = p.W + bn0 * p.ldw;
+    baseW = p.W + w_off + bn0 * p.ldw;
   };
   // past the end of the stream the cursor stays on its last K-tile: the loop below has ONE instruction stream (one register allocation for the 256 pinned
   // accumulators -- with one body per stream state hipcc spilled accumulators at the joins), so the last two K-tiles of a workgroup re-request a K-tile
@@ -1399,8 +1457,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     MRAG_GSTAMP(q3);
     int tm, tn;
     tile_coords(p, L, tm, tn);
-    if constexpr (is_geglu<EPI>) epilogue_w4_geglu<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
-    else epilogue_w4<EPI>(p, smem, acc, (long long)tm * 256, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
+    long long e_bm0, e_mend, e_woff;
+    tile_origin(tm, e_bm0, e_mend, e_woff);
+    if constexpr (is_geglu<EPI>) epilogue_w4_geglu<EPI>(p, smem, acc, e_bm0, (long long)tn * 256, wave, wm * 128, wn * 128, lane);
+    else epilogue_w4<EPI>(p, smem, acc, e_bm0, (long long)tn * 256, wave, wm * 128, wn * 128, lane, e_mend);
 #ifdef MRAG_GEMM_STAMPS
     MRAG_GSTAMP(q4);
     q_acc[0] += q1 - q0; q_acc[1] += q2 - q1; q_acc[2] += q3 - q2; q_acc[3] += q4 - q3; q_acc[4] += 1;
@@ -1419,63 +1479,97 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #undef MRAG_W4_LGKM0
 }
 
+template <int WM, int WN, int TM, int TN, int CONV = 0>
+int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullptr);
+
+// The partial last round of the persistent grid as a RECTANGLE of small tiles.  One workgroup per CU: a launch costs ceil(tiles / 256) rounds however
+// full the last one is -- the DiT's FF1 (139 x 48 = 6 672 tiles = 26.06 rounds) pays a 27th round of 79 us for 16 tiles.  Stream-K over those tiles
+// measured slower (EXPERIMENTS.md section 3: the runs lose the lock-step that lets an XCD's L2 serve an operand panel once).  When the remainder is SMALL
+// the tail is cheaper as its own launch of 128x128 tiles (two workgroups per CU, 72 workgroups for FF1's 3 x 6 tiles): the logical tile order walks
+// the last group of row tiles column by column, so the last `rem` tiles lie inside the rectangle [last row group] x [last ceil(rem / gsz) tile
+// columns]; the persistent launch stops in front of it (GemmP::tile_limit) and the rectangle runs as a plain sub-problem (pointers advanced).  Same K
+// order and rounding points: bit-equal to the one-launch form (test_gemm_w4_tail_rectangle).
+struct TailRect { bool use = false; int limit = 0; long long r0 = 0, c0 = 0; };
+constexpr int W4_TAIL_MAX = 32;
+inline TailRect plan_tail_rect(const GemmP& p, int epi) {
+  TailRect t;
+  if (p.wb_tiles_m || (p.tuning & MRAG_GEMM_TUNE_NO_TAIL_RECT)) return t;
+  if (!(epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID)) return t;   // (epilogues whose arithmetic does not depend on a row's absolute index)
+  const long long tiles = (long long)p.tiles_m * p.tiles_n;
+  const int rem = (int)(tiles % SK_CUS);
+  if (tiles < 2 * SK_CUS || rem == 0 || rem > W4_TAIL_MAX) return t;
+  const int first_m = ((p.tiles_m - 1) / p.group_m) * p.group_m, gsz = p.tiles_m - first_m;
+  const int ncols = (rem + gsz - 1) / gsz;
+  if (ncols > p.tiles_n) return t;
+  t.use = true;
+  t.limit = (int)(tiles - (long long)gsz * ncols);
+  t.r0 = (long long)first_m * 256; t.c0 = (long long)(p.tiles_n - ncols) * 256;
+  return t;
+}
+
 // the persistent four-wave launch: one workgroup per CU, 128 KB of LDS
 inline int launch_w4(hipStream_t s, const GemmP& p0, int epi) {
   // the K-tile stream walks A and W with 32-bit byte offsets inside a 256-row panel: (row * ld + chunk) * 2 with row <= 255 must stay below 4 GiB
   // (a view with a huge leading dimension goes to the 8-wave kernel, whose row pointers are 64-bit)
   if (256LL * (p0.lda > p0.ldw ? p0.lda : p0.ldw) * 2 >= (1LL << 32)) return MRAG_ENOTSUP;
   GemmP p = p0;
-  p.tiles_m = (int)((p.M + 255) / 256);
+  const bool wb = p.w_bstride != 0;
+  if (wb) {                                     // per-sample weights: the row-tile grid restarts at every sample
+    if (epi != MRAG_EPI_NONE || p.rows_per_batch <= 0 || p.M % p.rows_per_batch != 0) return MRAG_ENOTSUP;
+    p.wb_tiles_m = (int)((p.rows_per_batch + 255) / 256);
+    p.tiles_m = (int)(p.M / p.rows_per_batch) * p.wb_tiles_m;
+  } else {
+    p.wb_tiles_m = 0;
+    p.tiles_m = (int)((p.M + 255) / 256);
+  }
   p.tiles_n = (int)((p.N + 255) / 256);
   p.group_m = ((p.tuning >> 8) & 0xff) ? ((p.tuning >> 8) & 0xff) : 4;
   const long long tiles = (long long)p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(tiles < SK_CUS ? tiles : SK_CUS)), block(256);
   // the LDS-staged epilogue needs 16-byte aligned rows of C (and of the residual); otherwise the direct 8-byte store path runs
   p.staged = (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0) && (!p.resid || ((p.ldr % 8 == 0) && (((uintptr_t)p.resid & 15) == 0)));
   if (p.tuning & MRAG_GEMM_TUNE_NO_STAGED) p.staged = 0;
+  const TailRect tail = plan_tail_rect(p, epi);
+  p.tile_limit = tail.use ? tail.limit : (int)tiles;
+  const dim3 grid((unsigned)(p.tile_limit < SK_CUS ? p.tile_limit : SK_CUS)), block(256);
   const size_t lds = 131072 + 32768;   // two operand stages + 8 KB of epilogue staging per wave: all 160 KB of a CU
-#define MRAG_W4_CASE(E)                                                                                \
-  case E: {                                                                                            \
-    auto kfn = gemm_w4_kernel<E>;                                                                      \
+#define MRAG_W4_LAUNCH(...)                                                                            \
+  {                                                                                                    \
+    auto kfn = gemm_w4_kernel<__VA_ARGS__>;                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
-    break;                                                                                             \
   }
   switch (epi) {
-    MRAG_W4_CASE(MRAG_EPI_NONE)
-    MRAG_W4_CASE(MRAG_EPI_GELU_TANH)
-    MRAG_W4_CASE(MRAG_EPI_RESID)
-    MRAG_W4_CASE(MRAG_EPI_GATE_RESID)
+    case MRAG_EPI_NONE:
+      if (wb) MRAG_W4_LAUNCH(MRAG_EPI_NONE, true) else MRAG_W4_LAUNCH(MRAG_EPI_NONE)
+      break;
+    case MRAG_EPI_GELU_TANH: MRAG_W4_LAUNCH(MRAG_EPI_GELU_TANH) break;
+    case MRAG_EPI_RESID: MRAG_W4_LAUNCH(MRAG_EPI_RESID) break;
+    case MRAG_EPI_GATE_RESID: MRAG_W4_LAUNCH(MRAG_EPI_GATE_RESID) break;
     case MRAG_EPI_GEGLU:
-    case EPI_GEGLU_TANH: {                // whole 128-column wave tiles, aligned rows of C [M, N / 2]
+    case EPI_GEGLU_TANH:                  // whole 128-column wave tiles, aligned rows of C [M, N / 2]
       if (!p.staged || p.N % 128 != 0) return MRAG_ENOTSUP;
-      if (epi == MRAG_EPI_GEGLU) {
-        auto kfn = gemm_w4_kernel<MRAG_EPI_GEGLU>;
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        MRAG_LAUNCH(kfn, grid, block, lds, s, p);
-      } else {
-        auto kfn = gemm_w4_kernel<EPI_GEGLU_TANH>;
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        MRAG_LAUNCH(kfn, grid, block, lds, s, p);
-      }
+      if (epi == MRAG_EPI_GEGLU) MRAG_W4_LAUNCH(MRAG_EPI_GEGLU) else MRAG_W4_LAUNCH(EPI_GEGLU_TANH)
       break;
-    }
-    case MRAG_EPI_QKNORM_ROPE: {          // fast epilogue path only: whole 128-column wave tiles inside one third, aligned rows
+    case MRAG_EPI_QKNORM_ROPE:            // fast epilogue path only: whole 128-column wave tiles inside one third, aligned rows
       if (!p.staged || p.N % 128 != 0 || p.qk_D % 128 != 0) return MRAG_ENOTSUP;
-      auto kfn = gemm_w4_kernel<MRAG_EPI_QKNORM_ROPE>;
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      MRAG_LAUNCH(kfn, grid, block, lds, s, p);
+      MRAG_W4_LAUNCH(MRAG_EPI_QKNORM_ROPE)
       break;
-    }
     default: return MRAG_ENOTSUP;
   }
-#undef MRAG_W4_CASE
+#undef MRAG_W4_LAUNCH
   MRAG_LAUNCH_CHECK();
-  MRAG_COUNT(epi == MRAG_EPI_QKNORM_ROPE ? MRAG_K_GEMM_W4_QKNORM_ROPE : (epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) ? MRAG_K_GEMM_W4_GEGLU : MRAG_K_GEMM_W4);
+  MRAG_COUNT(epi == MRAG_EPI_QKNORM_ROPE ? MRAG_K_GEMM_W4_QKNORM_ROPE : (epi == MRAG_EPI_GEGLU || epi == EPI_GEGLU_TANH) ? MRAG_K_GEMM_W4_GEGLU : wb ? MRAG_K_GEMM_W4_BATCHED_W : MRAG_K_GEMM_W4);
+  if (tail.use) {                               // the rectangle behind the whole rounds: rows [r0, M) x columns [c0, N) on 128x128 tiles
+    GemmP t = p0;
+    t.A = p0.A + tail.r0 * p0.lda; t.W = p0.W + tail.c0 * p0.ldw; t.C = p0.C + tail.r0 * p0.ldc + tail.c0;
+    if (p0.bias) t.bias = p0.bias + tail.c0;
+    if (p0.resid) t.resid = p0.resid + tail.r0 * p0.ldr + tail.c0;
+    t.M = p0.M - tail.r0; t.N = p0.N - tail.c0;
+    const int rc = launch_cfg<2, 2, 4, 4>(s, t, epi);
+    if (rc != MRAG_OK) return rc;
+    MRAG_COUNT(MRAG_K_GEMM_W4_TAIL_RECT);
+  }
   return MRAG_OK;
 }
 
@@ -1781,8 +1875,8 @@ inline int launch_k320(hipStream_t s, const GemmP& p, int epi) {
   return MRAG_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int CONV = 0>
-int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullptr) {
+template <int WM, int WN, int TM, int TN, int CONV>
+int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   GemmP p = p0;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -1795,7 +1889,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
   if (epi == MRAG_EPI_QKNORM_ROPE && !((WM == 2 && WN == 4 && TM == 8 && TN == 4) && p.staged)) return MRAG_ENOTSUP;   // lives in the LDS-staged epilogue
   const size_t lds_stages = 2 * (BM + BN) * 64 * 2;
   size_t lds = (WM == 2 && WN == 4 && TM == 8 && TN == 4 && lds_stages < 8 * 128 * 144) ? 8 * 128 * 144 : lds_stages;
-  if constexpr (CONV != 0) {   // eight parked words per lane (gemm_tile: cv_park)
+  if constexpr (CONV != 0 && WM == 2 && WN == 4 && TM == 8 && TN == 4) {   // the SLIM form's eight parked words per lane (gemm_tile: cv_park)
     p.cv_lds = (int)lds;
     lds += (size_t)WM * WN * 64 * 32;
   }
@@ -1836,7 +1930,7 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
     constexpr int tile = (BM == 256 && BN == 320) ? 1 : (BM == 256 && BN == 128) ? 2 : (BM == 128 && BN == 128) ? 3 : (BM == 192) ? 4 : 0;   // 0: 256x256 (8 or 16 waves)
     constexpr int ids[3][5] = {{MRAG_K_GEMM_256x256, MRAG_K_GEMM_256x320, MRAG_K_GEMM_256x128, MRAG_K_GEMM_128x128, MRAG_K_GEMM_192x256},
                                {MRAG_K_CONV3_256x256, MRAG_K_CONV3_256x320, MRAG_K_CONV3_256x128, MRAG_K_CONV3_128x128, MRAG_K_CONV3_192x256},
-                               {MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_256x256, MRAG_K_CONVT_128x128, MRAG_K_CONVT_192x256}};
+                               {MRAG_K_CONVT_256x256, MRAG_K_CONVT_256x320, MRAG_K_CONVT_256x128, MRAG_K_CONVT_128x128, MRAG_K_CONVT_192x256}};
     MRAG_COUNT(ids[CONV][tile]);
   }
   if constexpr (WM == 2 && WN == 4 && TM == 8 && TN == 4 && CONV == 0) {
@@ -1888,6 +1982,8 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
   p.acc_scale = a->acc_scale == 0.0f ? 1.0f : a->acc_scale;
+  if (a->w_batch_stride < 0 || a->w_batch_stride % 8 != 0) return MRAG_EINVAL;
+  p.w_bstride = a->w_batch_stride;
   if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
     if (a->qk_dmodel <= 0 || a->qk_dmodel % 64 != 0 || a->N % a->qk_dmodel != 0 || a->qk_first < 0 || a->qk_first + a->N / a->qk_dmodel > 3 ||
@@ -1918,6 +2014,14 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   // problems made of whole 128-column wave tiles: the persistent four-wave kernel -- 3-13 % ahead of the 8-wave 256x256 tile on the DiT's shapes, 8-27 %
   // on the UNets' N = 640 / 1280 linears (where it also replaces the 256x320 tile); behind the 8-wave tile where the epilogue of one wave per SIMD outweighs
   // a short K loop (GELU below K = 1536, anything below K = 320), and on shapes that would take its general epilogue path (profiles/r3_gemm_w4_ab.txt)
+  if (a->w_batch_stride != 0) {
+    // per-sample weights (the motion branch's folded score GEMM): the persistent four-wave kernel only -- whole 128-column wave tiles, aligned rows, no
+    // epilogue; anything else is the caller's loop over the samples
+    if (epi != MRAG_EPI_NONE || a->N % 128 != 0 || a->K < 320 || a->rows_per_batch <= 0 || a->M % a->rows_per_batch != 0 || a->ldc % 8 != 0 || (((uintptr_t)a->C) & 15) ||
+        (a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED)))
+      return MRAG_ENOTSUP;
+    return launch_w4(s, p, epi);
+  }
   if (skinny_applies(a, epi)) return launch_skinny(s, p, epi);       // M <= 256: eight waves split K, no LDS ring (gemm_skinny_kernel)
   if (k320_applies(a, epi)) return launch_k320(s, p, epi);           // K = 320, N = 320 .. 2 560: the weight in registers, activations streamed (gemm_k320_kernel)
   // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)

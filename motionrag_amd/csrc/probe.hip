@@ -6,6 +6,9 @@
 //   the upper bound of ANY bf16 kernel on the box in its current power state: the nominal 2.5 PFLOP/s assumes the 2.4 GHz peak clock, which the
 //   part does not hold under a dense matrix load on random data (profiles/r2_mfma_shape_power.txt).
 //   mrag_probe_mfma_f32: the same for v_mfma_f32_32x32x2_f32 (nominal 157 TFLOP/s), the pipe of the retrieval fan-out kernel.
+//   mrag_probe_stream_copy: a grid-stride copy with 16-byte loads and stores, four of each in flight per lane -- the 1 : 1 read / write stream every
+//   "HBM-bound" kernel of the library is priced against (the guide's float4 copy reaches 6.3 of the 8 TB/s; `dst.copy_(src)` on uint8, which bench.py
+//   quoted until round 5, only 4.8: not a ceiling -- the library's own LayerNorm and top-k kernels move more).
 #include "common.h"
 #include "../../include/mrag_hip.h"
 
@@ -67,7 +70,33 @@ __global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __rest
   out[t] = s;
 }
 
+// 16 bytes per lane and access, UNROLL independent loads before the first store; consecutive lanes touch consecutive 16-byte pieces, a workgroup's UNROLL
+// accesses are UNROLL contiguous 4-KiB runs one grid stride apart
+template <int UNROLL>
+__global__ __launch_bounds__(256) void probe_stream_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long n16) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) dst[i + u * stride] = v[u];
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+extern "C" int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes) {
+  if (!src || !dst || bytes < 16 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MRAG_EINVAL;
+  const long long n16 = bytes / 16;
+  long long wgs = (n16 + 4 * 256 - 1) / (4 * 256);
+  if (wgs > 256 * 8) wgs = 256 * 8;                   // 8 workgroups per CU: 32 waves, 128 KiB of loads in flight per CU
+  MRAG_LAUNCH((probe_stream_copy_kernel<4>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, n16);
+  MRAG_LAUNCH_CHECK();
+  return MRAG_OK;
+}
 
 extern "C" int64_t mrag_probe_mfma_f32_flops(int32_t iters) {
   // 256 workgroups x 4 waves x iters x 32 MFMAs x (2 * 32 * 32 * 2) FLOP

@@ -41,8 +41,16 @@ struct GnP {
   const bf16_t* mod;
   int mT, mH, mW, mTz, mshift, msplit;
   long long y_stride_n;
+  unsigned* tickets;   // FOLD: one arrival counter per sample (zero between calls)
+  float* ab;           // FOLD: per-(n, c) scale / shift
 };
 
+constexpr int GN_TICKET_BYTES = 16384, GN_FOLD_MAX_CHUNKS = 128;   // the last-arriver fold: up to 4096 samples, up to 128 chunk partials per channel
+
+// FOLD: the workgroup that arrives LAST for a sample (ticket) also does pass 2 for that sample -- one launch less per GroupNorm (105 / 145 launches of 10-13 us
+// per SVD / DynamiCrafter CFG step).  Taken when the partial lists are short (<= 128 chunks: the per-frame norms of the spatial blocks, N = 28 / 32 samples);
+// the (t, h, w) norms of the temporal blocks (N = 2, 1024 chunks: 2.6-10 MB of partials per sample) keep the parallel fold kernel below.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int c_off = blockIdx.z * 2048;                                  // channel segment of at most 2048 channels
@@ -81,6 +89,59 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
     float* out = p.part + (((long long)n * p.chunks + chunk) * p.C + c_off + threadIdx.x * 8) * 2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { out[2 * e] = ts[e]; out[2 * e + 1] = ts[8 + e]; }
+  }
+  if constexpr (FOLD) {
+    // ---- arrival: every partial of this workgroup has left, then the ticket (agent-scope release / acquire, the pattern of topk_scan_kernel's fused merge)
+    float* fl = &red[0][0];                                 // 4 352 floats, free again behind the barrier below: [0, C) sums, [2048, 2048 + C) squares, [4096, ..) groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned total = gridDim.x * gridDim.z;
+      const unsigned old = __hip_atomic_fetch_add(p.tickets + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = old == total - 1;
+      if (last) {
+        __hip_atomic_store(p.tickets + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next call
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      fl[4351] = last ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (fl[4351] == 0.f) return;
+    __syncthreads();
+    // ---- pass 2 for sample n, fixed orders (bit-reproducible): per channel over the chunks, then the analytic embedding terms, per group over its channels
+    const int C = (int)p.C, cpg = C / p.G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float cs = 0.f, cq = 0.f;
+      const float2* pr = (const float2*)p.part + (long long)n * p.chunks * C + c;
+      for (int k = 0; k < p.chunks; ++k) { const float2 v = pr[(long long)k * C]; cs += v.x; cq += v.y; }
+      if (p.emb) {
+        const float e = bf2f(p.emb[(long long)n * p.emb_stride + c]);
+        cq += 2.f * e * cs + (float)p.HW * e * e;           // sum (x+e)^2 = sum x^2 + 2 e sum x + P e^2
+        cs += (float)p.HW * e;
+      }
+      fl[c] = cs; fl[2048 + c] = cq;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < p.G; g += 256) {
+      float gs = 0.f, gq = 0.f;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { gs += fl[c]; gq += fl[2048 + c]; }
+      const float cnt = (float)p.HW * (float)cpg;
+      const float mean = gs / cnt;
+      const float var = fmaxf(gq / cnt - mean * mean, 0.f);
+      fl[4096 + 2 * g] = mean; fl[4097 + 2 * g] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int g = c / cpg;
+      const float mean = fl[4096 + 2 * g], rstd = fl[4097 + 2 * g];
+      const float ga = p.gamma ? bf2f(p.gamma[c]) : 1.f, be = p.beta ? bf2f(p.beta[c]) : 0.f;
+      const float e = p.emb ? bf2f(p.emb[(long long)n * p.emb_stride + c]) : 0.f;
+      p.ab[((long long)n * C + c) * 2] = ga * rstd;
+      p.ab[((long long)n * C + c) * 2 + 1] = be + (e - mean) * ga * rstd;
+    }
   }
 }
 
@@ -286,7 +347,7 @@ inline unsigned grid_for(long long items) {
 
 extern "C" int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks) {
   if (N <= 0 || C <= 0 || chunks <= 0) return 0;
-  return (N * chunks * C * 2 + N * C * 2) * (int64_t)sizeof(float);   // chunk partials + per-(n, c) scale / shift
+  return GN_TICKET_BYTES + (N * chunks * C * 2 + N * C * 2) * (int64_t)sizeof(float);   // arrival counters, chunk partials, per-(n, c) scale / shift
 }
 
 extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
@@ -304,17 +365,27 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   } else if (a->y_stride_n != 0) return MRAG_EINVAL;
   GnP p{};
   p.x = (const bf16_t*)a->x; p.y = (bf16_t*)a->y; p.gamma = (const bf16_t*)a->gamma; p.beta = (const bf16_t*)a->beta;
-  p.emb = (const bf16_t*)a->emb; p.part = (float*)a->workspace;
+  if (((uintptr_t)a->workspace) & 15) return MRAG_EINVAL;
+  p.emb = (const bf16_t*)a->emb; p.tickets = (unsigned*)a->workspace; p.part = (float*)((char*)a->workspace + GN_TICKET_BYTES);
   p.N = a->N; p.HW = a->HW; p.C = a->C; p.emb_stride = a->emb_stride; p.G = a->G; p.chunks = a->chunks; p.silu = a->silu; p.eps = a->eps;
   hipStream_t s = (hipStream_t)stream;
-  MRAG_LAUNCH(gn_stats_kernel, dim3(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048)), dim3(256), 0, s, p);
-  MRAG_LAUNCH_CHECK();
-  MRAG_COUNT(MRAG_K_GN_STATS);
   if (a->C / a->G > 256) return MRAG_ENOTSUP;
   float* ab = p.part + a->N * a->chunks * a->C * 2;
-  MRAG_LAUNCH(gn_fold_kernel, dim3((unsigned)a->G, (unsigned)a->N), dim3(256), 0, s, p, ab);
-  MRAG_LAUNCH_CHECK();
-  MRAG_COUNT(MRAG_K_GN_FOLD);
+  p.ab = ab;
+  const bool fold = a->chunks <= GN_FOLD_MAX_CHUNKS && a->C <= 2048 && a->G <= 127 && a->N <= GN_TICKET_BYTES / 4;
+  const dim3 sgrid(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048));
+  if (fold) {
+    MRAG_LAUNCH(gn_stats_kernel<true>, sgrid, dim3(256), 0, s, p);
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_GN_STATS_FOLD);
+  } else {
+    MRAG_LAUNCH(gn_stats_kernel<false>, sgrid, dim3(256), 0, s, p);
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_GN_STATS);
+    MRAG_LAUNCH(gn_fold_kernel, dim3((unsigned)a->G, (unsigned)a->N), dim3(256), 0, s, p, ab);
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_GN_FOLD);
+  }
   const size_t lds = (size_t)a->C * 2 * sizeof(float);
   if (a->mod) {
     p.mod = (const bf16_t*)a->mod; p.mT = a->mod_T; p.mH = a->mod_H; p.mW = a->mod_W; p.mTz = a->mod_Tz; p.mshift = a->mod_shift; p.msplit = a->mod_split;

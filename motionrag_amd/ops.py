@@ -20,7 +20,7 @@ LOG2E = 1.4426950408889634
 
 # Developer tuning knobs (tools/microbench.py, A/B tests): explicit `tuning` fields of the C-ABI argument structs, 0 = the shipped behaviour.
 # Nothing on the launch path reads the environment.
-TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False}
+TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False, "no_batched_w": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
 ATTN_TUNE_NO_TINY, ATTN_TUNE_LEGACY = 1, 8
 
@@ -137,18 +137,48 @@ GEMM_TUNE_NO_W4 = 1 << 16      # keep long-K linears on the 8-wave 256x256 tile 
 
 
 def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,
-                    out_scale: float = 1.0) -> torch.Tensor:
-    """hidden [B, S, H*64] += out_scale * softmax(scores[..., h, :keys] * scale) @ v[b // kv_batch_div, :, h]; scores [B, S, H*32] (keys padded to
-    32 per head), v [B', keys, H*64] (rows may be strided)."""
+                    out_scale: float = 1.0, key_stride: int = 32) -> torch.Tensor:
+    """hidden [B, S, H*64] += out_scale * softmax(scores[..., h, :keys] * scale) @ v[b // kv_batch_div, :, h]; scores [B, S, W] with key k of head h at
+    column key_stride * h + k (32: keys padded to 32 per head, W = 32 H; an even key_stride in [keys, 32] packs the heads, W >= (H - 1) key_stride + 32),
+    v [B', keys, H*64] (rows may be strided)."""
     _dev(scores, name="scores"); _dev(v, name="v"); _dev(hidden, name="hidden")
     B, S, W = scores.shape
-    if W != H * 32 or not scores.is_contiguous() or hidden.shape != (B, S, H * 64) or not hidden.is_contiguous():
-        raise ValueError("ip_attn_folded_: scores [B, S, H*32] and hidden [B, S, H*64], contiguous")
+    if W < (H - 1) * key_stride + 32 or not scores.is_contiguous() or hidden.shape != (B, S, H * 64) or not hidden.is_contiguous():
+        raise ValueError("ip_attn_folded_: scores [B, S, >= (H - 1) key_stride + 32] and hidden [B, S, H*64], contiguous")
     if v.shape[0] * kv_batch_div != B or v.shape[1] != keys or v.shape[2] != H * 64 or v.stride(2) != 1:
         raise ValueError("ip_attn_folded_: v [B / kv_batch_div, keys, H*64]")
     check(_lib.lib().mrag_ip_attn_folded_bf16(_stream(), _p(scores), _p(v), _p(hidden), B, S, H, keys, kv_batch_div, W, H * 64, v.stride(0), v.stride(1),
-                                              float(scale), float(out_scale)), "mrag_ip_attn_folded_bf16")
+                                              float(scale), float(out_scale), key_stride), "mrag_ip_attn_folded_bf16")
     return hidden
+
+
+def linear_per_sample(x: torch.Tensor, weight: torch.Tensor, *, out: Optional[torch.Tensor] = None, samples_per_weight: int = 1) -> torch.Tensor:
+    """out[b] = x[b] @ weight[b // samples_per_weight].T for x [B, S, K], weight [B', N, K]: ONE launch of the persistent GEMM with per-sample weights
+    (mrag_gemm_args.w_batch_stride) where the shape allows it, else a launch per sample.  Stands behind the motion branch's folded score GEMM."""
+    _dev(x, name="x"); _dev(weight, name="weight")
+    B, S, K = x.shape
+    Bw, N, Kw = weight.shape
+    if Kw != K or Bw * samples_per_weight != B or not x.is_contiguous() or not weight.is_contiguous():
+        raise ValueError(f"linear_per_sample: x {tuple(x.shape)} / weight {tuple(weight.shape)} / samples_per_weight {samples_per_weight}")
+    if out is None:
+        out = torch.empty(B, S, N, dtype=torch.bfloat16, device=x.device)
+    if Bw == 1:                                   # one weight for every sample: a plain GEMM over all rows
+        return linear(x, weight[0], out=out)
+    if samples_per_weight == 1 and B > 1 and K % 64 == 0 and out.is_contiguous() and not TUNING.get("no_batched_w"):
+        a = GemmArgs()
+        a.A, a.W, a.C = _p(x), _p(weight), _p(out)
+        a.M, a.N, a.K = B * S, N, K
+        a.lda, a.ldw, a.ldc = K, K, N
+        a.epilogue, a.tuning = EPI_NONE, TUNING["gemm"]
+        a.rows_per_batch, a.w_batch_stride = S, N * K
+        rc = _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))
+        if rc == 0:
+            return out
+        if rc != _lib.MRAG_ENOTSUP:
+            check(rc, "mrag_gemm_bf16 (per-sample weights)")
+    for b in range(B):
+        linear(x[b], weight[b // samples_per_weight], out=out[b])
+    return out
 
 
 def geglu_interleave(weight: torch.Tensor, bias: Optional[torch.Tensor]):
@@ -172,7 +202,8 @@ def _attn_workspace(device: torch.device, nbytes: int, kind: str = "split") -> t
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, kind)
     ws = _ATTN_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _ATTN_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # "gn": the first 16 KiB are mrag_groupnorm_bf16's arrival counters -- zero when the buffer is born, left zero by every call (include/mrag_hip.h)
+        ws = _ATTN_WS[key] = (torch.zeros if kind == "gn" else torch.empty)(nbytes, dtype=torch.uint8, device=device)
     return ws
 
 

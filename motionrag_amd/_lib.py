@@ -248,8 +248,16 @@ def lib() -> ctypes.CDLL:
     if L.mrag_abi_version() != ABI_VERSION:
         raise HipLibraryMissing(f"{LIB_PATH} has ABI {L.mrag_abi_version()}, expected {ABI_VERSION}: rebuild")
     L.mrag_source_hash.restype = c_char_p
-    have, want = L.mrag_source_hash().decode(), source_hash()
-    if have != want and not os.environ.get("MRAG_HIP_LIB_ANY_SOURCE"):      # the explicit override is for tools/ A/B runs of archived variant libraries
+    have = L.mrag_source_hash().decode()
+    if os.environ.get("MRAG_HIP_LIB_ANY_SOURCE"):                            # the explicit override is for tools/ A/B runs of archived variant libraries
+        want = have
+    else:
+        try:
+            want = source_hash()
+        except OSError as e:                                                 # a binary-only install: nothing to compare the stamp with
+            raise HipLibraryMissing(f"{LIB_PATH} carries stamp {have} but the sources it must be checked against are not readable ({e}); "
+                                    "set MRAG_HIP_LIB_ANY_SOURCE=1 to load a library without its sources") from e
+    if have != want:
         raise HipLibraryMissing(f"{LIB_PATH} was built from other sources (stamp {have}, sources beside it {want}): rebuild with "
                                 "`python -m motionrag_amd._lib` -- a stale or variant binary is never loaded silently")
     L.mrag_dispatch_name.restype = c_char_p

@@ -22,6 +22,7 @@ from torch import nn
 from . import ops
 
 
+PACK_SCORE_BLOCKS = True   # developer A/B knob (tools/r6_step_ab.py): False keeps the folded scores at 32 columns per head (round 5's layout)
 # fold `to_q_ip` into the motion keys once per clip (joint_attention_core); False reproduces the reference's op order literally
 FOLD_IP_QUERY = True
 
@@ -163,7 +164,7 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
             # KS = 32), else 32.  Both CFG samples' score GEMMs are ONE launch with per-sample weights (ops.linear_per_sample): 700 tiles = 3 rounds of
             # the persistent grid where two launches of 420 paid 2 + 2 (round 6).
             nk = ip.size(1)
-            KS = next((c for c in range(nk + (nk & 1), 32, 2) if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256)), 32)
+            KS = next((c for c in range(nk + (nk & 1), 32, 2) if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256)), 32) if PACK_SCORE_BLOCKS else 32
             NW = -(-((H - 1) * KS + 32) // 256) * 256 if KS != 32 else H * 32
 
             def build():
@@ -185,7 +186,7 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
             # cache hit only for the SAME tensor object at the same version: the entry keeps a reference to `ip`, so its address cannot be
             # recycled for another clip's tokens while the entry lives (a data_ptr key alone would go stale silently)
             ent = fw._cache.get("ipfold")
-            if ent is None or ent[0] is not ip or ent[1] != ip._version or ent[2] != (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight)):
+            if ent is None or ent[0] is not ip or ent[1] != ip._version or ent[2] != (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight)) or ent[5] != KS:
                 ent = (ip, ip._version, (_wkey(proc.to_q_ip[0].weight), _wkey(proc.to_k_ip[0].weight), _wkey(proc.to_v_ip[0].weight))) + build()
                 fw._cache["ipfold"] = ent
             M, v_ip = ent[3], ent[4]

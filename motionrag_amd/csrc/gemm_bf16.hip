@@ -964,9 +964,13 @@ inline long long round_cost(long long M, long long N, int BN) {
   const long long tiles = ((M + 255) / 256) * ((N + BN - 1) / BN);
   return ((tiles + 255) / 256) * BN;
 }
-inline bool wide_rounds_pay(long long M, long long N, int tuning = 0) {
+// (tail_rect: the caller will run a small partial last round of the 256x256 grid as its own launch of 128x128 tiles -- plan_tail_rect -- which costs about half
+// a round instead of a whole one)
+inline bool wide_rounds_pay(long long M, long long N, int tuning = 0, bool tail_rect = false) {
   if (tuning & MRAG_GEMM_TUNE_NO_WIDE) return false;
-  return round_cost(M, N, 320) * 100 < round_cost(M, N, 256) * 85;
+  long long c256 = round_cost(M, N, 256);
+  if (tail_rect) c256 = (((M + 255) / 256) * ((N + 255) / 256) / 256) * 256 + 128;
+  return round_cost(M, N, 320) * 100 < c256 * 85;
 }
 // DynamiCrafter's level 2 (M = 18 432 rows, N = 1 280) is 72 x 5 = 360 tiles of 256x256 -- two rounds, the second 41 % full -- and 288 of 256x320 (two rounds
 // of larger tiles: worse).  A 192-row tile (8 waves of 96 x 64; the generic K loop and the direct epilogue, ~8 % behind the pipelined 256x256 loop per FLOP)
@@ -2024,14 +2028,18 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   }
   if (skinny_applies(a, epi)) return launch_skinny(s, p, epi);       // M <= 256: eight waves split K, no LDS ring (gemm_skinny_kernel)
   if (k320_applies(a, epi)) return launch_k320(s, p, epi);           // K = 320, N = 320 .. 2 560: the weight in registers, activations streamed (gemm_k320_kernel)
-  // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
-  if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
-      a->epilogue != MRAG_EPI_QKNORM_ROPE)
-    return launch_cfg<2, 4, 8, 5>(s, p, epi);
-  if (t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 && a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
+  const bool w4_ok = t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 &&
+      a->K >= (epi == MRAG_EPI_GELU_TANH ? 1536 : 320) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
        epi == EPI_GEGLU_TANH) &&
-      a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0))) {
+      a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0));
+  const bool w4_tail = w4_ok && t256 >= 2 * SK_CUS && t256 % SK_CUS != 0 && t256 % SK_CUS <= W4_TAIL_MAX && !(a->tuning & MRAG_GEMM_TUNE_NO_TAIL_RECT) &&
+      (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID);                    // (plan_tail_rect's conditions)
+  // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
+  if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning, w4_tail) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&
+      a->epilogue != MRAG_EPI_QKNORM_ROPE)
+    return launch_cfg<2, 4, 8, 5>(s, p, epi);
+  if (w4_ok) {
     const int rc = launch_w4(s, p, epi);
     if (rc != MRAG_ENOTSUP) return rc;
   }

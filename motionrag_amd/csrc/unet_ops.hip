@@ -372,7 +372,11 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   if (a->C / a->G > 256) return MRAG_ENOTSUP;
   float* ab = p.part + a->N * a->chunks * a->C * 2;
   p.ab = ab;
+#ifdef MRAG_GN_NO_FOLD      // developer A/B build (tools/build_variant.sh): always the three-kernel form
+  const bool fold = false;
+#else
   const bool fold = a->chunks <= GN_FOLD_MAX_CHUNKS && a->C <= 2048 && a->G <= 127 && a->N <= GN_TICKET_BYTES / 4;
+#endif
   const dim3 sgrid(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048));
   if (fold) {
     MRAG_LAUNCH(gn_stats_kernel<true>, sgrid, dim3(256), 0, s, p);

@@ -404,6 +404,70 @@ def cogvideox_vae(frames=13, h=60, w=90, tiling=True):
     return res
 
 
+def r6():
+    """round 6's items at the BASELINE shapes, each against the form it replaces (same process, back to back)"""
+    import ctypes
+    from motionrag_amd import _lib
+    B, S, H, D = 2, 17776, 48, 3072
+    # (1) AdaLN LayerNorm [35 552, 3 072]: layernorm_stream_kernel (unless the library was built with -DMRAG_LN_NO_STREAM: tools/build_variant.sh)
+    x = torch.randn(B, S, D, device=DEV).to(torch.bfloat16)
+    w = torch.ones(D, device=DEV, dtype=torch.bfloat16)
+    md = (0.3 * torch.randn(B, 4, D, device=DEV)).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    with ops.dispatched() as d:
+        dt = timeit(lambda: ops.layernorm(x, w, w, 1e-5, out=y, shift0=md[:, 0], scale0=md[:, 1], shift1=md[:, 2], scale1=md[:, 3], rows_per_batch=S, split=226, mod_stride=md.stride(0)), iters=50)
+    print(f"r6 layernorm + AdaLN [{B*S},{D}] ({'/'.join(d.counts)}): {dt*1e6:.1f} us  {2*x.numel()*2/dt/1e12:.2f} TB/s")
+    # (2) the folded motion branch: scores as one launch with per-sample weights over packed 26-column blocks, vs round 5's two launches over 32-column blocks
+    o = torch.randn(B, S, H * 64, device=DEV).to(torch.bfloat16)
+    v = torch.randn(B, 25, H * 64, device=DEV).to(torch.bfloat16)
+    M32 = (torch.randn(B, H * 32, D, device=DEV) * 0.02).to(torch.bfloat16)
+    M26 = (torch.randn(B, 1280, D, device=DEV) * 0.02).to(torch.bfloat16)
+    sc32 = torch.empty(B, S, H * 32, device=DEV, dtype=torch.bfloat16)
+
+    def gemms32():
+        for b in range(B):
+            ops.linear(o[b], M32[b], out=sc32[b])
+    dt32 = timeit(gemms32, iters=30)
+    sc26 = torch.empty(B, S, 1280, device=DEV, dtype=torch.bfloat16)
+    with ops.dispatched() as d:
+        dt26 = timeit(lambda: ops.linear_per_sample(o, M26, out=sc26), iters=30)
+    print(f"r6 score GEMM: two launches x [17776 x 1536 x 3072] {dt32*1e6:.1f} us -> one launch, per-sample weights [35552 x 1280 x 3072] ({'/'.join(d.counts)}) {dt26*1e6:.1f} us")
+    f32 = timeit(lambda: ops.ip_attn_folded_(sc32, v, o, H, 25), iters=50)
+    f26 = timeit(lambda: ops.ip_attn_folded_(sc26, v, o, H, 25, key_stride=26), iters=50)
+    print(f"r6 ip_attn_folded: 32-column blocks {f32*1e6:.1f} us ({(sc32.numel()+2*o.numel())*2/f32/1e12:.2f} TB/s) -> 26-column blocks {f26*1e6:.1f} us ({(sc26.numel()+2*o.numel())*2/f26/1e12:.2f} TB/s)")
+    del sc32, sc26, M32, M26
+    # (3) FF1 + GELU [35 552 x 12 288 x 3 072]: 26 rounds + a 16-tile tail as a rectangle of 128x128 tiles vs a 27th round
+    wf = (torch.randn(4 * D, D, device=DEV) * 0.02).to(torch.bfloat16)
+    bfb = torch.zeros(4 * D, device=DEV, dtype=torch.bfloat16)
+    hid = torch.empty(B * S, 4 * D, device=DEV, dtype=torch.bfloat16)
+    x2 = x.view(B * S, D)
+    for name, tune in (("tail rectangle", 0), ("27th round", 1 << 19), ("tail rectangle", 0), ("27th round", 1 << 19)):
+        ops.TUNING["gemm"] = tune
+        with ops.dispatched() as d:
+            dt = timeit(lambda: ops.linear(x2, wf, bfb, out=hid, epilogue=ops.EPI_GELU_TANH), iters=20)
+        print(f"r6 FF1 + GELU, {name} ({'/'.join(d.counts)}): {dt*1e3:.3f} ms  {2.0*B*S*D*4*D/dt/1e12:.0f} TFLOP/s")
+    ops.TUNING["gemm"] = 0
+    del wf, hid
+    # (4) the stream-copy ceiling beside torch's copy
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=DEV).random_(0, 255)
+    dst = torch.empty_like(src)
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dtc = timeit(lambda: L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel()), iters=20)
+    dtt = timeit(lambda: dst.copy_(src), iters=20)
+    print(f"r6 1 GiB copy: library stream copy {2*src.numel()/dtc/1e12:.2f} TB/s, torch copy_ {2*src.numel()/dtt/1e12:.2f} TB/s")
+    del src, dst
+    # (5) how much a partial last round of the attention costs: query rows chosen so that the launch is 11.0 / 11.5 / 12.0 rounds of 768 resident workgroups
+    qkv = torch.randn(B, S, 3, H, 64, device=DEV).to(torch.bfloat16)
+    out = torch.empty(B, S, H * 64, device=DEV, dtype=torch.bfloat16)
+    for tiles in (88, 92, 96, 88, 92, 96):
+        sq = tiles * 192
+        qv = qkv[:, :sq, 0] if sq <= S else torch.randn(B, sq, H, 64, device=DEV).to(torch.bfloat16)
+        ov = out[:, :sq] if sq <= S else torch.empty(B, sq, H * 64, device=DEV, dtype=torch.bfloat16)
+        dt = timeit(lambda: ops.attention(qv, qkv[:, :, 1], qkv[:, :, 2], out=ov), iters=15)
+        print(f"r6 attention, {tiles} query tiles x 96 (b, h) = {tiles * 96 / 768:.2f} rounds of 768 workgroups: {dt*1e3:.3f} ms = {dt*1e3/(tiles*96/768):.4f} ms per round-equivalent")
+
+
 def topk_small():
     """the fan-out kernel at BASELINE config #1's table size (10 000 rows) x 256 queries, for a kernel trace (tools/prof.sh topk_small)"""
     db = torch.randn(10000, 768, device=DEV); q = torch.randn(256, 768, device=DEV)

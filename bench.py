@@ -48,6 +48,11 @@ def parse():
                          "classifier-free-guidance branch, 2.2 MB exchange per step (SURVEY 8e tier 1)")
     ap.add_argument("--no-attn-split", action="store_true", help="developer check: run long attention launches without the key-split tail, so that "
                     "sharded and unsharded runs use the same summation order (tests)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="NOT a measurement: the whole multi-rank control flow of this script (launcher child, rank -> clip mapping, "
+                    "process group, the sharding modes' collectives, end-of-loop gather, max-over-ranks timing, rank-0 JSON) on CPU over gloo with the DiT replaced by a "
+                    "shape-faithful fake -- what tests/test_dist_cpu.py runs at world 8 where no 8-GPU node exists; the printed line says dry_run_cpu: true")
+    ap.add_argument("--dry-run-rccl-env", action="store_true", help="print (JSON) the launcher command and the RCCL / HSA / HIP environment an N-rank run of this script will use, and exit "
+                    "without touching a GPU")
     ap.add_argument("--check", type=str, default=None, metavar="FILE.npy",
                     help="developer check: rank 0 saves its final latents (fp32 .npy) -- tests compare N = 1 with the sharded N > 1 runs")
     return ap.parse_args()
@@ -90,6 +95,82 @@ def build_models(dev, layers, lat_frames):
     dit.eval(); cam.eval()
     pipe = CogVideoXImageToVideoCTPipeline(dit, CogVideoXDDIMScheduler(), condition_transformer=cam)
     return dit, cam, pipe
+
+
+def build_fake_models(dev, lat_frames):
+    """--dry-run-cpu: stand-ins with the call signatures `main` uses and the shapes of the real workload (S = 226 + lat_frames * 1350 joint rows), cheap on CPU.
+    The fake DiT is built so that its sharded forms reproduce the unsharded result EXACTLY: per 'layer' every row adds the mean over ALL rows of a gathered
+    [K | V]-shaped tensor (one `all_gather_rows_async` per layer, as the real blocks issue), and the output rows are gathered once at the end (as
+    CogVideoXTransformer3DModel.forward does) -- so a wrong row range, rank order or clip mapping changes the printed checksums."""
+    from motionrag_amd.cogvideox import CogVideoXDDIMScheduler
+
+    class FakeDiT:
+        layers, text_len, width = 2, 226, 64
+
+        def __call__(self, latents, prompt, timestep, image_rotary_emb=None, image_latents=None, batch=None, sp=None):
+            from motionrag_amd.dist import SequenceParallel
+            B = batch
+            lat = latents.float().repeat(B // latents.shape[0], 1, 1, 1, 1)                       # CFG: both branches see the clip
+            rope, ip = image_rotary_emb                                                            # ((cos, sin), motion tokens [B, 25, 1024])
+            video = (lat + 0.5 * image_latents.float().repeat(B // latents.shape[0], 1, 1, 1, 1)).reshape(B, -1, self.width)      # [B, lat_frames * 1350, 64]
+            text = prompt.float()[:, :, :self.width] + ip.float().mean(dim=(1, 2))[:, None, None] + timestep.float()[:, None, None] * 1e-3
+            x = torch.cat([text, video], dim=1)                                                    # the joint [text ; video] sequence
+            S = x.shape[1]
+            lay = (SequenceParallel(0, 1) if sp is None else sp).layout(S, self.text_len)
+            xl = x[:, lay.r0:lay.r1].contiguous()
+            for i in range(self.layers):
+                kv = torch.cat([xl * (0.5 + i), xl * 0.25], dim=-1).contiguous()                  # this rank's K | V rows
+                full = kv if sp is None else sp.all_gather_rows_async(kv).wait()                   # [B, S, 2 W]: the per-block exchange of the real model
+                xl = xl + full[..., :self.width].double().mean(dim=1, keepdim=True).float() * 0.1 + full[..., self.width:].double().mean(dim=1, keepdim=True).float() * 0.1
+            out = xl
+            if sp is not None:                                                                     # [Sl, B, C] per rank -> [S, B, C] -> [B, S, C]
+                out = sp.all_gather(out.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+            return out[:, self.text_len:].reshape(B, *latents.shape[1:]).to(latents.dtype)
+
+    class FakePipe:
+        def __init__(self):
+            self.scheduler, self.action_emb = CogVideoXDDIMScheduler(), None
+
+        def prepare_action_embeddings(self, ref_videos, _unused, do_classifier_free_guidance=True, image=None):
+            g = torch.Generator().manual_seed(7)
+            return torch.randn(2 * ref_videos.shape[0], 25, 1024, generator=g).to(ref_videos.dtype)
+
+        def _prepare_rotary_positional_embeddings(self, frames, h, w, dev_):
+            return (torch.zeros(frames * h * w, 64), torch.zeros(frames * h * w, 64)), self.action_emb
+
+    return FakeDiT(), None, FakePipe()
+
+
+def fake_cfg_ddim_step_(v, latents, guidance, sa, sb, a, b_):
+    """--dry-run-cpu: the arithmetic of mrag_cfg_ddim_step_bf16 (v-prediction DDIM on the guided v) in torch, in place"""
+    n = latents.shape[0]
+    vu, vc = v[:n].float(), v[n:].float()
+    vg = vu + guidance * (vc - vu)
+    x = latents.float()
+    x0 = sa * x - sb * vg
+    latents.copy_((a * x + b_ * x0).to(latents.dtype))
+    return latents
+
+
+def rccl_env_report(args):
+    """--dry-run-rccl-env: what an N-rank run will be started with (no GPU call, no process group)"""
+    import socket
+    keys = sorted(k for k in os.environ if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "ROCR_", "GPU_", "MASTER_", "TORCH_NCCL", "AMD_")) or k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    try:
+        import torch.cuda
+        n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+    except Exception:                              # noqa: BLE001
+        n_dev = None
+    return {"dry_run_rccl_env": True, "gpus_requested": args.gpus, "visible_devices": n_dev, "hostname": socket.gethostname(),
+            "launcher_cmd": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", "<free port>",
+                             os.path.abspath(__file__), "--gpus", str(args.gpus), "--shard", args.shard],
+            "backend": "nccl (= RCCL on ROCm), init_process_group(device_id=cuda:<LOCAL_RANK>); one rank per GPU, 127.0.0.1 rendezvous",
+            "collectives": {"clips": "one all_gather_into_tensor of the ranks' final latents (2.2 MB per clip) at the end of the loop",
+                            "sequence": "per DiT block one async all_gather_into_tensor of this rank's K | V rows (54.6 MB per rank at N = 8), one all-gather of the output rows per forward",
+                            "cfg": "per step one 2.2 MB exchange inside rank pairs"}[args.shard],
+            "env": {k: os.environ[k] for k in keys},
+            "required": {"HSA_ENABLE_IPC_MODE_LEGACY": "0 (dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument on this pool)"},
+            "hsa_enable_ipc_mode_legacy_ok": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"}
 
 
 def _usable_cores() -> int:
@@ -240,6 +321,10 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.dry_run_rccl_env:
+        print(json.dumps(rccl_env_report(args)), flush=True)
+        return
+    dry = args.dry_run_cpu
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,28 +337,34 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; launch with --nproc-per-node {args.gpus}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    assert dry or torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists; --dry-run-cpu exercises the multi-rank control flow only and measures nothing)"
     # MRAG_BENCH_ONE_GPU=1 (developer check of the N > 1 code path on a single-GPU box): every rank uses cuda:0 and the collectives go
     # through gloo; the judged multi-GPU run is one rank per GPU over RCCL
     one_gpu = os.environ.get("MRAG_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
+    if dry:
+        dev = "cpu"
+    else:
+        torch.cuda.set_device(local)
+        dev = f"cuda:{local}"
     use_pg = world > 1 or launched
     if use_pg:
         import torch.distributed as dist
-        if one_gpu:
+        if one_gpu or dry:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
     from motionrag_amd import _lib, ops
     from motionrag_amd.dist import SequenceParallel, gather_latents
-    _lib.lib()   # fail loudly if the HIP library is missing
+    if not dry:
+        _lib.lib()   # fail loudly if the HIP library is missing
     ops.TUNING["attn_no_split"] = bool(args.no_attn_split)
+    cuda_sync = (lambda: None) if dry else torch.cuda.synchronize
+    cfg_step_ = fake_cfg_ddim_step_ if dry else ops.cfg_ddim_step_
 
     lat_frames = (args.frames - 1) // 4 + 1
-    dit, cam, pipe = build_models(dev, args.layers, lat_frames)
+    dit, cam, pipe = build_fake_models(dev, lat_frames) if dry else build_models(dev, args.layers, lat_frames)
     seq = args.shard == "sequence" and use_pg
     cfg_dp = args.shard == "cfg" and world > 1
     sp = SequenceParallel(rank, world) if seq else None
@@ -291,31 +382,33 @@ def main():
     image = torch.zeros(b, 3, 8, 8, dtype=torch.bfloat16, device=dev)
 
     # CAMA runs once per clip, before the loop (pipeline.py:86-88); timed separately
-    torch.cuda.synchronize()
+    cuda_sync()
     t0 = time.perf_counter()
     action_emb = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
-    torch.cuda.synchronize()
+    cuda_sync()
     cama_first_ms = (time.perf_counter() - t0) * 1e3
     runs = []
     for _ in range(5):                                    # median of five: one eager pass is ~190 launches, and a host hiccup (allocator, GC) in a single run reads as 60 ms
         t0 = time.perf_counter()
         action_emb = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
-        torch.cuda.synchronize()
+        cuda_sync()
         runs.append((time.perf_counter() - t0) * 1e3)
     cama_ms = sorted(runs)[len(runs) // 2]
 
     # the same as ONE HIP graph replay per clip (cama.GraphedPredict): CAMA is launch-bound when driven eagerly from Python
     cama_graph_ms = None
     try:
+        if dry:
+            raise RuntimeError("dry run: no HIP graph")
         from motionrag_amd.cama import GraphedPredict
         gp = GraphedPredict(cam, do_classifier_free_guidance=True)
         batch_ = {"ref_videos": ref_videos, "video": image[:, None].expand(-1, ref_videos.size(2), -1, -1, -1).contiguous()}
         gp(batch_)
-        torch.cuda.synchronize()
+        cuda_sync()
         t0 = time.perf_counter()
         for _ in range(5):
             gp(batch_)
-        torch.cuda.synchronize()
+        cuda_sync()
         cama_graph_ms = (time.perf_counter() - t0) / 5 * 1e3
     except Exception as e:                       # noqa: BLE001 -- reported, never fatal for the headline measurement
         cama_graph_ms = f"capture failed: {type(e).__name__}: {e}"[:200]
@@ -337,13 +430,13 @@ def main():
         else:                                                                  # this rank's guidance branch at batch b, then the pair's 2.2 MB exchange
             v = dit(latents, prompt_br, timestep[:b], image_rotary_emb=rope_br, image_latents=image_latents, batch=b)
             v = cfgp.gather_branches(v.view(1, *v.shape)).view(2 * b, *v.shape[1:])
-        ops.cfg_ddim_step_(v, latents, 6.0, *sched.coeffs(t))
+        cfg_step_(v, latents, 6.0, *sched.coeffs(t))
 
     def barrier():
         if use_pg:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        cuda_sync()
 
     for i in range(args.warmup):
         step(i)
@@ -358,18 +451,18 @@ def main():
     timing, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     assert torch.isfinite(gathered.float()).all(), "non-finite latents"
     # the box's measured ceilings, right after the timed region (the part is in the step's power state), rank 0 at N = 1 only
-    ceilings = measured_ceilings(dev) if (world == 1 and not args.no_ceilings) else None
+    ceilings = measured_ceilings(dev) if (world == 1 and not args.no_ceilings and not dry) else None
 
     # BASELINE's second metric, MEASURED outside the timed region: one whole clip = CAMA + 50 motion-injected DDIM steps (N = 1 only)
     e2e_sec, e2e_graph_sec = None, None
-    if world == 1 and not args.no_e2e and args.layers == 42 and args.frames == 49:
+    if world == 1 and not args.no_e2e and args.layers == 42 and args.frames == 49 and not dry:
         lat2 = torch.randn(b, lat_frames, 16, 60, 90, generator=g).to(dev, torch.bfloat16)
         lat2_init = lat2.clone()
-        torch.cuda.synchronize()
+        cuda_sync()
         t1 = time.perf_counter()
         ae = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
         out2 = pipe.denoise(lat2, image_latents, prompt, ae, num_inference_steps=50, guidance_scale=6.0)
-        torch.cuda.synchronize()
+        cuda_sync()
         e2e_sec = time.perf_counter() - t1
         assert torch.isfinite(out2.float()).all(), "non-finite latents after 50 steps"
         # the same clip with the DiT forward captured once as a HIP graph and replayed per step (bit-identical latents; the capture is inside the clock)
@@ -377,11 +470,11 @@ def main():
             if not args.e2e_graph:
                 raise StopIteration
             lat3 = lat2_init.clone()
-            torch.cuda.synchronize()
+            cuda_sync()
             t1 = time.perf_counter()
             ae = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
             out3 = pipe.denoise(lat3, image_latents, prompt, ae, num_inference_steps=50, guidance_scale=6.0, hip_graph=True)
-            torch.cuda.synchronize()
+            cuda_sync()
             e2e_graph_sec = time.perf_counter() - t1
             if not torch.equal(out3, out2):
                 e2e_graph_sec = "hip-graph clip differs from the eager clip"
@@ -394,7 +487,7 @@ def main():
     # the one its README's seconds-per-clip figures were taken on: CAMA + the whole loop, measured (N = 1 only; ~5 s)
     shipped_sec = None
     profiled = profiler_attached()
-    if world == 1 and not args.no_shipped_config and (args.shipped_config or not profiled) and args.layers == 42 and args.frames == 49:
+    if world == 1 and not args.no_shipped_config and (args.shipped_config or not profiled) and args.layers == 42 and args.frames == 49 and not dry:
         try:
             from motionrag_amd.cogvideox import make_scheduler
             gs = torch.Generator().manual_seed(4321)
@@ -403,11 +496,11 @@ def main():
             pipe.scheduler = make_scheduler("dpm")
             for timed in (False, True):              # one untimed pass builds the per-geometry caches (RoPE table, workspaces)
                 lat = lat5.clone()
-                torch.cuda.synchronize()
+                cuda_sync()
                 t1 = time.perf_counter()
                 ae = pipe.prepare_action_embeddings(ref_videos, None, do_classifier_free_guidance=True, image=image)
                 out5 = pipe.denoise(lat, img5, prompt, ae, num_inference_steps=25 if timed else 2, guidance_scale=3.0, generator=torch.Generator().manual_seed(9))
-                torch.cuda.synchronize()
+                cuda_sync()
                 shipped_sec = time.perf_counter() - t1
             assert torch.isfinite(out5.float()).all(), "non-finite latents after 25 DPM steps"
             pipe.scheduler = ddim
@@ -416,7 +509,7 @@ def main():
 
     # the other BASELINE.json configs, measured after the timed region and reported beside the headline (N = 1 only; ~20 s)
     secondary = None
-    if world == 1 and not args.no_secondary:
+    if world == 1 and not args.no_secondary and not dry:
         if args.cooldown > 0:
             time.sleep(args.cooldown)
         import contextlib
@@ -459,7 +552,7 @@ def main():
 
     if use_pg:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (one_gpu or dry) else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -486,7 +579,9 @@ def main():
             "metric": "denoise_step_frames_per_sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if seq else "weak", "vs_baseline": None,
             **({"latents_abs_mean": float(latents.float().abs().mean().item())} if args.check else {}),
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" if not dry else "DRY RUN on CPU over gloo with a fake DiT: NOT a measurement (bench.py --dry-run-cpu)",
+            **({"dry_run_cpu": True, "gathered_clip_checksums": [__import__("zlib").crc32(gathered[i].float().numpy().tobytes()) for i in range(gathered.shape[0])],
+                "rank0_clip_id": clip_id} if dry else {}),
             "config": {"workload": f"CogVideoX-5B-I2V DiT ({args.layers} layers) + CAMA motion injection, {args.frames}x480x720, CFG batch 2, "
                                    f"one DDIM denoise step per clip, " + (f"token sequence sharded sp{world} (K/V all-gather per block)" if seq else (f"CFG branches on rank pairs, dp{world // 2} x cfg2" if cfg_dp else f"clip-sharded dp{world}")),
                        "clips_per_gpu": b, "tokens": S,
@@ -503,7 +598,7 @@ def main():
             "shipped_config_skipped_reason": (None if isinstance(shipped_sec, float) else shipped_sec if isinstance(shipped_sec, str) else
                                               "rocprofv3 tool library injected (--shipped-config forces the clip)" if profiled and not args.no_shipped_config and world == 1 and not args.shipped_config
                                               else "not requested / N > 1 / reduced model"),
-            "process_group": (("gloo" if one_gpu else "nccl") + f", world {world}") if use_pg else None,
+            "process_group": (("gloo" if (one_gpu or dry) else "nccl") + f", world {world}") if use_pg else None,
             "secondary_workloads": secondary,
             "roofline": {"kernel": "attn16_kernel<3,4,3,true> + attn_combine_kernel (joint text+video flash attention on 16x16x32 MFMAs: optimistic sweep without a running max, row sums on the matrix pipe, key-split tail; 48 heads x 64, S=%d, B=2)" % S,
                          "bound": "mfma", "achieved": round(flops / avg / 1e12, 1) if durs else None, "peak": 2500.0, "unit": "TFLOP/s",
@@ -539,7 +634,7 @@ def main():
                                                           + sw["svd_temporal_vae_14x576x1024"]["encode_frame_ms"] + sw["rag_side_encoders_plus_cama"]["cama_predict_from_pixels_ms"]), 2)}
         except (KeyError, TypeError):
             out["e2e_sec_per_clip_other_pipelines_from_measured_parts"] = None
-        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 at N = 1 only (other ranks would idle in the barrier)
+        if not args.no_cpu_baseline and world == 1 and not dry:          # the CPU baseline is timed on rank 0 at N = 1 only (other ranks would idle in the barrier)
             dt, fl, cores, what = cpu_baseline_sample()
             full = dt * (step_flops / fl)
             out["cpu_baseline"] = {"value": round(args.frames / full, 6), "unit": "frames/s", "cores": cores, "machine_cores": os.cpu_count(), "kind": "port",

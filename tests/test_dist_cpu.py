@@ -2,6 +2,7 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -254,3 +255,69 @@ def test_config4_world8_gloo_real_geometry():
     mp.spawn(_w8_worker, args=(WORLD8, port, ret), nprocs=WORLD8, join=True)
     for r in range(WORLD8):
         assert ret[r] == {"kv_rows": True, "out_rows": True, "latents": True, "cfg": True}, (r, ret[r])
+
+
+# ---------------------------------------------------------------------------------------------- bench.py end to end at world 8 (round 6)
+def _bench_dry(tmp_path, gpus, shard, tag):
+    """`python bench.py --gpus N --shard ... --dry-run-cpu`: bench.py's own launcher child (torch.distributed.run, 127.0.0.1), N ranks over gloo, the DiT
+    replaced by a shape-faithful fake.  Returns (the JSON lines on stdout, rank 0's latents)."""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    chk = tmp_path / f"{tag}.npy"
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--shard", shard, "--dry-run-cpu", "--steps", "2", "--warmup", "1", "--check", str(chk)],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    return lines, np.load(chk)
+
+
+def test_bench_world8_clip_sharding_end_to_end_dry_run(tmp_path):
+    """what the first 8-GPU scaling run exercises besides RCCL itself: the launcher child, rank -> clip mapping (clip r on rank r), the end-of-loop gather in
+    rank-major order, the max-over-ranks time, whole-job `value`, and ONE line printed by rank 0"""
+    one, lat1 = _bench_dry(tmp_path, 1, "clips", "w1")
+    eight, lat8 = _bench_dry(tmp_path, 8, "clips", "w8")
+    assert len(one) == 1 and len(eight) == 1, "exactly one JSON line per run (rank 0 only)"
+    d = eight[0]
+    assert d["dry_run_cpu"] is True and "NOT a measurement" in d["data"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["process_group"] == "gloo, world 8" and d["config"]["parallelism"] == "dp8"
+    assert abs(d["value"] - 8 * 49 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]          # whole-job frames/s over all ranks
+    assert abs(d["frames_per_sec_per_gpu"] * 8 - d["value"]) <= 1e-3 * d["value"]
+    cs = d["gathered_clip_checksums"]
+    assert len(cs) == 8 and len(set(cs)) == 8, cs                                               # eight different clips came back
+    assert cs[0] == one[0]["gathered_clip_checksums"][0]                                        # clip 0 is the clip a single rank denoises
+    assert np.array_equal(lat1, lat8)                                                           # rank 0's own latents: bit for bit the one-rank run's
+
+
+def test_bench_world8_sequence_sharding_end_to_end_dry_run(tmp_path):
+    """--shard sequence (BASELINE config #4): ONE clip over 8 ranks, 17 776 = 8 x 2 222 rows; the per-block K | V gather and the output gather run through
+    SequenceParallel over the real process group, and the sharded fake forward reproduces the unsharded one bit for bit"""
+    one, lat1 = _bench_dry(tmp_path, 1, "clips", "s1")
+    eight, lat8 = _bench_dry(tmp_path, 8, "sequence", "s8")
+    d = eight[0]
+    assert len(eight) == 1 and d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["parallelism"] == "sp8"
+    assert abs(d["value"] - 49 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]              # one clip for the whole job
+    assert np.array_equal(lat1, lat8)
+
+
+def test_bench_world4_cfg_pairs_end_to_end_dry_run(tmp_path):
+    """--shard cfg: two clips on four ranks, each pair exchanging its guidance branches every step"""
+    four, lat4 = _bench_dry(tmp_path, 4, "cfg", "c4")
+    one, lat1 = _bench_dry(tmp_path, 1, "clips", "c1")
+    d = four[0]
+    assert len(four) == 1 and d["n_gpus"] == 4 and d["config"]["parallelism"] == "dp2xcfg2"
+    assert abs(d["value"] - 2 * 49 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert np.array_equal(lat1, lat4)
+
+
+def test_bench_dry_run_rccl_env_report():
+    import json
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shard", "sequence", "--dry-run-rccl-env"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["dry_run_rccl_env"] and d["gpus_requested"] == 8 and "--nproc-per-node=8" in d["launcher_cmd"] and "127.0.0.1" in d["launcher_cmd"]
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" in d["required"] and isinstance(d["hsa_enable_ipc_mode_legacy_ok"], bool)

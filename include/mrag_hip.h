@@ -85,6 +85,7 @@ enum mrag_kernel_id {
   MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
   MRAG_K_GEMM_W4_TAIL_RECT,    /* the 128x128-tile launch behind a persistent launch whose last round would be nearly empty (<= 32 tiles) */
   MRAG_K_GEMM_W4_BATCHED_W,    /* gemm_w4_kernel<NONE, true>: per-sample weights (w_batch_stride) */
+  MRAG_K_GEMM_SKINNY_LNA,      /* gemm_skinny_kernel<.., LNA>: LayerNorm of the A rows fused into the few-row GEMM's A load */
   MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
   MRAG_K_COUNT
 };
@@ -183,6 +184,12 @@ typedef struct mrag_gemm_args {
                               The motion branch's folded score GEMM (attn_processor.py:250-256: `to_q_ip` folded into each CFG sample's own motion keys) as ONE
                               launch for both samples.  MRAG_EPI_NONE, N % 128 == 0, K >= 320, M % rows_per_batch == 0, 16-byte aligned rows of C; any other
                               shape returns MRAG_ENOTSUP (the caller then loops over the samples).                                                          */
+  /* a_ln = 1: A := LayerNorm over K of every row of A (eps a_ln_eps, [K] bf16 a_ln_gamma / a_ln_beta or NULL), rounded to bf16, in FRONT of the product -- the
+   * `to_q(norm2(latents))` / `ff1(ln(latents))` pairs of CAMA's Perceiver layers (src/projects/condition/encoders/resampler.py:81-105, :52-63) as one launch.
+   * Bit-identical to mrag_layernorm_bf16 followed by this GEMM.  Few-row problems only (M <= 256: the K-split kernel reads all of K per row tile anyway),
+   * MRAG_EPI_NONE or MRAG_EPI_GELU_ERF; anything else returns MRAG_ENOTSUP and the caller launches the LayerNorm itself.                                       */
+  const void* a_ln_gamma; const void* a_ln_beta;
+  float a_ln_eps; int32_t a_ln;
 } mrag_gemm_args;
 enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_GEGLU_NO_STAGED = 4, MRAG_GEMM_TUNE_STREAMK = 8,
        MRAG_GEMM_TUNE_NO_W4 = 1 << 16, /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */

@@ -55,6 +55,7 @@ class GemmArgs(Structure):
         ("q_gamma", c_void_p), ("q_beta", c_void_p), ("k_gamma", c_void_p), ("k_beta", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
         ("qk_dmodel", c_int64), ("qk_eps", c_float), ("q_premul", c_float), ("qk_first", c_int32), ("tuning", c_int32), ("geglu_act", c_int32),
         ("workspace", c_void_p), ("acc_scale", c_float), ("workspace_bytes", c_int64), ("w_batch_stride", c_int64),
+        ("a_ln_gamma", c_void_p), ("a_ln_beta", c_void_p), ("a_ln_eps", c_float), ("a_ln", c_int32),
     ]
 
 

@@ -25,8 +25,24 @@ inline int gemm(void* s, const void* A, const void* W, const void* bias, void* C
   return mrag_gemm_bf16(s, &g);
 }
 
+// C = epilogue(LayerNorm(A) . W^T): ONE launch where the few-row kernel takes it (mrag_gemm_args.a_ln: bit-identical to the two launches), else LayerNorm into
+// `scratch` and the plain GEMM
+inline int ln(void* s, const void* x, void* y, const void* w, const void* b, int64_t rows, int64_t D, float eps, int64_t y_rows_per_batch, int64_t y_batch_stride);
+inline int gemm_ln(void* s, const void* A, const void* lw, const void* lb, float eps, void* scratch, const void* W, void* C, int64_t M, int64_t N, int64_t K, int epi) {
+  mrag_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.epilogue = epi;
+  g.a_ln = 1; g.a_ln_gamma = lw; g.a_ln_beta = lb; g.a_ln_eps = eps;
+  const int rc = mrag_gemm_bf16(s, &g);
+  if (rc != MRAG_ENOTSUP) return rc;
+  const int rl = ln(s, A, scratch, lw, lb, M, K, eps, 0, 0);
+  if (rl != 0) return rl;
+  return gemm(s, scratch, W, nullptr, C, M, N, K, epi, nullptr);
+}
+
 inline int ln(void* s, const void* x, void* y, const void* w, const void* b, int64_t rows, int64_t D, float eps, int64_t y_rows_per_batch = 0,
-              int64_t y_batch_stride = 0) {
+              int64_t y_batch_stride = 0);
+inline int ln(void* s, const void* x, void* y, const void* w, const void* b, int64_t rows, int64_t D, float eps, int64_t y_rows_per_batch, int64_t y_batch_stride) {
   mrag_ln_args a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.y = y; a.gamma = w; a.beta = b; a.rows = rows; a.D = D; a.ldx = D; a.ldy = D; a.eps = eps;
@@ -95,8 +111,7 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     // PerceiverAttention.forward :81-105 -- LN1(x) and LN2(latents) land directly in the [x ; latents] concat buffer
     TRY(ln(stream, w.x, w.kv_in, L.norm1_w, L.norm1_b, N * n1, dim, a->eps, n1, (n1 + nq) * dim));
     TRY(ln(stream, lat, w.kv_in + n1 * dim, L.norm2_w, L.norm2_b, N * nq, dim, a->eps, nq, (n1 + nq) * dim));
-    TRY(ln(stream, lat, w.ln_lat, L.norm2_w, L.norm2_b, N * nq, dim, a->eps));
-    TRY(gemm(stream, w.ln_lat, L.to_q, nullptr, w.q, N * nq, inner, dim, MRAG_EPI_NONE, nullptr));
+    TRY(gemm_ln(stream, lat, L.norm2_w, L.norm2_b, a->eps, w.ln_lat, L.to_q, w.q, N * nq, inner, dim, MRAG_EPI_NONE));                     // to_q(norm2(latents)): one launch
     TRY(gemm(stream, w.kv_in, L.to_kv, nullptr, w.kv, N * (n1 + nq), 2 * inner, dim, MRAG_EPI_NONE, nullptr));                          // K rows first (chunk(2)) :96
     mrag_attn_args at;
     memset(&at, 0, sizeof(at));
@@ -111,8 +126,7 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     TRY(mrag_attn_fwd_bf16(stream, &at));
     TRY(gemm(stream, w.o, L.to_out, nullptr, lat_next, N * nq, dim, inner, MRAG_EPI_RESID, lat));                                        // attn(...) + latents :162
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
-    TRY(ln(stream, lat, w.h_ln, L.ff_ln_w, L.ff_ln_b, N * nq, dim, a->eps));
-    TRY(gemm(stream, w.h_ln, L.ff_w1, nullptr, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF, nullptr));
+    TRY(gemm_ln(stream, lat, L.ff_ln_w, L.ff_ln_b, a->eps, w.h_ln, L.ff_w1, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF));                     // gelu(ff1(ln(latents))): one launch
     TRY(gemm(stream, w.h, L.ff_w2, nullptr, lat_next, N * nq, dim, ff, MRAG_EPI_RESID, lat));                                            // ff(...) + latents :163
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
   }

@@ -66,6 +66,7 @@ struct GemmP {
   float acc_scale;    // MRAG_EPI_RESID: C = resid + acc_scale * (acc + bias) (1 unless the caller blends: AlphaBlender folded into a residual branch)
   float* sk_part; unsigned* sk_ticket;
   int sk_main, sk_rem, sk_units, sk_maxparts;
+  const bf16_t* lna_g; const bf16_t* lna_b; float lna_eps; int lna;   // gemm_skinny_kernel<.., LNA>: A := LayerNorm_K(A) * lna_g + lna_b in front of the product (either may be null)
   int tile_limit;     // gemm_w4_kernel: tiles [0, tile_limit) of the logical order (all of them, or the whole rounds in front of a tail launch: launch_w4)
   int wb_tiles_m;     // gemm_w4_kernel<EPI, true> (per-sample weights): 256-row tiles per sample -- the row-tile grid restarts at every sample; 0 otherwise
   long long w_bstride;   // elements between the samples' weight matrices
@@ -1712,7 +1713,12 @@ __global__ __launch_bounds__(640) void gemm_k320_kernel(const GemmP p) {
 // Long K (>= 2 048: the feed-forward's second projection) takes SIXTEEN waves over a 32 x 32 tile instead: half the K-steps per wave, twice the workgroups.
 constexpr int SKM_ROWS = 32;
 
-template <int EPI, int NWV, int COLS>
+// LNA (round 6): the LayerNorm in FRONT of the projection rides in the A load -- CAMA's Perceiver layers run `to_q(norm2(latents))` and `ff1(ln(latents))` over 250
+// rows, where the LayerNorm was a 6 us launch of its own in a chain of dependent launches.  A workgroup reads all of K for its 32 rows anyway: its waves first
+// compute the rows' statistics (4 or 2 rows per wave, the arithmetic of layernorm_kernel in norm.hip lane for lane: per-lane sums over idx = (c 64 + lane) 8,
+// the wave butterfly, mean, then the squared deviations -- so the normalised bf16 values are the SAME BITS the separate kernel writes), park them in LDS, and every
+// A fragment is normalised, scaled, shifted and rounded to bf16 in registers before its MFMAs.  Results are bit-identical to LayerNorm kernel + GEMM.
+template <int EPI, int NWV, int COLS, bool LNA = false>
 __global__ __launch_bounds__(64 * NWV) void gemm_skinny_kernel(const GemmP p) {
   constexpr int TJ = COLS / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1740,9 +1746,53 @@ __global__ __launch_bounds__(64 * NWV) void gemm_skinny_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nks = (int)(p.K / 32);
+  float ln_mean[2] = {0.f, 0.f}, ln_rstd[2] = {1.f, 1.f};
+  if constexpr (LNA) {
+    constexpr int RPWV = SKM_ROWS / NWV;                          // rows whose statistics this wave computes
+    const int D = (int)p.K;
+#pragma unroll
+    for (int rr = 0; rr < RPWV; ++rr) {
+      const int row_l = wave * RPWV + rr;
+      long long m = m0 + row_l;
+      m = m < p.M ? m : p.M - 1;
+      const bf16_t* x = p.A + m * p.lda;
+      float sum = 0.f;
+      for (int c = 0; c * 512 < D; ++c) {
+        const int idx = (c * 64 + lane) * 8;
+        if (idx < D) {
+          const u32x4 raw = *(const u32x4*)(x + idx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sum += __uint_as_float(raw[e] << 16); sum += __uint_as_float(raw[e] & 0xffff0000u); }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mean = sum / (float)D;
+      float sq = 0.f;
+      for (int c = 0; c * 512 < D; ++c) {
+        const int idx = (c * 64 + lane) * 8;
+        if (idx < D) {
+          const u32x4 raw = *(const u32x4*)(x + idx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d0 = __fsub_rn(__uint_as_float(raw[e] << 16), mean), d1 = __fsub_rn(__uint_as_float(raw[e] & 0xffff0000u), mean);
+            sq = __builtin_fmaf(d0, d0, sq); sq = __builtin_fmaf(d1, d1, sq);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (lane == 0) { part[2 * row_l] = mean; part[2 * row_l + 1] = rsqrtf(sq / (float)D + p.lna_eps); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ln_mean[i] = part[2 * (i * 16 + r)]; ln_rstd[i] = part[2 * (i * 16 + r) + 1]; }
+    __syncthreads();                                              // (the partial tiles reuse this LDS behind the K loop)
+  }
   auto steps = [&](auto U, const int ks0) __attribute__((always_inline)) {       // U K-steps of this wave from ks0: all loads first ((2 + TJ) U independent 16-byte loads in flight)
     constexpr int u_n = decltype(U)::value;
     bf16x8 a[u_n][2], w[u_n][TJ];
+    u32x4 lg[LNA ? u_n : 1], lb[LNA ? u_n : 1];
 #pragma unroll
     for (int u = 0; u < u_n; ++u) {
       const int k = (ks0 + u * NWV) * 32;
@@ -1750,6 +1800,27 @@ __global__ __launch_bounds__(64 * NWV) void gemm_skinny_kernel(const GemmP p) {
       for (int i = 0; i < 2; ++i) a[u][i] = *(const bf16x8*)(ap[i] + k);
 #pragma unroll
       for (int j = 0; j < TJ; ++j) w[u][j] = *(const bf16x8*)(wp[j] + k);
+      if constexpr (LNA) {
+        lg[u] = p.lna_g ? *(const u32x4*)(p.lna_g + k + kc) : u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        lb[u] = p.lna_b ? *(const u32x4*)(p.lna_b + k + kc) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    if constexpr (LNA) {                                           // o = (v - mean) * rstd [* gamma] [+ beta], ONE rounding to bf16: layernorm_kernel's arithmetic
+#pragma unroll
+      for (int u = 0; u < u_n; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, a[u][i]);
+          u32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o0 = __fmul_rn(__fsub_rn(__uint_as_float(raw[e] << 16), ln_mean[i]), ln_rstd[i]), o1 = __fmul_rn(__fsub_rn(__uint_as_float(raw[e] & 0xffff0000u), ln_mean[i]), ln_rstd[i]);
+            if (p.lna_g) { o0 = __fmul_rn(o0, __uint_as_float(lg[u][e] << 16)); o1 = __fmul_rn(o1, __uint_as_float(lg[u][e] & 0xffff0000u)); }
+            if (p.lna_b) { o0 = __fadd_rn(o0, __uint_as_float(lb[u][e] << 16)); o1 = __fadd_rn(o1, __uint_as_float(lb[u][e] & 0xffff0000u)); }
+            o4[e] = pack_bf2(o0, o1);
+          }
+          a[u][i] = __builtin_bit_cast(bf16x8, o4);
+        }
     }
 #pragma unroll
     for (int u = 0; u < u_n; ++u)
@@ -1759,7 +1830,8 @@ __global__ __launch_bounds__(64 * NWV) void gemm_skinny_kernel(const GemmP p) {
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[u][j], a[u][i], acc[i][j], 0, 0, 0);
   };
   int ks = wave;
-  for (; ks + 3 * NWV < nks; ks += 4 * NWV) steps(std::integral_constant<int, 4>{}, ks);
+  constexpr int UB = (LNA && NWV == 16) ? 2 : 4;   // K-steps whose loads are in flight together (sixteen waves leave 128 registers per lane: four steps + the LayerNorm's operands spilled)
+  for (; ks + (UB - 1) * NWV < nks; ks += UB * NWV) steps(std::integral_constant<int, UB>{}, ks);
   for (; ks < nks; ks += NWV) steps(std::integral_constant<int, 1>{}, ks);
   // accumulator layout: lane owns row i * 16 + (lane & 15), columns j * 16 + (lane >> 4) * 4 + {0..3}
   float* mine = part + wave * (SKM_ROWS * COLS);
@@ -1813,6 +1885,7 @@ inline bool skinny_applies(const mrag_gemm_args* a, int epi) {
 }
 
 inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
+  if (p.lna && !(epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_ERF)) return MRAG_ENOTSUP;   // the two forms CAMA runs: to_q(norm2(.)), gelu(ff1(ln(.)))
   // 16 waves x 32 columns where K is long and the 8-wave grid would leave most CUs idle ([250 x 1024 x 4096] 25.5 -> 20.1 us, [64 x 4096 x 4096] 26.1 -> 20.7;
   // a grid that already fills the chip loses: [128 x 4096 x 4096] 26.6 -> 34.6; profiles/r5_gemm_skinny_sweep.txt).  MRAG_GEMM_TUNE_SKINNY_8: the 8-wave form always (A/B runs)
   const long long wg8 = ((p.M + SKM_ROWS - 1) / SKM_ROWS) * ((p.N + 63) / 64);
@@ -1820,9 +1893,9 @@ inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
   const int cols = sixteen ? 32 : 64, nw = sixteen ? 16 : 8;
   const dim3 grid((unsigned)((p.N + cols - 1) / cols), (unsigned)((p.M + SKM_ROWS - 1) / SKM_ROWS)), block(64 * nw);
   const size_t lds = (size_t)nw * SKM_ROWS * cols * sizeof(float);
-#define MRAG_SKINNY_LAUNCH(E, W, C)                                                                    \
+#define MRAG_SKINNY_LAUNCH(E, W, ...)                                                                  \
   {                                                                                                    \
-    auto kfn = gemm_skinny_kernel<E, W, C>;                                                            \
+    auto kfn = gemm_skinny_kernel<E, W, __VA_ARGS__>;                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                \
     MRAG_LAUNCH(kfn, grid, block, lds, s, p);                                                          \
@@ -1831,6 +1904,13 @@ inline int launch_skinny(hipStream_t s, const GemmP& p, int epi) {
   case E:                                                                                              \
     if (sixteen) MRAG_SKINNY_LAUNCH(E, 16, 32) else MRAG_SKINNY_LAUNCH(E, 8, 64)                        \
     break;
+  if (p.lna) {
+    if (epi == MRAG_EPI_NONE) { if (sixteen) MRAG_SKINNY_LAUNCH(MRAG_EPI_NONE, 16, 32, true) else MRAG_SKINNY_LAUNCH(MRAG_EPI_NONE, 8, 64, true) }
+    else { if (sixteen) MRAG_SKINNY_LAUNCH(MRAG_EPI_GELU_ERF, 16, 32, true) else MRAG_SKINNY_LAUNCH(MRAG_EPI_GELU_ERF, 8, 64, true) }
+    MRAG_LAUNCH_CHECK();
+    MRAG_COUNT(MRAG_K_GEMM_SKINNY_LNA);
+    return MRAG_OK;
+  }
   switch (epi) {
     MRAG_SKINNY_CASE(MRAG_EPI_NONE)
     MRAG_SKINNY_CASE(MRAG_EPI_GELU_TANH)
@@ -1987,6 +2067,11 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
   p.rows_per_batch = a->rows_per_batch; p.split = a->split; p.gate_stride = a->gate_stride;
   p.acc_scale = a->acc_scale == 0.0f ? 1.0f : a->acc_scale;
   if (a->w_batch_stride < 0 || a->w_batch_stride % 8 != 0) return MRAG_EINVAL;
+  if (a->a_ln != 0 && a->a_ln != 1) return MRAG_EINVAL;
+  if (a->a_ln) {
+    if ((((uintptr_t)a->a_ln_gamma | (uintptr_t)a->a_ln_beta) & 15) || a->K > 8192) return MRAG_EINVAL;
+    p.lna = 1; p.lna_g = (const bf16_t*)a->a_ln_gamma; p.lna_b = (const bf16_t*)a->a_ln_beta; p.lna_eps = a->a_ln_eps;
+  }
   p.w_bstride = a->w_batch_stride;
   if (a->epilogue == MRAG_EPI_GEGLU && a->geglu_act != 0 && a->geglu_act != 1) return MRAG_EINVAL;
   if (a->epilogue == MRAG_EPI_QKNORM_ROPE) {
@@ -2026,6 +2111,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
       return MRAG_ENOTSUP;
     return launch_w4(s, p, epi);
   }
+  if (a->a_ln) return skinny_applies(a, epi) ? launch_skinny(s, p, epi) : MRAG_ENOTSUP;   // the LayerNorm-in-the-A-load form lives in the few-row kernel only: the caller runs LayerNorm + GEMM otherwise
   if (skinny_applies(a, epi)) return launch_skinny(s, p, epi);       // M <= 256: eight waves split K, no LDS ring (gemm_skinny_kernel)
   if (k320_applies(a, epi)) return launch_k320(s, p, epi);           // K = 320, N = 320 .. 2 560: the weight in registers, activations streamed (gemm_k320_kernel)
   const bool w4_ok = t256 >= 192 && !(a->tuning & (MRAG_GEMM_TUNE_NO_W4 | MRAG_GEMM_TUNE_NO_STAGED | MRAG_GEMM_TUNE_STREAMK | MRAG_GEMM_TUNE_NO_WIDE)) && a->N % 128 == 0 &&

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
     const long long idx = ((long long)c * 64 + lane) * 8;
     if (idx < p.D) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+      for (int e = 0; e < 8; ++e) { const float d = __fsub_rn(v[c][e], mean); sq = __builtin_fmaf(d, d, sq); }   // (explicit roundings: gemm_skinny_kernel<.., LNA> repeats this arithmetic and must get the same bits)
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
@@ -86,16 +86,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
     if (idx >= p.D) continue;
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+    for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(__fsub_rn(v[c][e], mean), rstd);
     if (p.gamma) {
       float g[8]; unpack8(*(const u32x4*)(p.gamma + idx), g);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] *= g[e];
+      for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(o[e], g[e]);
     }
     if (p.beta) {
       float bb[8]; unpack8(*(const u32x4*)(p.beta + idx), bb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += bb[e];
+      for (int e = 0; e < 8; ++e) o[e] = __fadd_rn(o[e], bb[e]);
     }
     if (shift) {
       float sc[8], sh[8];

@@ -120,6 +120,31 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def linear_ln(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], eps: float, weight: torch.Tensor, *,
+              epilogue: int = EPI_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(LayerNorm(x) @ weight.T): ONE launch where the few-row kernel takes it (mrag_gemm_args.a_ln: M <= 256, EPI_NONE / EPI_GELU_ERF; bit-identical
+    to layernorm + linear), else the two launches.  CAMA's `to_q(norm2(latents))` and `gelu(ff1(ln(latents)))`."""
+    _dev(x, name="x"); _dev(weight, name="weight")
+    x2 = _rows(x)
+    M, K = x2.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
+    if K % 64 == 0 and weight.shape[1] == K and x2.stride(0) == K and weight.is_contiguous():
+        o2 = _rows(out)
+        a = GemmArgs()
+        a.A, a.W, a.C = _p(x2), _p(weight), _p(o2)
+        a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, o2.stride(0)
+        a.epilogue, a.tuning = epilogue, TUNING["gemm"]
+        a.a_ln, a.a_ln_gamma, a.a_ln_beta, a.a_ln_eps = 1, _p(ln_weight), _p(ln_bias), eps
+        rc = _lib.lib().mrag_gemm_bf16(_stream(), ctypes.byref(a))
+        if rc == 0:
+            return out
+        if rc != _lib.MRAG_ENOTSUP:
+            check(rc, "mrag_gemm_bf16 (LayerNorm in the A load)")
+    return linear(layernorm(x, ln_weight, ln_bias, eps), weight, out=out, epilogue=epilogue)
+
+
 def _gemm_workspace(a: "GemmArgs", device: torch.device) -> None:
     """with TUNING["gemm"] & GEMM_TUNE_STREAMK: hand mrag_gemm_bf16 the scratch that turns a partial last round of 256x256 tiles into a stream-K tail (include/mrag_hip.h); the same grow-only
     per-(device, stream) buffers as the attention's: launches on one stream are ordered"""

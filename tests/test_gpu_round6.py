@@ -225,6 +225,33 @@ def test_conv_temporal_and_causal3d_256x256_tile(hip):
     close(got3, want3)
 
 
+# ---------------------------------------------------------------------------------------------- LayerNorm in the few-row GEMM's A load
+@pytest.mark.parametrize("M,N,K,epi", [(250, 1024, 1024, "none"), (250, 4096, 1024, "gelu"), (25, 1024, 1024, "gelu"), (16, 3072, 768, "none"), (251, 2048, 2048, "none")])
+def test_gemm_few_rows_layernorm_in_a_load(hip, M, N, K, epi):
+    """`to_q(norm2(latents))` / `gelu(ff1(ln(latents)))` of CAMA's Perceiver layers as ONE launch (mrag_gemm_args.a_ln): the rows' statistics and the normalised
+    bf16 operands are computed inside the few-row kernel with layernorm_kernel's arithmetic, so the result is BIT-identical to LayerNorm kernel + GEMM"""
+    from motionrag_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = bf(torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    lw, lb = bf(1 + 0.2 * torch.randn(K, generator=g)).to(DEV), bf(0.1 * torch.randn(K, generator=g)).to(DEV)
+    w = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    e = ops.EPI_GELU_ERF if epi == "gelu" else ops.EPI_NONE
+    with ops.dispatched() as d:
+        got = ops.linear_ln(x, lw, lb, 1e-5, w, epilogue=e)
+    assert d.counts == {"GEMM_SKINNY_LNA": 1}, d.counts
+    two = ops.linear(ops.layernorm(x, lw, lb, 1e-5), w, epilogue=e)
+    assert torch.equal(got, two)
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), lw.float(), lb.float(), 1e-5).to(torch.bfloat16).float() @ w.float().t()
+    close(got, torch.nn.functional.gelu(ref) if epi == "gelu" else ref, scale=ref.abs().mean().item())
+    assert torch.equal(ops.linear_ln(x, None, None, 1e-6, w, epilogue=e), ops.linear(ops.layernorm(x, None, None, 1e-6), w, epilogue=e))
+    # more than 256 rows: the two launches, same bits
+    xl = torch.cat([x, x])[:300].contiguous()
+    with ops.dispatched() as d:
+        big = ops.linear_ln(xl, lw, lb, 1e-5, w, epilogue=e)
+    assert "GEMM_SKINNY_LNA" not in d.counts and d.counts.get("LAYERNORM") == 1, d.counts
+    close(big[:M], two[:300], scale=ref.abs().mean().item())              # (another GEMM kernel above 256 rows: another K summation order, bf16-close)
+
+
 # ---------------------------------------------------------------------------------------------- stream-copy probe, retrieval second scoring
 def test_stream_copy_probe(hip):
     from motionrag_amd import _lib

@@ -14,7 +14,10 @@
 //        P'  = exp2(S') * 8            (the shift rides in m; it keeps small probabilities out of e4m3's subnormals and cancels in O / l)
 //        O^T = V8^T . P8^T             a lane's 32 packed P' bytes of one 64-key tile ARE its B operand (no cross-lane movement)
 //        O   = O^T / l * 2^-ev * out_scale
-//      fp32 softmax with the lazy running max of attn16.hip (re-centre when a 16-key partial row sum leaves e4m3's range).
+//      fp32 softmax with a LAZY running max: a row is centred on its first tile's maximum and moves only when a 64-key row sum of P' reaches e4m3's range.
+//      Round 6: the row sums ride the matrix pipe -- l^T = ONES . P8^T, one more MFMA per 64 keys whose every output register is the lane's complete tile sum
+//      (of the e4m3 values that multiply V) -- instead of 32 v_add per lane and sub-tile: the loop was bound by vector issue (32 v_exp + 32 v_add + 16 v_cvt_pk per
+//      four 64-cycle MFMAs), now it issues 32 v_exp + 16 v_cvt_pk against five MFMAs; waves switch priority by phase as in attn16.hip.
 // Operand maps were measured, not assumed: tools/exp/fp8_layout_probe.hip -> A[row = l & 31][k = 32 (l >> 5) + byte], B likewise, the lane's
 // scale byte applies to its own 32 k's (profiles/r2_fp8_layout_probe.txt).
 // Precision: e4m3 carries 3 mantissa bits: expect ~3-6 % relative Frobenius error against fp32 attention (tests state the tolerance);
@@ -30,8 +33,11 @@ constexpr int KT = 128;               // keys per LDS stage (two 64-key sub-tile
 constexpr int STAGE_K = KT * 64;      // 8 KB of K8
 constexpr int STAGE = 2 * STAGE_K;    // + 8 KB of V8
 constexpr int NS8 = 4;
-constexpr float kPShift = 3.0f;       // P' = 8 P
-constexpr float kBig8 = 448.0f;       // a 16-key partial row sum above e4m3's largest finite value -> some P' may not be representable
+constexpr float kPShift = 2.0f;       // P' = 4 P: a re-centred row's 64-key tile sums to at most 256, below the trigger
+constexpr float kBig8 = 448.0f;       // a 64-key row sum of P' at or above e4m3's largest finite value -> some P' may not have been representable: re-centre
+#ifndef MRAG_ATTN8_SETPRIO
+#define MRAG_ATTN8_SETPRIO 1          // wave priority by phase as in attn16.hip (score MFMAs 1, exp / convert block 0, P.V + row-sum MFMAs 2)
+#endif
 
 struct Fp8P {
   AttnP a;
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(512, 4) void attn8_kernel(const Fp8P fp) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; negm[i] = 0.f; }
   float m = 0.f, l = 0.f;
+  const i32x8 ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0 in every byte: the A operand of the row-sum MFMA
 
   constexpr int D = NS8 - 1;
   auto wait_pair = [&]() {
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(512, 4) void attn8_kernel(const Fp8P fp) {
     constexpr int OFF = decltype(stage_c)::value * STAGE + decltype(sub_c)::value * 4096;
     f32x16 s0, s1;
     bool recentre = (t == 0 && sub == 0);
-    float a0, a1;
+    float tile_sum;
+    i32x8 pb;
     for (int pass = 0;; ++pass) {
       u32x4 ka[2], kb[2];
       asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
@@ -222,24 +230,36 @@ __global__ __launch_bounds__(512, 4) void attn8_kernel(const Fp8P fp) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { negm[i] = -m; s0[i] -= delta; s1[i] -= delta; }
       }
-      a0 = 0.f; a1 = 0.f;
+#if MRAG_ATTN8_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s0[i] = __builtin_amdgcn_exp2f(s0[i]);
         s1[i] = __builtin_amdgcn_exp2f(s1[i]);
-        a0 += s0[i]; a1 += s1[i];
       }
-      const bool blown = !(a0 <= kBig8) || !(a1 <= kBig8);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        pb[v] = (int)pack4_fp8(s0[4 * v], s0[4 * v + 1], s0[4 * v + 2], s0[4 * v + 3]);
+        pb[4 + v] = (int)pack4_fp8(s1[4 * v], s1[4 * v + 1], s1[4 * v + 2], s1[4 * v + 3]);
+      }
+#if MRAG_ATTN8_SETPRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
+      // l^T[., q] = ONES . P8^T: every register of lane (q, .) is the sum of the tile's 64 e4m3 values of its query (the values that multiply V below)
+      f32x16 zero16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+      const f32x16 lt = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones8, pb, zero16, 0, 0, 0, scale_one, 0, scale_one);
+      tile_sum = lt[0];
+      const bool blown = !(tile_sum < kBig8);                        // a saturated (or non-finite) P' makes the sum reach 448; a re-centred tile sums to <= 256
       if (__builtin_expect(!__any(blown), 1) || recentre) break;
       recentre = true;
+#if MRAG_ATTN8_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
     }
-    l += a0 + a1;
-    i32x8 pb;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      pb[v] = (int)pack4_fp8(s0[4 * v], s0[4 * v + 1], s0[4 * v + 2], s0[4 * v + 3]);
-      pb[4 + v] = (int)pack4_fp8(s1[4 * v], s1[4 * v + 1], s1[4 * v + 2], s1[4 * v + 3]);
-    }
+    l += tile_sum;
     u32x4 va[2], vb[2];
     asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
                  "s_waitcnt lgkmcnt(0)"
@@ -249,6 +269,9 @@ __global__ __launch_bounds__(512, 4) void attn8_kernel(const Fp8P fp) {
     const i32x8 vf1 = {(int)vb[0][0], (int)vb[0][1], (int)vb[0][2], (int)vb[0][3], (int)vb[1][0], (int)vb[1][1], (int)vb[1][2], (int)vb[1][3]};
     o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf0, pb, o0, 0, 0, 0, scale_one, 0, scale_one);
     o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf1, pb, o1, 0, 0, 0, scale_one, 0, scale_one);
+#if MRAG_ATTN8_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
   };
   auto iter = [&](int t, auto stage_c) {
     constexpr int STG = decltype(stage_c)::value;
@@ -271,10 +294,7 @@ __global__ __launch_bounds__(512, 4) void attn8_kernel(const Fp8P fp) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (!wave_active || qrow >= p.Sq) return;
 
-  {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-    l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-  }
+  // (l is complete in every lane: the row-sum MFMA contracts over all 64 keys of a tile, both lane halves included)
   const float inv = ldexpf(p.out_scale, -ev) / l;
   // D of O^T = V^T . P^T: lane (query r32, half hh) holds d = 32 db + (i & 3) + 8 (i >> 2) + 4 hh
   const long long obase = (long long)b * p.o_sb + (long long)qrow * p.o_ss + h * 64 + 4 * hh;

@@ -41,7 +41,8 @@ def sdpa_fp32(q, k, v, scale=0.125):
 
 
 def sdpa_fp8_emulated(q, k, v, scale=0.125):
-    """what the kernel computes, in fp32 arithmetic: per-(b, h) power-of-two scales, e4m3 operands, exact softmax with P' = 8 P quantised"""
+    """what the kernel computes, in fp32 arithmetic: per-(b, h) power-of-two scales, e4m3 operands, exact softmax with P' = 4 P quantised (numerator AND row sum:
+    the kernel sums the e4m3 values on the matrix pipe, round 6)"""
     B, Sq, H, _ = q.shape
     out = torch.empty(B, Sq, H, 64)
     lazy_ok = torch.ones(B, Sq, H, dtype=torch.bool)
@@ -52,11 +53,12 @@ def sdpa_fp8_emulated(q, k, v, scale=0.125):
             y, ek, ev = pow2_fit(qq.abs().max().item() * c), pow2_fit(kk.abs().max().item()), pow2_fit(vv.abs().max().item())
             q8, k8, v8 = e4m3(qq * (c * 2.0 ** y)), e4m3(kk * 2.0 ** ek), e4m3(vv * 2.0 ** ev)
             s = (q8 @ k8.T) * 2.0 ** -(y + ek)                       # log2-domain scores
-            # the kernel's LAZY running max: a row is centred on the maximum of its first 64 keys (P' = 8 there) and stays there unless a
-            # 16-key partial sum of P' would leave e4m3's range (rows where that happens re-centre in the kernel: excluded by the caller)
-            p = torch.exp2(s - s[:, :64].amax(-1, keepdim=True) + 3.0)
-            lazy_ok[b, :, h] = p.amax(-1) <= 100.0
-            out[b, :, h] = (e4m3(p.clamp(max=448.0)) @ v8) / p.sum(-1, keepdim=True) * 2.0 ** -ev
+            # the kernel's LAZY running max: a row is centred on the maximum of its first 64 keys (P' = 4 there) and stays there unless the row sum of a
+            # 64-key tile of P' reaches e4m3's largest value, 448 (rows where that happens re-centre in the kernel: excluded by the caller, with a margin)
+            p = torch.exp2(s - s[:, :64].amax(-1, keepdim=True) + 2.0)
+            lazy_ok[b, :, h] = p.view(p.shape[0], -1, 64).sum(-1).amax(-1) <= 400.0
+            p8 = e4m3(p.clamp(max=448.0))
+            out[b, :, h] = (p8 @ v8) / p8.sum(-1, keepdim=True) * 2.0 ** -ev
     return out.reshape(B, Sq, H * 64), lazy_ok
 
 
@@ -110,8 +112,8 @@ def test_fp8_attention_recentre_and_scale_ranges(hip):
         sl = slice(64 * h, 64 * h + 64)
         assert rel_l2(got[..., sl], want[..., sl]) <= 0.08, h
         if h == 0:
-            continue          # head 0's first tile is depressed on purpose: many of its rows re-centre later (by 16-key partial sums, which the
-                              # emulation does not model) -> fp32 check only
+            continue          # head 0's first tile is depressed on purpose: many of its rows re-centre later (by 64-key tile sums, which the
+                              # emulation models only as an exclusion) -> fp32 check only
         rows = ok[0, :, h]
         assert rows.float().mean().item() > 0.95 and rel_l2(got[0, rows][:, sl], emu[0, rows][:, sl]) <= 0.012, h
     assert rel_l2(got[:, 77, :64], want[:, 77, :64]) <= 0.08

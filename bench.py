@@ -280,7 +280,7 @@ def measured_ceilings(dev, seconds: float = 1.0):
         out["d2d_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)                          # torch's uint8 copy kernel: reported for continuity, NOT a ceiling (round-5 review)
         L = _lib.lib()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        copy = lambda: _lib.check(L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel()), "mrag_probe_stream_copy")  # noqa: E731
+        copy = lambda: _lib.check(L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel(), 0), "mrag_probe_stream_copy")  # noqa: E731
         dt = timed(copy, 20)
         out["stream_copy_TBps"] = round(2 * src.numel() / dt / 1e12, 3)                       # the library's 16-byte grid-stride copy (csrc/probe.hip): the HBM ceiling of a 1 : 1 stream
         assert torch.equal(src[-4096:], dst[-4096:]) and torch.equal(src[:4096], dst[:4096])
@@ -570,7 +570,7 @@ def main():
         d = 3072
         step_flops = 2 * args.layers * (24 * S * d * d + 4 * S * S * d + 2 * S * d * d + 4 * S * 25 * d + 4 * 25 * 1024 * d)
         traffic, traffic_src = None, None
-        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_attn_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), None)   # newest rocprofv3 PMC pass of this kernel + shape (tools/pmc_traffic.sh)
+        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_attn_traffic.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), None)   # newest rocprofv3 PMC pass of this kernel + shape (tools/pmc_traffic.sh)
         if args.layers == 42 and args.frames == 49 and tp:
             with open(tp) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch_corrected"])

@@ -83,7 +83,7 @@ enum mrag_kernel_id {
   MRAG_K_LAYERNORM_STREAM,     /* layernorm_stream_kernel: persistent waves, AdaLN factors folded into registers (D = 3 072, >= 8 192 rows) */
   MRAG_K_GN_STATS_FOLD,        /* gn_stats_kernel<true>: statistics + the fold by the sample's last-arriving workgroup (<= 128 chunks) */
   MRAG_K_TOPK_SCAN, MRAG_K_TOPK_SCAN_FUSED_MERGE, MRAG_K_TOPK_MERGE, MRAG_K_TOPK_MFMA,
-  MRAG_K_GEMM_W4_TAIL_RECT,    /* the 128x128-tile launch behind a persistent launch whose last round would be nearly empty (<= 32 tiles) */
+  MRAG_K_GEMM_W4_TAIL_RECT,    /* (opt-in, MRAG_GEMM_TUNE_TAIL_RECT) the 128x128-tile launch behind a persistent launch whose last round would be nearly empty */
   MRAG_K_GEMM_W4_BATCHED_W,    /* gemm_w4_kernel<NONE, true>: per-sample weights (w_batch_stride) */
   MRAG_K_GEMM_SKINNY_LNA,      /* gemm_skinny_kernel<.., LNA>: LayerNorm of the A rows fused into the few-row GEMM's A load */
   MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
@@ -107,7 +107,7 @@ int64_t mrag_probe_mfma_f32_flops(int32_t iters);
 int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
 /* the HBM stream every "HBM-bound" kernel is priced against (`roofline.ceilings.stream_copy_TBps`: bytes read + bytes written per second): a grid-stride copy
  * of `bytes` (a multiple of 16; both pointers 16-byte aligned) with 16-byte loads and stores, four of each in flight per lane, 8 workgroups per CU.          */
-int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes);
+int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes, int32_t variant /* 0 = shipped form; developer sweep: bits 0-3 kernel form, bits 4-11 workgroups per CU */);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])     bf16 in/out      */
@@ -195,7 +195,8 @@ enum { MRAG_GEMM_TUNE_NO_WIDE = 1, MRAG_GEMM_TUNE_NO_STAGED = 2, MRAG_GEMM_TUNE_
        MRAG_GEMM_TUNE_NO_W4 = 1 << 16, /* keep long-K problems on the 8-wave 256x256 tile instead of the persistent four-wave kernel */
        MRAG_GEMM_TUNE_NO_SKINNY = 1 << 17, /* keep few-row problems (M <= 256) on the 128x128 tile instead of the K-split few-row kernel */
        MRAG_GEMM_TUNE_SKINNY_8 = 1 << 18, /* few-row kernel: eight waves x 64 columns also for K >= 2 048 (shipped there: sixteen waves x 32 columns) */
-       MRAG_GEMM_TUNE_NO_TAIL_RECT = 1 << 19 /* persistent kernel: a small partial last round stays in the launch (shipped: its own launch of 128x128 tiles) */ };
+       MRAG_GEMM_TUNE_TAIL_RECT = 1 << 19 /* persistent kernel: a small partial last round (<= 32 tiles) as its own launch of 128x128 tiles.  OPT-IN: measured equal
+                                              to the partial round it replaces (FF1 of the DiT: 2.24 vs 2.25 ms, the step unchanged: profiles/r6_microbench_items.txt) */ };
 
 int mrag_gemm_bf16(void* stream, const mrag_gemm_args* args);
 /* scratch bytes that let mrag_gemm_bf16 run its last, partial round of tiles as stream-K; 0 when the shape has nothing to gain */
@@ -542,10 +543,10 @@ int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n
 /* pre-add: `h + emb_out` of ResBlock._forward, openaimodel3d.py:216-229]     */
 /* [+ SiLU].  lvdm/basics.py:81-88; openaimodel3d.py:152-181,258-268;         */
 /* lvdm/modules/attention.py:286,357.  workspace: 16-byte aligned; its first  */
-/* 16 KiB are per-sample arrival counters (<= 128 chunks: the sample's last    */
-/* statistics workgroup also folds the partial sums -- one launch less): they  */
-/* must be ZERO before the first call on a workspace; every call leaves them   */
-/* zero.  Behind them: fp32 partial sums and per-(n, c) scale / shift.         */
+/* 16 KiB are per-sample arrival counters of the opt-in one-launch form        */
+/* (`fold`): they must be ZERO before the first call on a workspace; every     */
+/* call leaves them zero.  Behind them: fp32 partial sums, per-(n, c) scale /  */
+/* shift.                                                                      */
 typedef struct mrag_groupnorm_args {
   const void* x; void* y;          /* [N, HW, C] bf16                           */
   const void* gamma; const void* beta;   /* [C] bf16 or NULL                    */
@@ -563,6 +564,8 @@ typedef struct mrag_groupnorm_args {
   const void* mod;
   int32_t mod_T, mod_H, mod_W, mod_Tz, mod_shift, mod_split;
   int64_t y_stride_n;
+  int32_t fold;   /* 1: statistics + fold in ONE launch where the shape allows (<= 128 chunks; the sample's last-arriving workgroup folds).  Opt-in: measured 5 %
+                     slower on the UNet CFG steps than the separate fold launch (every workgroup pays a release in front of its ticket). 0 = shipped. */
 } mrag_groupnorm_args;
 int64_t mrag_groupnorm_workspace_bytes(int64_t N, int64_t C, int32_t chunks);
 int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* args);

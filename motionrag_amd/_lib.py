@@ -132,7 +132,7 @@ class GroupNormArgs(Structure):
         ("N", c_int64), ("HW", c_int64), ("C", c_int64), ("emb_stride", c_int64),
         ("G", c_int32), ("chunks", c_int32), ("silu", c_int32), ("eps", c_float),
         ("mod", c_void_p), ("mod_T", c_int32), ("mod_H", c_int32), ("mod_W", c_int32), ("mod_Tz", c_int32), ("mod_shift", c_int32), ("mod_split", c_int32),
-        ("y_stride_n", c_int64),
+        ("y_stride_n", c_int64), ("fold", c_int32),
     ]
 
 
@@ -270,7 +270,7 @@ def lib() -> ctypes.CDLL:
     L.mrag_probe_mfma_f32_flops.argtypes = [c_int32]
     L.mrag_probe_mfma_f32_flops.restype = c_int64
     L.mrag_probe_mfma_f32.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int32]
-    L.mrag_probe_stream_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
+    L.mrag_probe_stream_copy.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32]
     L.mrag_gemm_bf16.argtypes = [c_void_p, POINTER(GemmArgs)]
     L.mrag_attn_fwd_bf16.argtypes = [c_void_p, POINTER(AttnArgs)]
     L.mrag_gemm_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]

@@ -33,8 +33,10 @@ inline int gemm_ln(void* s, const void* A, const void* lw, const void* lb, float
   memset(&g, 0, sizeof(g));
   g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.epilogue = epi;
   g.a_ln = 1; g.a_ln_gamma = lw; g.a_ln_beta = lb; g.a_ln_eps = eps;
+#ifndef MRAG_CAMA_NO_LNA     // developer A/B build (tools/build_variant.sh): always the two launches
   const int rc = mrag_gemm_bf16(s, &g);
   if (rc != MRAG_ENOTSUP) return rc;
+#endif
   const int rl = ln(s, A, scratch, lw, lb, M, K, eps, 0, 0);
   if (rl != 0) return rl;
   return gemm(s, scratch, W, nullptr, C, M, N, K, epi, nullptr);

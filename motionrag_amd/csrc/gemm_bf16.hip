@@ -1490,7 +1490,10 @@ int launch_cfg(hipStream_t s, const GemmP& p0, int epi, const SkPlan* sk = nullp
 // The partial last round of the persistent grid as a RECTANGLE of small tiles.  One workgroup per CU: a launch costs ceil(tiles / 256) rounds however
 // full the last one is -- the DiT's FF1 (139 x 48 = 6 672 tiles = 26.06 rounds) pays a 27th round of 79 us for 16 tiles.  Stream-K over those tiles
 // measured slower (EXPERIMENTS.md section 3: the runs lose the lock-step that lets an XCD's L2 serve an operand panel once).  When the remainder is SMALL
-// the tail is cheaper as its own launch of 128x128 tiles (two workgroups per CU, 72 workgroups for FF1's 3 x 6 tiles): the logical tile order walks
+// the tail was EXPECTED to be cheaper as its own launch of 128x128 tiles (two workgroups per CU, 72 workgroups for FF1's 3 x 6 tiles) -- and MEASURED equal:
+// FF1 + GELU 2.236-2.246 ms against 2.245-2.257 ms, the denoise step 550.41 against 550.40 ms (profiles/r6_microbench_items.txt, r6_step_ab_toggles.txt): sixteen
+// tiles on sixteen CUs of an otherwise idle chip run well above the loaded rate, so the 27th round costs far less than a round.  OPT-IN
+// (MRAG_GEMM_TUNE_TAIL_RECT), kept with its test like the stream-K tail.  The logical tile order walks
 // the last group of row tiles column by column, so the last `rem` tiles lie inside the rectangle [last row group] x [last ceil(rem / gsz) tile
 // columns]; the persistent launch stops in front of it (GemmP::tile_limit) and the rectangle runs as a plain sub-problem (pointers advanced).  Same K
 // order and rounding points: bit-equal to the one-launch form (test_gemm_w4_tail_rectangle).
@@ -1498,7 +1501,7 @@ struct TailRect { bool use = false; int limit = 0; long long r0 = 0, c0 = 0; };
 constexpr int W4_TAIL_MAX = 32;
 inline TailRect plan_tail_rect(const GemmP& p, int epi) {
   TailRect t;
-  if (p.wb_tiles_m || (p.tuning & MRAG_GEMM_TUNE_NO_TAIL_RECT)) return t;
+  if (p.wb_tiles_m || !(p.tuning & MRAG_GEMM_TUNE_TAIL_RECT)) return t;
   if (!(epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID)) return t;   // (epilogues whose arithmetic does not depend on a row's absolute index)
   const long long tiles = (long long)p.tiles_m * p.tiles_n;
   const int rem = (int)(tiles % SK_CUS);
@@ -2119,7 +2122,7 @@ extern "C" int mrag_gemm_bf16(void* stream, const mrag_gemm_args* a) {
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID || epi == MRAG_EPI_GATE_RESID || epi == MRAG_EPI_QKNORM_ROPE || epi == MRAG_EPI_GEGLU ||
        epi == EPI_GEGLU_TANH) &&
       a->ldc % 8 == 0 && (((uintptr_t)a->C) & 15) == 0 && (!a->resid || (a->ldr % 8 == 0 && (((uintptr_t)a->resid) & 15) == 0));
-  const bool w4_tail = w4_ok && t256 >= 2 * SK_CUS && t256 % SK_CUS != 0 && t256 % SK_CUS <= W4_TAIL_MAX && !(a->tuning & MRAG_GEMM_TUNE_NO_TAIL_RECT) &&
+  const bool w4_tail = w4_ok && t256 >= 2 * SK_CUS && t256 % SK_CUS != 0 && t256 % SK_CUS <= W4_TAIL_MAX && (a->tuning & MRAG_GEMM_TUNE_TAIL_RECT) &&
       (epi == MRAG_EPI_NONE || epi == MRAG_EPI_GELU_TANH || epi == MRAG_EPI_RESID);                    // (plan_tail_rect's conditions)
   // (first: a problem that the 320-wide tile finishes in fewer rounds -- see wide_rounds_pay; the persistent kernel walks the same 256x256 tile grid)
   if (t256 >= 192 && !wide_n_pays(a->N, a->tuning) && wide_rounds_pay(a->M, a->N, a->tuning, w4_tail) && !(a->tuning & MRAG_GEMM_TUNE_STREAMK) && a->epilogue != MRAG_EPI_GEGLU &&

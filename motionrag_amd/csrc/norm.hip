@@ -6,7 +6,7 @@
 
 #ifndef MRAG_LN_STREAM_WGS
 #define MRAG_LN_STREAM_WGS 2        // persistent workgroups per CU of layernorm_stream_kernel (developer knobs: tools/build_variant.sh).  With the next row prefetched the
-#define MRAG_LN_STREAM_PREFETCH 1   // kernel needs ~190 registers (96 of them the folded factors): two workgroups per CU; three fit only without the prefetch
+#define MRAG_LN_STREAM_PREFETCH 1   // kernel holds 144 registers of row + per-column vectors: two workgroups per CU
 #endif
 
 namespace {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       unpack8(*(const u32x4*)(scale + idx), sc);
       unpack8(*(const u32x4*)(shift + idx), sh);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+      for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(o[e], __fadd_rn(1.0f, sc[e]), sh[e]);   // (explicit: layernorm_stream_kernel repeats this arithmetic bit for bit)
     }
     __builtin_nontemporal_store(pack8(o), (u32x4*)(y + idx));
   }
@@ -110,17 +110,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 
 // Wide rows, many of them (round 6; the DiT's two AdaLN-modulated LayerNorms per block over [35 552, 3 072]): PERSISTENT waves.  layernorm_kernel above gives
 // every row a fresh wave that loads the row AND, per row again, gamma / beta / scale / shift of its columns from L2 -- three bytes through the CU's
-// vector-memory path for every byte of the row -- and retires after one row (4.6 TB/s).  Here a wave keeps its lanes' columns for its whole life: the
-// per-column factors are folded ONCE into A = gamma (1 + scale), B = beta (1 + scale) + shift (fp32 registers; refolded when the wave crosses a sample or
-// the text / video boundary, i.e. a handful of times), rows are dealt to the waves round-robin (the rows in flight at any moment are neighbours in HBM),
-// and row i + 1 is requested before row i is reduced.  y = (x - mean) rstd A + B: the arithmetic of the kernel above up to the fp32 rounding of the fold.
+// vector-memory path for every byte of the row -- and retires after one row (3.8 TB/s alone, 4.6 in the step).  Here a wave keeps its lanes' columns for its
+// whole life: the per-column vectors stay in registers as the packed bf16 they were loaded as (reloaded when the wave crosses a sample or the text / video
+// boundary, i.e. a handful of times), rows are dealt to the waves round-robin (the rows in flight at any moment are neighbours in HBM), and row i + 1 is
+// requested before row i is reduced: 5.2 TB/s.  The arithmetic is layernorm_kernel's operation for operation (same per-lane summation order, same explicit
+// roundings), so the two kernels give the SAME BITS: a sequence-sharded rank (fewer rows: the per-row kernel) reproduces the unsharded model's rows.
 // D = 512 MAXC exactly (every lane busy), no output row remap.
 template <int MAXC>
 __global__ __launch_bounds__(256, MRAG_LN_STREAM_WGS) void layernorm_stream_kernel(const LnP p) {
   const int lane = threadIdx.x & 63;
   const long long nw = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= p.rows) return;
-  float A[MAXC][8], B[MAXC][8];
+  u32x4 pg[MAXC], pb[MAXC], psc[MAXC], psh[MAXC];     // gamma, beta, scale, shift of this lane's columns, packed bf16
   long long key_now = -1;
   u32x4 cur[MAXC], nxt[MAXC];
   auto load_row = [&](const long long row, u32x4 (&dst)[MAXC]) {
@@ -129,43 +130,34 @@ __global__ __launch_bounds__(256, MRAG_LN_STREAM_WGS) void layernorm_stream_kern
     for (int c = 0; c < MAXC; ++c) dst[c] = __builtin_nontemporal_load((const u32x4*)(x + c * 512));
   };
   load_row(gw, nxt);
-  const float inv_d = 1.0f / (float)p.D;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int idx = (c * 64 + lane) * 8;
+    pg[c] = p.gamma ? *(const u32x4*)(p.gamma + idx) : u32x4{0u, 0u, 0u, 0u};
+    pb[c] = p.beta ? *(const u32x4*)(p.beta + idx) : u32x4{0u, 0u, 0u, 0u};
+    psc[c] = u32x4{0u, 0u, 0u, 0u}; psh[c] = u32x4{0u, 0u, 0u, 0u};
+  }
   for (long long row = gw; row < p.rows; row += nw) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) cur[c] = nxt[c];
     if (MRAG_LN_STREAM_PREFETCH && row + nw < p.rows) load_row(row + nw, nxt);
-    // ---- the per-column factors of this row's (sample, segment)
-    long long key = 0;
-    const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
-    if (p.shift0) {
+    if (p.shift0) {                              // the modulation vectors of this row's (sample, segment)
       const unsigned b = (unsigned)row / (unsigned)p.rows_per_batch, pos = (unsigned)row - b * (unsigned)p.rows_per_batch;
       const bool second = (long long)pos >= p.split;
-      key = 2LL * b + (second ? 1 : 0);
-      shift = (second ? p.shift1 : p.shift0) + (long long)b * p.mod_stride;
-      scale = (second ? p.scale1 : p.scale0) + (long long)b * p.mod_stride;
-    }
-    if (key != key_now) {                       // (wave-uniform)
-      key_now = key;
+      const long long key = 2LL * b + (second ? 1 : 0);
+      if (key != key_now) {                      // (wave-uniform)
+        key_now = key;
+        const bf16_t* shift = (second ? p.shift1 : p.shift0) + (long long)b * p.mod_stride;
+        const bf16_t* scale = (second ? p.scale1 : p.scale0) + (long long)b * p.mod_stride;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
-        const int idx = (c * 64 + lane) * 8;
-        float g[8], bb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { g[e] = 1.f; bb[e] = 0.f; }
-        if (p.gamma) unpack8(*(const u32x4*)(p.gamma + idx), g);
-        if (p.beta) unpack8(*(const u32x4*)(p.beta + idx), bb);
-        if (shift) {
-          float sc[8], sh[8];
-          unpack8(*(const u32x4*)(scale + idx), sc);
-          unpack8(*(const u32x4*)(shift + idx), sh);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float m = 1.0f + sc[e]; g[e] *= m; bb[e] = bb[e] * m + sh[e]; }
+        for (int c = 0; c < MAXC; ++c) {
+          const int idx = (c * 64 + lane) * 8;
+          psc[c] = *(const u32x4*)(scale + idx);
+          psh[c] = *(const u32x4*)(shift + idx);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { A[c][e] = g[e]; B[c][e] = bb[e]; }
       }
     }
-    // ---- statistics: two passes over the row in registers (the packed row is unpacked on the fly: 24 registers instead of 48)
+    // ---- statistics: two passes over the row in registers (the packed row is unpacked on the fly), layernorm_kernel's order and roundings
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -173,21 +165,36 @@ __global__ __launch_bounds__(256, MRAG_LN_STREAM_WGS) void layernorm_stream_kern
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += v[e];
     }
-    const float mean = p.rms ? 0.f : wave_sum(sum) * inv_d;
+    const float mean = p.rms ? 0.f : wave_sum(sum) / (float)p.D;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       float v[8]; unpack8(cur[c], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+      for (int e = 0; e < 8; ++e) { const float d = __fsub_rn(v[e], mean); sq = __builtin_fmaf(d, d, sq); }
     }
-    const float rstd = rsqrtf(wave_sum(sq) * inv_d + p.eps);
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
     bf16_t* y = p.y + row * p.ldy + lane * 8;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       float v[8], o[8]; unpack8(cur[c], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * A[c][e] + B[c][e];
+      for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(__fsub_rn(v[e], mean), rstd);
+      if (p.gamma) {
+        float g[8]; unpack8(pg[c], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(o[e], g[e]);
+      }
+      if (p.beta) {
+        float bb[8]; unpack8(pb[c], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __fadd_rn(o[e], bb[e]);
+      }
+      if (p.shift0) {
+        float sc[8], sh[8]; unpack8(psc[c], sc); unpack8(psh[c], sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(o[e], __fadd_rn(1.0f, sc[e]), sh[e]);
+      }
       __builtin_nontemporal_store(pack8(o), (u32x4*)(y + c * 512));
     }
     if (!MRAG_LN_STREAM_PREFETCH && row + nw < p.rows) load_row(row + nw, nxt);

@@ -70,30 +70,58 @@ __global__ __launch_bounds__(256) void probe_mfma_f32_kernel(const float* __rest
   out[t] = s;
 }
 
-// 16 bytes per lane and access, UNROLL independent loads before the first store; consecutive lanes touch consecutive 16-byte pieces, a workgroup's UNROLL
-// accesses are UNROLL contiguous 4-KiB runs one grid stride apart
-template <int UNROLL>
+// 16 bytes per lane and access, UNROLL independent loads before the first store.  CONTIG: a workgroup's UNROLL accesses of one iteration are ONE contiguous run of
+// UNROLL x 4 KiB (grid-stride over such runs); otherwise they are UNROLL 4-KiB runs a whole grid stride apart (the first form: 4.4 TB/s, slower than torch's copy --
+// too many concurrent DRAM pages).  NT: nontemporal loads / stores (streamed once, as the library's LayerNorm kernels do).
+template <int UNROLL, bool CONTIG, bool NT>
 __global__ __launch_bounds__(256) void probe_stream_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long n16) {
-  const long long stride = (long long)gridDim.x * 256;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
-    u32x4 v[UNROLL];
+  auto ld = [&](long long i) { return NT ? __builtin_nontemporal_load(src + i) : src[i]; };
+  auto st = [&](long long i, u32x4 v) { if (NT) __builtin_nontemporal_store(v, dst + i); else dst[i] = v; };
+  if constexpr (CONTIG) {
+    const long long run = 256LL * UNROLL, nrun = n16 / run;
+    for (long long r = blockIdx.x; r < nrun; r += gridDim.x) {
+      const long long i = r * run + threadIdx.x;
+      u32x4 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) v[u] = src[i + u * stride];
+      for (int u = 0; u < UNROLL; ++u) v[u] = ld(i + u * 256);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) dst[i + u * stride] = v[u];
+      for (int u = 0; u < UNROLL; ++u) st(i + u * 256, v[u]);
+    }
+    for (long long i = nrun * run + (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) st(i, ld(i));
+  } else {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+      u32x4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = ld(i + u * stride);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) st(i + u * stride, v[u]);
+    }
+    for (; i < n16; i += stride) st(i, ld(i));
   }
-  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
 
-extern "C" int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes) {
-  if (!src || !dst || bytes < 16 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MRAG_EINVAL;
+// variant: bits 0-3 the kernel form (0 = the shipped one), bits 4-11 workgroups per CU (0 = the shipped count) -- developer sweep (tools/microbench.py copy_probe)
+extern "C" int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes, int32_t variant) {
+  if (!src || !dst || bytes < 16 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15) || variant < 0) return MRAG_EINVAL;
   const long long n16 = bytes / 16;
+  const int form = variant & 15, per_cu = (variant >> 4) & 0xff ? (variant >> 4) & 0xff : 8;
   long long wgs = (n16 + 4 * 256 - 1) / (4 * 256);
-  if (wgs > 256 * 8) wgs = 256 * 8;                   // 8 workgroups per CU: 32 waves, 128 KiB of loads in flight per CU
-  MRAG_LAUNCH((probe_stream_copy_kernel<4>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, n16);
+  if (wgs > 256LL * per_cu) wgs = 256LL * per_cu;
+  const dim3 grid((unsigned)wgs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (form) {
+    case 0: MRAG_LAUNCH((probe_stream_copy_kernel<4, true, true>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    case 1: MRAG_LAUNCH((probe_stream_copy_kernel<4, true, false>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    case 2: MRAG_LAUNCH((probe_stream_copy_kernel<8, true, true>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    case 3: MRAG_LAUNCH((probe_stream_copy_kernel<4, false, false>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    case 4: MRAG_LAUNCH((probe_stream_copy_kernel<2, true, true>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    case 5: MRAG_LAUNCH((probe_stream_copy_kernel<1, true, true>), grid, block, 0, s, (const u32x4*)src, (u32x4*)dst, n16); break;
+    default: return MRAG_EINVAL;
+  }
   MRAG_LAUNCH_CHECK();
   return MRAG_OK;
 }

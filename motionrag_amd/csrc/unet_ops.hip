@@ -47,9 +47,10 @@ struct GnP {
 
 constexpr int GN_TICKET_BYTES = 16384, GN_FOLD_MAX_CHUNKS = 128;   // the last-arriver fold: up to 4096 samples, up to 128 chunk partials per channel
 
-// FOLD: the workgroup that arrives LAST for a sample (ticket) also does pass 2 for that sample -- one launch less per GroupNorm (105 / 145 launches of 10-13 us
-// per SVD / DynamiCrafter CFG step).  Taken when the partial lists are short (<= 128 chunks: the per-frame norms of the spatial blocks, N = 28 / 32 samples);
-// the (t, h, w) norms of the temporal blocks (N = 2, 1024 chunks: 2.6-10 MB of partials per sample) keep the parallel fold kernel below.
+// FOLD (opt-in: mrag_groupnorm_args.fold; measured 5 % SLOWER on the UNet steps, see mrag_groupnorm_bf16): the workgroup that arrives LAST for a sample (ticket)
+// also does pass 2 for that sample -- one launch less per GroupNorm (105 / 145 launches of 10-13 us per SVD / DynamiCrafter CFG step).  Possible when the partial
+// lists are short (<= 128 chunks: the per-frame norms of the spatial blocks, N = 28 / 32 samples); the (t, h, w) norms of the temporal blocks (N = 2, 1024 chunks:
+// 2.6-10 MB of partials per sample) keep the parallel fold kernel below.
 template <bool FOLD>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -372,11 +373,11 @@ extern "C" int mrag_groupnorm_bf16(void* stream, const mrag_groupnorm_args* a) {
   if (a->C / a->G > 256) return MRAG_ENOTSUP;
   float* ab = p.part + a->N * a->chunks * a->C * 2;
   p.ab = ab;
-#ifdef MRAG_GN_NO_FOLD      // developer A/B build (tools/build_variant.sh): always the three-kernel form
-  const bool fold = false;
-#else
-  const bool fold = a->chunks <= GN_FOLD_MAX_CHUNKS && a->C <= 2048 && a->G <= 127 && a->N <= GN_TICKET_BYTES / 4;
-#endif
+  // MEASURED SLOWER and therefore off: same box, interleaved, SVD / DynamiCrafter CFG step 110.4 -> 116.2 ms / 141.6 -> 149.0 ms with the fold by the last
+  // arriver (profiles/r6_unet_gn_fold_ab.txt).  Every statistics workgroup (2 048 per call) pays an agent-scope release in front of its ticket -- an L2
+  // write-back -- which costs far more than the 10-13 us fold launch it removes.  `fold` stays reachable through the args' `fold` flag (tests keep the path
+  // alive; a cheaper arrival protocol would make it pay).
+  const bool fold = a->fold == 1 && a->chunks <= GN_FOLD_MAX_CHUNKS && a->C <= 2048 && a->G <= 127 && a->N <= GN_TICKET_BYTES / 4;
   const dim3 sgrid(a->chunks, (unsigned)a->N, (unsigned)((a->C + 2047) / 2048));
   if (fold) {
     MRAG_LAUNCH(gn_stats_kernel<true>, sgrid, dim3(256), 0, s, p);

@@ -702,7 +702,7 @@ class TopkPlan:
 # ---------------------------------------------------------------------------------------------- UNet ops (channels-last rows)
 def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int, eps: float, *, silu: bool = False,
               emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, mod: Optional[torch.Tensor] = None,
-              mod_geom: Optional[tuple] = None) -> torch.Tensor:
+              mod_geom: Optional[tuple] = None, fold: bool = False) -> torch.Tensor:
     """nn.GroupNorm over x [N, HW, C] (channels-last) [+ per-(n, c) `emb` added before the statistics] [+ SiLU].
     `mod` [N, Tz, hz, wz, 2C] + `mod_geom` = (T, H, W, shift, split): the spatially conditioned form gn(x) * mod[.., :C] + mod[.., C:] with the
     latent-resolution maps read through the nearest-neighbour frame / pixel map (mrag_hip.h); `out` may then be a [N, HW, C] view whose
@@ -722,6 +722,7 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     a = GroupNormArgs()
     a.x, a.y, a.gamma, a.beta, a.workspace = _p(x), _p(out), _p(gamma), _p(beta), _p(ws)
     a.N, a.HW, a.C, a.G, a.chunks, a.silu, a.eps = N, HW, C, groups, chunks, 1 if silu else 0, eps
+    a.fold = 1 if fold else 0                    # opt-in: statistics + fold in one launch (measured slower than the separate fold: include/mrag_hip.h)
     if emb is not None:
         _dev(emb, name="emb")
         if emb.shape != (N, C) or emb.stride(1) != 1:

@@ -18,6 +18,14 @@ _, cam, _ = bench.build_models(dev, 1, 13)
 batch = {"ref_videos": torch.zeros(1, 9, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev), "video": torch.zeros(1, 16, 3, 8, 8, dtype=torch.bfloat16, device=dev)}
 dt = timeit(lambda: cam.predict(batch, do_classifier_free_guidance=True), iters=int(os.environ.get("ITERS", "20")), warm=3)
 print(f"CAMA predict: {dt*1e3:.3f} ms per clip")
+from motionrag_amd import ops  # noqa: E402
+with ops.dispatched() as d:
+    cam.predict(batch, do_classifier_free_guidance=True)
+print(f"CAMA predict: {sum(d.counts.values())} library launches per clip: {dict(sorted(d.counts.items()))}")
+from motionrag_amd.cama import GraphedPredict  # noqa: E402
+gp0 = GraphedPredict(cam, do_classifier_free_guidance=True)
+gp0(batch)
+print(f"CAMA predict as one HIP graph: {timeit(lambda: gp0(batch), iters=30, warm=3)*1e3:.3f} ms per clip")
 if os.environ.get("CAMA_AB"):          # side-stream condition branch on / off, eager and as one HIP graph, interleaved
     from motionrag_amd.cama import GraphedPredict
     for rnd in range(3):

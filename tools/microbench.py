@@ -441,7 +441,7 @@ def r6():
     bfb = torch.zeros(4 * D, device=DEV, dtype=torch.bfloat16)
     hid = torch.empty(B * S, 4 * D, device=DEV, dtype=torch.bfloat16)
     x2 = x.view(B * S, D)
-    for name, tune in (("tail rectangle", 0), ("27th round", 1 << 19), ("tail rectangle", 0), ("27th round", 1 << 19)):
+    for name, tune in (("tail rectangle", 1 << 19), ("27th round", 0), ("tail rectangle", 1 << 19), ("27th round", 0)):
         ops.TUNING["gemm"] = tune
         with ops.dispatched() as d:
             dt = timeit(lambda: ops.linear(x2, wf, bfb, out=hid, epilogue=ops.EPI_GELU_TANH), iters=20)
@@ -453,7 +453,7 @@ def r6():
     dst = torch.empty_like(src)
     L = _lib.lib()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    dtc = timeit(lambda: L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel()), iters=20)
+    dtc = timeit(lambda: L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel(), 0), iters=20)
     dtt = timeit(lambda: dst.copy_(src), iters=20)
     print(f"r6 1 GiB copy: library stream copy {2*src.numel()/dtc/1e12:.2f} TB/s, torch copy_ {2*src.numel()/dtt/1e12:.2f} TB/s")
     del src, dst
@@ -466,6 +466,26 @@ def r6():
         ov = out[:, :sq] if sq <= S else torch.empty(B, sq, H * 64, device=DEV, dtype=torch.bfloat16)
         dt = timeit(lambda: ops.attention(qv, qkv[:, :, 1], qkv[:, :, 2], out=ov), iters=15)
         print(f"r6 attention, {tiles} query tiles x 96 (b, h) = {tiles * 96 / 768:.2f} rounds of 768 workgroups: {dt*1e3:.3f} ms = {dt*1e3/(tiles*96/768):.4f} ms per round-equivalent")
+
+
+def copy_probe():
+    """sweep of the stream-copy probe's forms (csrc/probe.hip) against torch's copy: the form that wins is the library's HBM ceiling (roofline.ceilings.stream_copy_TBps)"""
+    import ctypes
+    from motionrag_amd import _lib
+    L = _lib.lib()
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=DEV).random_(0, 255)
+    dst = torch.empty_like(src)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    names = {0: "unroll 4, contiguous runs, nontemporal", 1: "unroll 4, contiguous runs", 2: "unroll 8, contiguous, nontemporal", 3: "unroll 4, grid-strided (first form)",
+             4: "unroll 2, contiguous, nontemporal", 5: "unroll 1, nontemporal"}
+    for rep in range(2):
+        for form in range(6):
+            for per_cu in (4, 8, 16, 32):
+                v = form | (per_cu << 4)
+                dt = timeit(lambda: L.mrag_probe_stream_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel(), v), iters=10)
+                print(f"copy_probe form {form} ({names[form]}), {per_cu} workgroups per CU: {2*src.numel()/dt/1e12:.2f} TB/s")
+        dtt = timeit(lambda: dst.copy_(src), iters=10)
+        print(f"copy_probe torch copy_: {2*src.numel()/dtt/1e12:.2f} TB/s")
 
 
 def topk_small():

@@ -2,7 +2,7 @@
 """developer tool (round 6): the headline CFG denoise step under in-process toggles, interleaved on ONE device in ONE process (same box, same power state):
     python3 tools/r6_step_ab.py [rounds] [steps]
   shipped        everything on
-  no_tail_rect   FF1's 16-tile 27th round stays inside the persistent launch (MRAG_GEMM_TUNE_NO_TAIL_RECT)
+  tail_rect      FF1's 16-tile 27th round as its own launch of 128x128 tiles (opt-in MRAG_GEMM_TUNE_TAIL_RECT)
   loop_scores    the folded score GEMM as one launch per CFG sample (packed 26-column blocks kept)
   r5_scores      round 5's score path: one launch per sample, 32 columns per head
 Prints ms per step per configuration and round, then the medians."""
@@ -41,7 +41,7 @@ def step(i):
     ops.cfg_ddim_step_(v, latents.clone(), 6.0, *sched.coeffs(t))
 
 
-CONFIGS = {"shipped": dict(gemm=0, loop=False, pack=True), "no_tail_rect": dict(gemm=1 << 19, loop=False, pack=True),
+CONFIGS = {"shipped": dict(gemm=0, loop=False, pack=True), "tail_rect": dict(gemm=1 << 19, loop=False, pack=True),
            "loop_scores": dict(gemm=0, loop=True, pack=True), "r5_scores": dict(gemm=0, loop=True, pack=False)}
 res = {k: [] for k in CONFIGS}
 for r in range(rounds + 1):

@@ -106,7 +106,7 @@ int mrag_probe_mfma_bf16(void* stream, const void* operands, int64_t operand_byt
 int64_t mrag_probe_mfma_f32_flops(int32_t iters);
 int mrag_probe_mfma_f32(void* stream, const void* operands, int64_t operand_bytes, float* out, int32_t iters);
 /* the HBM stream every "HBM-bound" kernel is priced against (`roofline.ceilings.stream_copy_TBps`: bytes read + bytes written per second): a grid-stride copy
- * of `bytes` (a multiple of 16; both pointers 16-byte aligned) with 16-byte loads and stores, four of each in flight per lane, 8 workgroups per CU.          */
+ * of `bytes` (a multiple of 16; both pointers 16-byte aligned) with nontemporal 16-byte loads and stores, four of each in flight per lane over contiguous 16-KiB runs, 16 workgroups per CU.          */
 int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes, int32_t variant /* 0 = shipped form; developer sweep: bits 0-3 kernel form, bits 4-11 workgroups per CU */);
 
 /* ------------------------------------------------------------------------ */

@@ -950,10 +950,22 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
   constexpr int HG = MRAG_IPFOLD_HG;
   const size_t lds = HG * 64 * 32 * sizeof(bf16_t);
   const long long groups = ((long long)kv_batch_div * S + 63) / 64;
-  const long long per = (256 * (128 * 1024 / (long long)lds)) / (((H + HG - 1) / HG) * (long long)(B / kv_batch_div));   // as many workgroups as fit the CUs' LDS: each one pays a V^T fill
-  const unsigned gx = (unsigned)(groups < (per > 1 ? per : 1) ? groups : (per > 1 ? per : 1));
   hipError_t e = hipFuncSetAttribute((const void*)ip_attn_folded_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
+  // ONE round of resident workgroups (each pays a V^T fill and then walks its share of the rows): the count the RUNTIME reports for this kernel's registers
+  // and LDS.  Until round 6 the grid assumed eight workgroups per CU from the LDS size alone; the kernel's 72 VGPRs allow seven -- 2 040 workgroups on 1 792
+  // slots, i.e. a second round for an eighth of them.
+  static int wg_per_cu = 0;                                  // (a property of the code object; the benign race writes the same value)
+  if (wg_per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)ip_attn_folded_kernel, 256, lds) != hipSuccess || n <= 0) n = 4;
+#ifdef MRAG_IPFOLD_WG8          // developer A/B build: round 5's grid (eight per CU from the LDS size alone)
+    n = (int)(128 * 1024 / lds);
+#endif
+    wg_per_cu = n;
+  }
+  const long long per = (256LL * wg_per_cu) / (((H + HG - 1) / HG) * (long long)(B / kv_batch_div));
+  const unsigned gx = (unsigned)(groups < (per > 1 ? per : 1) ? groups : (per > 1 ? per : 1));
   MRAG_LAUNCH(ip_attn_folded_kernel, dim3(gx, (unsigned)((H + HG - 1) / HG), (unsigned)(B / kv_batch_div)), dim3(256), lds, (hipStream_t)stream, p);
   MRAG_LAUNCH_CHECK();
   MRAG_COUNT(MRAG_K_IP_ATTN_FOLDED);

@@ -25,17 +25,22 @@ inline int gemm(void* s, const void* A, const void* W, const void* bias, void* C
   return mrag_gemm_bf16(s, &g);
 }
 
-// C = epilogue(LayerNorm(A) . W^T): ONE launch where the few-row kernel takes it (mrag_gemm_args.a_ln: bit-identical to the two launches), else LayerNorm into
-// `scratch` and the plain GEMM
+// C = epilogue(LayerNorm(A) . W^T).  Shipped: LayerNorm into `scratch`, then the plain GEMM.  The one-launch form (mrag_gemm_args.a_ln: the LayerNorm inside the
+// few-row kernel's A load, bit-identical) was built for the round-5 review's "fuse dependent steps" item and MEASURED SLOWER: CAMA 1.63 ms per clip with it against
+// 1.50 ms without, same box, interleaved, although it removes 16 of 114 launches (profiles/r6_cama_ln_in_a_load_ab.txt) -- every one of the 64-512 workgroups of a
+// projection recomputes the statistics of its 32 rows (two passes over 64 KB behind a barrier) before its first MFMA, which costs a 250-row problem more than the
+// 6 us LayerNorm launch it saves.  -DMRAG_CAMA_LNA builds the fused sequencer (tools/build_variant.sh); the C-ABI feature stays available and tested.
 inline int ln(void* s, const void* x, void* y, const void* w, const void* b, int64_t rows, int64_t D, float eps, int64_t y_rows_per_batch, int64_t y_batch_stride);
 inline int gemm_ln(void* s, const void* A, const void* lw, const void* lb, float eps, void* scratch, const void* W, void* C, int64_t M, int64_t N, int64_t K, int epi) {
   mrag_gemm_args g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.W = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.epilogue = epi;
   g.a_ln = 1; g.a_ln_gamma = lw; g.a_ln_beta = lb; g.a_ln_eps = eps;
-#ifndef MRAG_CAMA_NO_LNA     // developer A/B build (tools/build_variant.sh): always the two launches
+#ifdef MRAG_CAMA_LNA         // developer A/B build (tools/build_variant.sh): the one-launch form
   const int rc = mrag_gemm_bf16(s, &g);
   if (rc != MRAG_ENOTSUP) return rc;
+#else
+  (void)g;
 #endif
   const int rl = ln(s, A, scratch, lw, lb, M, K, eps, 0, 0);
   if (rl != 0) return rl;
@@ -113,7 +118,7 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     // PerceiverAttention.forward :81-105 -- LN1(x) and LN2(latents) land directly in the [x ; latents] concat buffer
     TRY(ln(stream, w.x, w.kv_in, L.norm1_w, L.norm1_b, N * n1, dim, a->eps, n1, (n1 + nq) * dim));
     TRY(ln(stream, lat, w.kv_in + n1 * dim, L.norm2_w, L.norm2_b, N * nq, dim, a->eps, nq, (n1 + nq) * dim));
-    TRY(gemm_ln(stream, lat, L.norm2_w, L.norm2_b, a->eps, w.ln_lat, L.to_q, w.q, N * nq, inner, dim, MRAG_EPI_NONE));                     // to_q(norm2(latents)): one launch
+    TRY(gemm_ln(stream, lat, L.norm2_w, L.norm2_b, a->eps, w.ln_lat, L.to_q, w.q, N * nq, inner, dim, MRAG_EPI_NONE));                     // to_q(norm2(latents))
     TRY(gemm(stream, w.kv_in, L.to_kv, nullptr, w.kv, N * (n1 + nq), 2 * inner, dim, MRAG_EPI_NONE, nullptr));                          // K rows first (chunk(2)) :96
     mrag_attn_args at;
     memset(&at, 0, sizeof(at));
@@ -128,7 +133,7 @@ extern "C" int mrag_resampler_fwd(void* stream, const mrag_resampler_args* a) {
     TRY(mrag_attn_fwd_bf16(stream, &at));
     TRY(gemm(stream, w.o, L.to_out, nullptr, lat_next, N * nq, dim, inner, MRAG_EPI_RESID, lat));                                        // attn(...) + latents :162
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
-    TRY(gemm_ln(stream, lat, L.ff_ln_w, L.ff_ln_b, a->eps, w.h_ln, L.ff_w1, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF));                     // gelu(ff1(ln(latents))): one launch
+    TRY(gemm_ln(stream, lat, L.ff_ln_w, L.ff_ln_b, a->eps, w.h_ln, L.ff_w1, w.h, N * nq, ff, dim, MRAG_EPI_GELU_ERF));                     // gelu(ff1(ln(latents)))
     TRY(gemm(stream, w.h, L.ff_w2, nullptr, lat_next, N * nq, dim, ff, MRAG_EPI_RESID, lat));                                            // ff(...) + latents :163
     { bf16_t* t = lat; lat = lat_next; lat_next = t; }
   }

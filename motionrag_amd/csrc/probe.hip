@@ -7,8 +7,8 @@
 //   part does not hold under a dense matrix load on random data (profiles/r2_mfma_shape_power.txt).
 //   mrag_probe_mfma_f32: the same for v_mfma_f32_32x32x2_f32 (nominal 157 TFLOP/s), the pipe of the retrieval fan-out kernel.
 //   mrag_probe_stream_copy: a grid-stride copy with 16-byte loads and stores, four of each in flight per lane -- the 1 : 1 read / write stream every
-//   "HBM-bound" kernel of the library is priced against (the guide's float4 copy reaches 6.3 of the 8 TB/s; `dst.copy_(src)` on uint8, which bench.py
-//   quoted until round 5, only 4.8: not a ceiling -- the library's own LayerNorm and top-k kernels move more).
+//   "HBM-bound" kernel of the library is priced against: 5.9-6.0 TB/s on this pool (the guide's float4 copy: 6.3 of the 8 TB/s; `dst.copy_(src)` on uint8, which
+//   bench.py quoted until round 5: 4.7-5.1 -- not a ceiling, the library's own LayerNorm and top-k kernels move more).
 #include "common.h"
 #include "../../include/mrag_hip.h"
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void probe_stream_copy_kernel(const u32x4* __r
 extern "C" int mrag_probe_stream_copy(void* stream, const void* src, void* dst, int64_t bytes, int32_t variant) {
   if (!src || !dst || bytes < 16 || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15) || variant < 0) return MRAG_EINVAL;
   const long long n16 = bytes / 16;
-  const int form = variant & 15, per_cu = (variant >> 4) & 0xff ? (variant >> 4) & 0xff : 8;
+  const int form = variant & 15, per_cu = (variant >> 4) & 0xff ? (variant >> 4) & 0xff : 16;   // (swept: profiles/r6_copy_probe_sweep.txt -- 16 workgroups per CU of the contiguous nontemporal form: 5.9-6.0 TB/s)
   long long wgs = (n16 + 4 * 256 - 1) / (4 * 256);
   if (wgs > 256LL * per_cu) wgs = 256LL * per_cu;
   const dim3 grid((unsigned)wgs), block(256);

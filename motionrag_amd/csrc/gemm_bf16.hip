@@ -1634,7 +1634,14 @@ __global__ __launch_bounds__(640) void gemm_k320_kernel(const GemmP p) {
     const bool more = tile + G < tiles;
     if (more) {
       issue(tile + G, stage ^ 1);                           // (the other stage was released by the barrier that closed the previous iteration)
+      // INVARIANT of the counted wait (as in topk_mfma_kernel): vmcnt retires in order and counts every vector-memory operation of the wave -- the residual loads and C
+      // stores of the previous tile's epilogue are all issued BEFORE the next tile's four pieces, so "4 outstanding" means exactly those pieces.  No global access may be
+      // moved between `issue` and this wait.  -DMRAG_DIAG_VMCNT0 replaces it by vmcnt(0): the results must not change.
+#ifdef MRAG_DIAG_VMCNT0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this tile's four pieces have landed, the next tile's four are in flight
+#endif
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

@@ -596,7 +596,15 @@ __global__ __launch_bounds__(256 * WN) void topk_mfma_kernel(const TopkMP p) {
   for (int i = 0; i < NST - 1; ++i) issue_all(i);
   int s = 0, blk = 0, stg = 0;
   for (int it = 0; it < total; ++it) {
+    // INVARIANT of the counted wait: vmcnt retires in order and counts EVERY vector-memory operation of the wave, so between the LDS-DMA pieces of a slab and the wait
+    // that guards it no other vector-memory operation may be issued -- the group-id loads, the tau_g atomics and the list stores of the selection all sit BEHIND this
+    // wait in program order (they are issued after the pieces they could otherwise be mistaken for).  A later edit that puts a global access in front of it silently lets
+    // the MFMAs read a half-landed stage.  -DMRAG_DIAG_VMCNT0 (tools/build_variant.sh) replaces the counted waits by vmcnt(0): the results must not change.
+#ifdef MRAG_DIAG_VMCNT0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (NST - 2)) : "memory");   // all but the newest NST - 2 slabs have landed: slab `it` is in LDS
+#endif
     __syncthreads();                                 // ... for every wave; and every wave is done reading the stage that slab it + NST - 1 overwrites
     const int nstage = stg == 0 ? NST - 1 : stg - 1; // slab it + NST - 1 -> stage (it + NST - 1) % NST
     const char* st = smem + stg * STAGE;

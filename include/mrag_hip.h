@@ -280,11 +280,12 @@ int mrag_attn_fwd_fp8(void* stream, const mrag_attn_args* args);
 /* and this kernel finishes: softmax over the `keys` valid scores of every      */
 /* (row, head) times `scale`, times V_ip, added into `hidden` in place.         */
 /*   scores [B*S, scores_ld] bf16, key k of head h at column key_stride h + k   */
-/*   (key_stride 0 = 32: 64-byte aligned blocks; an even value in [keys, 32]    */
-/*   packs the heads -- 26 puts 48 heads x 25 keys into 1 280 columns, five      */
-/*   instead of six 256-column tiles of the score GEMM; scores_ld >=             */
-/*   (H - 1) key_stride + 32: a lane group reads 32 elements from a block's      */
-/*   start);                                                                     */
+/*   (key_stride 0 = 32: 64-byte aligned blocks; a value in [keys, 32] packs    */
+/*   the heads -- 26 puts 48 heads x 25 keys into 1 280 columns, five instead    */
+/*   of six 256-column tiles of the score GEMM.  A lane group reads the four     */
+/*   aligned 16-byte chunks that cover a block, so ((key_stride h) mod 8) +      */
+/*   keys <= 32 must hold for every head, and scores_ld >= the aligned start     */
+/*   of the last block + 32);                                                    */
 /*   v: element (kv batch, key, h, d) at v + kb*v_batch_stride + key*v_key_stride + 64 h + d; */
 /*   hidden [B*S, hidden_ld] bf16; q batch b uses K/V batch b / kv_batch_div.   */
 /* ------------------------------------------------------------------------ */

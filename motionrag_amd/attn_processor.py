@@ -164,7 +164,9 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
             # KS = 32), else 32.  Both CFG samples' score GEMMs are ONE launch with per-sample weights (ops.linear_per_sample): 700 tiles = 3 rounds of
             # the persistent grid where two launches of 420 paid 2 + 2 (round 6).
             nk = ip.size(1)
-            KS = next((c for c in range(nk + (nk & 1), 32, 2) if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256)), 32) if PACK_SCORE_BLOCKS else 32
+            # (a block's keys must fit the 32 slots of the four aligned 16-byte chunks that cover it: ((KS h) mod 8) + nk <= 32 -- mrag_ip_attn_folded_bf16)
+            KS = next((c for c in range(nk + (nk & 1), 32, 2)
+                       if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256) and all(((c * h) & 7) + nk <= 32 for h in range(min(H, 8)))), 32) if PACK_SCORE_BLOCKS else 32
             NW = -(-((H - 1) * KS + 32) // 256) * 256 if KS != 32 else H * 32
 
             def build():

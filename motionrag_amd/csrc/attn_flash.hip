@@ -848,8 +848,12 @@ struct IpFoldP {
   int H, keys, kv_div, ks;   // ks: elements between the heads' score blocks (32: 64-byte aligned blocks; 26: the packed form of the one-launch score GEMM)
   float qscale, out_scale;
 };
-typedef u32x4 __attribute__((aligned(4))) u32x4_a4;   // a 16-byte load from a 4-byte aligned address (the packed score blocks start every 52 bytes)
 
+#ifdef MRAG_IPFOLD_NT        // developer A/B build: the scores (read once) through nontemporal loads
+#define MRAG_IPFOLD_LD(P) __builtin_nontemporal_load(P)
+#else
+#define MRAG_IPFOLD_LD(P) (*(P))
+#endif
 #ifndef MRAG_IPFOLD_HG
 #define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
 #endif
@@ -863,13 +867,18 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
   const int nh = min(HG, p.H - h0);
   for (int i = threadIdx.x; i < HG * 64 * 32 / 8; i += 256) ((u32x4*)vt)[i] = u32x4{0u, 0u, 0u, 0u};   // padding keys / heads
   __syncthreads();
+  // Key SLOTS.  The four lanes of a (row, head) read the four ALIGNED 16-byte chunks that cover the head's score block: with the packed blocks (ks = 26: a
+  // block starts every 52 bytes) the block begins s = (ks h) mod 8 elements into its first chunk, so key k of head h sits in MFMA slot k + s -- the contraction
+  // does not care which slot a key occupies as long as the V^T image uses the same one, and the slots in front of / behind the block (neighbouring heads'
+  // scores) are masked.  ks = 32: s = 0, the round-5 layout.  (The first packed form read 16 bytes from 4-byte aligned addresses: + 9 us per launch.)
   for (int i = threadIdx.x; i < p.keys * nh * 8; i += 256) {     // 16-byte chunk (key, head, 8 features) -> 8 transposed LDS elements
     const int c8 = i & 7, hl = (i >> 3) % nh, key = (i >> 3) / nh;
+    const int slot = key + ((p.ks * (h0 + hl)) & 7);
     const u32x4 raw = *(const u32x4*)(p.v + (long long)kb * p.v_bs + (long long)key * p.v_ks + (h0 + hl) * 64 + c8 * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int d = c8 * 8 + e;                                  // (d >> 3) & 3 == c8 & 3
-      vt[(hl * 64 + d) * 32 + ((((key >> 3) ^ (c8 & 3)) << 3) | (key & 7))] = (bf16_t)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu));
+      vt[(hl * 64 + d) * 32 + ((((slot >> 3) ^ (c8 & 3)) << 3) | (slot & 7))] = (bf16_t)((e & 1) ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu));
     }
   }
   __syncthreads();
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
     const long long row = g0 + r16;
     const long long rc = row < row_hi ? row : row_hi - 1;
     // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
-    u32x4 raw_n = *(const u32x4_a4*)(p.scores + rc * p.s_ld + h0 * p.ks + kq * 8);
+    u32x4 raw_n = MRAG_IPFOLD_LD((const u32x4*)(p.scores + rc * p.s_ld + ((h0 * p.ks) & ~7) + kq * 8));
     u32x4 old_n[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(p.o + rc * p.o_ld + h0 * 64 + 32 * hf + 8 * kq);
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
       bf16_t* op = p.o + rc * p.o_ld + h * 64;
       const u32x4 old[2] = {old_n[0], old_n[1]};
       if (hl + 1 < nh) {
-        raw_n = *(const u32x4_a4*)(p.scores + rc * p.s_ld + (h + 1) * p.ks + kq * 8);
+        raw_n = MRAG_IPFOLD_LD((const u32x4*)(p.scores + rc * p.s_ld + (((h + 1) * p.ks) & ~7) + kq * 8));
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(op + 64 + 32 * hf + 8 * kq);
       }
@@ -901,9 +910,10 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
         sv[2 * e] = __uint_as_float(raw[e] << 16) * p.qscale;
         sv[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u) * p.qscale;
       }
+      const int shift = (p.ks * h) & 7;                           // slot of key 0 (wave-uniform)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (kq * 8 + e >= p.keys) sv[e] = -INFINITY;
+        if ((unsigned)(kq * 8 + e - shift) >= (unsigned)p.keys) sv[e] = -INFINITY;
         m = fmaxf(m, sv[e]);
       }
       m = fmaxf(m, __shfl_xor(m, 16));
@@ -940,8 +950,10 @@ extern "C" int mrag_ip_attn_folded_bf16(void* stream, const void* scores, const 
                                         float scale, float out_scale, int32_t key_stride) {
   if (!scores || !v || !hidden || B <= 0 || S <= 0 || H <= 0 || keys <= 0 || keys > 32 || kv_batch_div <= 0 || B % kv_batch_div) return MRAG_EINVAL;
   const int ks = key_stride == 0 ? 32 : key_stride;
-  if (ks < keys || ks > 32 || (ks & 1)) return MRAG_EINVAL;                       // (score blocks start on 4-byte boundaries)
-  if (scores_ld % 8 || hidden_ld % 8 || scores_ld < (int64_t)(H - 1) * ks + 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;   // a lane group reads 32 elements from a block's start
+  if (ks < keys || ks > 32) return MRAG_EINVAL;
+  for (int h = 0; h < H && h < 8; ++h)                                            // a block's keys must fit the 32 slots of the aligned chunks that cover it ((ks h) mod 8 repeats with period <= 8)
+    if (((ks * h) & 7) + keys > 32) return MRAG_EINVAL;
+  if (scores_ld % 8 || hidden_ld % 8 || scores_ld < (((int64_t)(H - 1) * ks) & ~7LL) + 32 || hidden_ld < (int64_t)H * 64) return MRAG_EINVAL;   // a lane group reads the 32 elements from the aligned chunk that holds a block's start
   if (((uintptr_t)scores & 15) || ((uintptr_t)hidden & 15) || ((uintptr_t)v & 15) || v_batch_stride % 8 || v_key_stride % 8) return MRAG_EINVAL;
   IpFoldP p{};
   p.scores = (const bf16_t*)scores; p.v = (const bf16_t*)v; p.o = (bf16_t*)hidden;

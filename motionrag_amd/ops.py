@@ -164,7 +164,7 @@ GEMM_TUNE_NO_W4 = 1 << 16      # keep long-K linears on the 8-wave 256x256 tile 
 def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,
                     out_scale: float = 1.0, key_stride: int = 32) -> torch.Tensor:
     """hidden [B, S, H*64] += out_scale * softmax(scores[..., h, :keys] * scale) @ v[b // kv_batch_div, :, h]; scores [B, S, W] with key k of head h at
-    column key_stride * h + k (32: keys padded to 32 per head, W = 32 H; an even key_stride in [keys, 32] packs the heads, W >= (H - 1) key_stride + 32),
+    column key_stride * h + k (32: keys padded to 32 per head, W = 32 H; a key_stride in [keys, 32] with ((key_stride h) mod 8) + keys <= 32 packs the heads, W >= (H - 1) key_stride + 32),
     v [B', keys, H*64] (rows may be strided)."""
     _dev(scores, name="scores"); _dev(v, name="v"); _dev(hidden, name="hidden")
     B, S, W = scores.shape

@@ -85,6 +85,22 @@ def test_cama_predict_against_reference_golden(hip, golden_dir):
     model.parallel_branches = False
     assert torch.equal(model.predict(batch, do_classifier_free_guidance=True), out)
     assert torch.equal(model.predict(batch, do_classifier_free_guidance=False), out[2:])
+    # ... and with every GEMM pinned to the tiled kernels (MRAG_GEMM_TUNE_NO_SKINNY: the few-row kernel's 256-row switch is what separates the forms on this
+    # fixture) the same three statements hold BIT FOR BIT -- the 1 % bounds above are the summation order of one kernel family against another, nothing else
+    from motionrag_amd import ops
+    ops.TUNING["gemm"] = 1 << 17
+    try:
+        model.parallel_branches = True
+        with ops.dispatched() as d:
+            out_t = model.predict(batch, do_classifier_free_guidance=True)
+            ev_t = model.encode_vision(torch.zeros_like(batch["ref_videos"][:, 0:1]))
+            literal_t = torch.cat([ev_t[:, 0], model.batch_forward(batch, return_loss=False)[:, -1]], dim=0)
+    finally:
+        ops.TUNING["gemm"] = 0
+    assert "GEMM_SKINNY" not in d.counts and "GEMM_SKINNY_LNA" not in d.counts, d.counts
+    assert torch.equal(ev_t[:, 0], out_t[:2])
+    assert torch.equal(out_t, literal_t)
+    close(out_t, torch.from_numpy(g["predict"]))
 
 
 def test_cama_predict_forms_are_bit_identical_at_the_shipped_geometry(hip, golden_dir):

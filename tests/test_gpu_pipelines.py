@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def close_chained_cfg(got, want, rel_l2=4e-2, p999_frac=0.2, max_frac=0.5):
+def close_chained_cfg(got, want, rel_l2=4e-2, p999_frac=0.2, max_frac=0.35):
     """Two chained CFG steps of a bf16 UNet against the fp32 oracle.  Guidance multiplies the two branches' independent bf16 errors, so single
     elements scatter widely while the aggregate error stays put; an absolute slack wide enough for the worst element on EVERY element would hide
     real regressions.  Three instruments instead: relative Frobenius error <= 4 % (measured 3.0 %); the 99.9th percentile of the element error
-    beyond 5 % of the element, in units of the mean magnitude, <= 0.2 (the level no element but one outlier of 4 096 has reached); a loose
-    bound of 0.5 on the maximum (catches a wrong element, not rounding)."""
+    beyond 5 % of the element, in units of the mean magnitude, <= 0.2 (the level no element but one outlier of 4 096 has reached); the
+    maximum <= 0.35 (the bound of rounds 3-4: the one measured outlier reaches 0.32; ADVICE r5 asked for it back)."""
     g, w = got.float().cpu(), want.float().cpu()
     assert g.shape == w.shape and torch.isfinite(g).all()
     l2 = ((g - w).norm() / w.norm()).item()

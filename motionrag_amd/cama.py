@@ -131,8 +131,10 @@ class Resampler(nn.Module):
         if not x.is_cuda:
             raise ops.HipOnly("Resampler: GPU tensors only")
         N, n1, _ = x.shape
-        if self.dim % 64 or self.embedding_dim % 64 or self.layers[0][1][1].out_features % 64:
-            return self.forward_sequenced(x, return_cls_tokens)      # widths the GEMM must zero-pad (reduced test configurations): `ops.linear` does that per call
+        if self.dim % 64 or self.embedding_dim % 64 or self.layers[0][1][1].out_features % 64 or ops.TUNING["gemm"]:
+            # widths the GEMM must zero-pad (reduced test configurations): `ops.linear` does that per call; a developer GEMM knob (tests pin a kernel family with
+            # it): the native sequencer issues untuned launches, so the knob is honoured by the Python-sequenced form only
+            return self.forward_sequenced(x, return_cls_tokens)
         a = self._native_args()
         L = ops._lib.lib()
         need = L.mrag_resampler_workspace_bytes(N, n1, a.nq, a.dim, a.output_dim, a.heads, a.ff_dim)
@@ -254,6 +256,8 @@ class TransformerEncoder(nn.Module):
         if not x.is_cuda:
             raise ops.HipOnly("TransformerEncoder: GPU tensors only")
         B, Lq, d = x.shape
+        if ops.TUNING["gemm"]:                                         # (a developer GEMM knob is honoured by the Python-sequenced form only: see Resampler.forward)
+            return self.forward_sequenced(x, mask)
         a = self._native_args()
         if mask is not None:
             if mask.dtype == torch.bool:

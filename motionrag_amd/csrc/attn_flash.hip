@@ -849,11 +849,6 @@ struct IpFoldP {
   float qscale, out_scale;
 };
 
-#ifdef MRAG_IPFOLD_NT        // developer A/B build: the scores (read once) through nontemporal loads
-#define MRAG_IPFOLD_LD(P) __builtin_nontemporal_load(P)
-#else
-#define MRAG_IPFOLD_LD(P) (*(P))
-#endif
 #ifndef MRAG_IPFOLD_HG
 #define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
 #endif
@@ -890,7 +885,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
     const long long row = g0 + r16;
     const long long rc = row < row_hi ? row : row_hi - 1;
     // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
-    u32x4 raw_n = MRAG_IPFOLD_LD((const u32x4*)(p.scores + rc * p.s_ld + ((h0 * p.ks) & ~7) + kq * 8));
+    u32x4 raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + ((h0 * p.ks) & ~7) + kq * 8);   // (nontemporal loads of the scores measured no different: profiles/r6_ip_attn_folded_packed_aligned.txt)
     u32x4 old_n[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(p.o + rc * p.o_ld + h0 * 64 + 32 * hf + 8 * kq);
@@ -900,7 +895,7 @@ __global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
       bf16_t* op = p.o + rc * p.o_ld + h * 64;
       const u32x4 old[2] = {old_n[0], old_n[1]};
       if (hl + 1 < nh) {
-        raw_n = MRAG_IPFOLD_LD((const u32x4*)(p.scores + rc * p.s_ld + (((h + 1) * p.ks) & ~7) + kq * 8));
+        raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + (((h + 1) * p.ks) & ~7) + kq * 8);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(op + 64 + 32 * hf + 8 * kq);
       }

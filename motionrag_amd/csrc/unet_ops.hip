@@ -68,7 +68,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnP p) {
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
   if (rsub < rpp) {
     const bf16_t* base = p.x + ((long long)n * p.HW) * p.C + c_off + col * 8;
-    for (long long px = px0 + rsub; px < px1; px += rpp) {
+    long long px = px0 + rsub;
+#ifndef MRAG_GN_OLD
+    // four pixel rows in flight per thread (the chunk is one contiguous run of the sample: px advances by the rows a pass covers), nontemporal: x is streamed once
+    // here; accumulated in the same order as the one-at-a-time loop, so the partial sums keep their bits (round 6: the HBM-bound GroupNorm passes sat at 4.8 TB/s
+    // against the 6.0 TB/s of the stream copy, whose sweep -- profiles/r6_copy_probe_sweep.txt -- says: contiguous runs, several loads in flight, nontemporal)
+    for (; px + 3 * rpp < px1; px += 4 * rpp) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load((const u32x4*)(base + (px + u * rpp) * p.C));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8(raw[u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+      }
+    }
+#endif
+    for (; px < px1; px += rpp) {
       float v[8];
       unpack8(*(const u32x4*)(base + px * p.C), v);
 #pragma unroll
@@ -207,22 +225,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnP p, const float*
   const long long vecs = p.HW * C8;
   const bf16_t* xb = p.x + (long long)n * p.HW * p.C;
   bf16_t* yb = p.y + (long long)n * p.HW * p.C;
-  // channel vector of element i without a 64-bit modulo per vector (~100 instructions against 8 FMAs): one modulo per thread, then a
-  // conditional subtract per grid stride
-  const unsigned stride = gridDim.x * 256u, cstep = stride % (unsigned)C8;
-  unsigned cv = (unsigned)((blockIdx.x * 256u + threadIdx.x) % (unsigned)C8);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += stride, cv = cv + cstep >= (unsigned)C8 ? cv + cstep - (unsigned)C8 : cv + cstep) {
-    const int c0 = (int)cv * 8;
+  auto one = [&](const u32x4 raw, const unsigned cvv) {
+    const int c0 = (int)cvv * 8;
     float v[8];
-    unpack8(*(const u32x4*)(xb + i * 8), v);
+    unpack8(raw, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float2 w = abl[c0 + e];
       const float o = v[e] * w.x + w.y;
       v[e] = p.silu ? silu_f(o) : o;
     }
-    *(u32x4*)(yb + i * 8) = pack8(v);
+    return pack8(v);
+  };
+#ifndef MRAG_GN_OLD
+  // a workgroup walks CONTIGUOUS runs of 4 x 256 vectors (16 KiB), four nontemporal loads in flight per thread (x is not read again before the residual add at the
+  // end of the block; y stays a plain store: the convolution behind it reads it nine times).  Channel vector of a thread's first element of a run by one modulo,
+  // then conditional subtracts per unrolled vector and per grid stride of runs (a 64-bit modulo per vector is ~100 instructions against 8 FMAs).
+  constexpr int U = 4;
+  const long long run = 256LL * U, nrun = vecs / run;
+  const unsigned c8u = (unsigned)C8, ustep = 256u % c8u, rstep = (unsigned)(((long long)gridDim.x * run) % C8);
+  unsigned cv0 = (unsigned)(((long long)blockIdx.x * run + threadIdx.x) % C8);
+  for (long long r = blockIdx.x; r < nrun; r += gridDim.x, cv0 = cv0 + rstep >= c8u ? cv0 + rstep - c8u : cv0 + rstep) {
+    const long long i = r * run + threadIdx.x;
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) raw[u] = __builtin_nontemporal_load((const u32x4*)(xb + (i + u * 256) * 8));
+    unsigned cv = cv0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      *(u32x4*)(yb + (i + u * 256) * 8) = one(raw[u], cv);
+      cv = cv + ustep >= c8u ? cv + ustep - c8u : cv + ustep;
+    }
   }
+  const long long tail0 = nrun * run;
+#else
+  const long long tail0 = 0;
+#endif
+  // (the vectors behind the last whole run -- or, in the MRAG_GN_OLD developer build, all of them: one vector per thread and grid stride)
+  const unsigned stride = gridDim.x * 256u, cstep = stride % (unsigned)C8;
+  unsigned cv = (unsigned)((tail0 + blockIdx.x * 256u + threadIdx.x) % C8);
+  for (long long i = tail0 + (long long)blockIdx.x * 256 + threadIdx.x; i < vecs; i += stride, cv = cv + cstep >= (unsigned)C8 ? cv + cstep - (unsigned)C8 : cv + cstep)
+    *(u32x4*)(yb + i * 8) = one(*(const u32x4*)(xb + i * 8), cv);
 }
 
 // pass 3, spatially conditioned: x [N, (t, y, x), C]; mod [N, Tz, H >> shift, W >> shift, 2C] holds conv_y(zq) | conv_b(zq) at the latent

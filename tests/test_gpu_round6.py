@@ -92,7 +92,7 @@ def test_gemm_per_sample_weights(hip, B, S, N, K):
 @pytest.mark.parametrize("B,S,H,keys,ks", [(2, 1000, 48, 25, 26), (1, 333, 4, 25, 30), (2, 128, 48, 9, 10)])
 def test_ip_attn_folded_packed_score_blocks(hip, B, S, H, keys, ks):
     """key k of head h at column ks * h + k instead of 32 * h + k (48 heads x 25 keys: 1 280 columns = five GEMM tiles instead of six): the same softmax . V
-    update bit for bit, whatever sits in the columns between and behind the blocks"""
+    update (to a bf16 ulp: the keys occupy other MFMA slots), whatever sits in the columns between and behind the blocks"""
     from motionrag_amd import ops
     g = torch.Generator().manual_seed(S)
     sc32 = bf(torch.randn(B, S, H, 32, generator=g) * 3).to(DEV)
@@ -107,7 +107,10 @@ def test_ip_attn_folded_packed_score_blocks(hip, B, S, H, keys, ks):
     with ops.dispatched() as d:
         ops.ip_attn_folded_(packed, v, b2, H, keys, out_scale=0.7, key_stride=ks)
     assert d.counts == {"IP_ATTN_FOLDED": 1}
-    assert torch.equal(a, b2)
+    # (key k of head h sits in MFMA slot k + (ks h) mod 8 of the aligned chunks that cover its block: another summation order over the keys than the 32-column
+    # layout's, so the two agree to fp32 rounding in front of the bf16 store -- a bf16 ulp on a few elements -- not bit for bit)
+    diff = (a.float() - b2.float()).abs()
+    assert diff.max().item() <= 2.0 ** -5 and (diff.norm() / a.float().norm()).item() <= 1e-3, (diff.max().item(), (diff.norm() / a.float().norm()).item())
     p = torch.softmax(sc32[..., :keys].float() * 0.125, dim=-1)                 # [B, S, H, keys]
     want = h0.float() + 0.7 * torch.einsum("bshk,bkhd->bshd", p, v.view(B, keys, H, 64).float()).reshape(B, S, H * 64)
     close(a, want)

@@ -853,7 +853,7 @@ struct IpFoldP {
 #define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
 #endif
 #ifndef MRAG_IPFOLD_WPE
-#define MRAG_IPFOLD_WPE 8   // waves per SIMD the register allocation is held to (8 -> 62 VGPRs, 7 -> 65, unconstrained 76: developer knob, tools/build_variant.sh)
+#define MRAG_IPFOLD_WPE 7   // waves per SIMD the register allocation is held to (7 -> 65 VGPRs; 8 -> 62 with 42 spilled SGPRs measured 8 % slower; unconstrained: 76 VGPRs, 6 waves: developer knob, tools/build_variant.sh)
 #endif
 __global__ __launch_bounds__(256, MRAG_IPFOLD_WPE) void ip_attn_folded_kernel(const IpFoldP p) {
   constexpr int HG = MRAG_IPFOLD_HG;                       // heads per block

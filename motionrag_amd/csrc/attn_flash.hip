@@ -852,10 +852,7 @@ struct IpFoldP {
 #ifndef MRAG_IPFOLD_HG
 #define MRAG_IPFOLD_HG 4    // heads whose V^T image a workgroup keeps in LDS (4 KB each); MI355X, DiT shape: 16 -> 196 us, 8 -> 194, 4 -> 185 (more workgroups in flight)
 #endif
-#ifndef MRAG_IPFOLD_WPE
-#define MRAG_IPFOLD_WPE 7   // waves per SIMD the register allocation is held to (7 -> 65 VGPRs; 8 -> 62 with 42 spilled SGPRs measured 8 % slower; unconstrained: 76 VGPRs, 6 waves: developer knob, tools/build_variant.sh)
-#endif
-__global__ __launch_bounds__(256, MRAG_IPFOLD_WPE) void ip_attn_folded_kernel(const IpFoldP p) {
+__global__ __launch_bounds__(256) void ip_attn_folded_kernel(const IpFoldP p) {
   constexpr int HG = MRAG_IPFOLD_HG;                       // heads per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* vt = (bf16_t*)smem;                               // [HG][64 d][4 swizzled chunks of 8 keys]
@@ -884,95 +881,61 @@ __global__ __launch_bounds__(256, MRAG_IPFOLD_WPE) void ip_attn_folded_kernel(co
   const int dbase = 8 * (r16 >> 2) + (r16 & 3), kchunk = (kq ^ (r16 >> 2)) << 3;
   // this K/V batch covers q batches [kb * kv_div, (kb + 1) * kv_div): rows [row_lo, row_hi)
   const long long row_lo = (long long)kb * p.kv_div * p.rows_per_batch, row_hi = row_lo + (long long)p.kv_div * p.rows_per_batch;
-  // one head of one 16-row group: softmax over the head's key slots, P . V on four MFMAs, hidden += scale * that, two 16-byte stores per lane
-  auto head = [&](const int hl, const u32x4 raw, const u32x4 old0, const u32x4 old1, bf16_t* op, const bool store_ok) __attribute__((always_inline)) {
-    const int h = h0 + hl;
-    const u32x4 old[2] = {old0, old1};
-    float sv[8], m = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sv[2 * e] = __uint_as_float(raw[e] << 16) * p.qscale;
-      sv[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u) * p.qscale;
-    }
-    const int shift = (p.ks * h) & 7;                           // slot of key 0 (wave-uniform)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if ((unsigned)(kq * 8 + e - shift) >= (unsigned)p.keys) sv[e] = -INFINITY;
-      m = fmaxf(m, sv[e]);
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - m); l += sv[e]; }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const u32x4 pw = {pack_bf2(sv[0], sv[1]), pack_bf2(sv[2], sv[3]), pack_bf2(sv[4], sv[5]), pack_bf2(sv[6], sv[7])};
-    const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
-    const float inv = p.out_scale / l;
-    const bf16_t* vh = vt + hl * 64 * 32 + kchunk;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {                            // features 32 hf + 8 kq .. + 7 of this lane's row
-      u32x4 nw;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {                             // MFMA t = 2 hf + q: features 32 hf + 8 kq + 4 q .. + 3
-        const bf16x8 va = *(const bf16x8*)(vh + (dbase + 4 * q + 32 * hf) * 32);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 32 hf + 8 kq + 4 q + i]
-        const unsigned o0 = old[hf][2 * q], o1 = old[hf][2 * q + 1];
-        nw[2 * q] = pack_bf2(__uint_as_float(o0 << 16) + acc[0] * inv, __uint_as_float(o0 & 0xffff0000u) + acc[1] * inv);
-        nw[2 * q + 1] = pack_bf2(__uint_as_float(o1 << 16) + acc[2] * inv, __uint_as_float(o1 & 0xffff0000u) + acc[3] * inv);
-      }
-      if (store_ok) *(u32x4*)(op + 32 * hf + 8 * kq) = nw;
-    }
-  };
   for (long long g0 = row_lo + ((long long)blockIdx.x * 4 + wave) * 16; g0 < row_hi; g0 += (long long)gridDim.x * 64) {
     const long long row = g0 + r16;
     const long long rc = row < row_hi ? row : row_hi - 1;
-    const bf16_t* sp = p.scores + rc * p.s_ld + kq * 8;
-    bf16_t* hp = p.o + rc * p.o_ld + h0 * 64;
-#ifndef MRAG_IPFOLD_NO_COUNTED
-    if (HG == 4 && nh == HG && g0 + 16 <= row_hi) {
-      // FAST PATH (whole head groups, whole row groups: every workgroup of the DiT): the next head's scores and current values are requested while this head is
-      // processed, as below -- but on gfx950 vmcnt also counts STORES, and hipcc, which cannot see across the loop's back edge, waited with vmcnt(0) at the top of
-      // every head: for the previous head's two stores to retire, a round trip per head that the kernel's bandwidth paid for (4.7 TB/s).  Here the four heads are
-      // unrolled, the loads are hand-written (invisible to hipcc's counter) and each head waits with a COUNTED vmcnt that leaves the younger operations in flight:
-      // queue at head hl's wait = [L(hl): 3 loads][S(hl - 1): 2 stores][L(hl + 1): 3 loads] -> vmcnt(5) (3 at the first head, 2 at the last).  INVARIANT: exactly
-      // two stores per head and no other vector-memory operation between the requests and the waits.
-      u32x4 rw[2], oa[2], ob[2];
-#define MRAG_IPF_LD(D, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(D) : "v"(PTR), "n"(OFF) : "memory")
-#define MRAG_IPF_REQ(SET, HL)                                                      \
-      {                                                                            \
-        const bf16_t* s_ = sp + (((h0 + (HL)) * p.ks) & ~7);                       \
-        const bf16_t* o_ = hp + 64 * (HL) + 8 * kq;                                \
-        MRAG_IPF_LD(rw[SET], s_, 0); MRAG_IPF_LD(oa[SET], o_, 0); MRAG_IPF_LD(ob[SET], o_, 64);   \
-      }
-#define MRAG_IPF_WAIT(SET, N) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(rw[SET]), "+v"(oa[SET]), "+v"(ob[SET]) : "n"(N) : "memory")
-      MRAG_IPF_REQ(0, 0);
-      MRAG_IPF_REQ(1, 1); MRAG_IPF_WAIT(0, 3); head(0, rw[0], oa[0], ob[0], hp, true);
-      MRAG_IPF_REQ(0, 2); MRAG_IPF_WAIT(1, 5); head(1, rw[1], oa[1], ob[1], hp + 64, true);
-      MRAG_IPF_REQ(1, 3); MRAG_IPF_WAIT(0, 5); head(2, rw[0], oa[0], ob[0], hp + 128, true);
-      MRAG_IPF_WAIT(1, 2); head(3, rw[1], oa[1], ob[1], hp + 192, true);
-#undef MRAG_IPF_LD
-#undef MRAG_IPF_REQ
-#undef MRAG_IPF_WAIT
-      continue;
-    }
-#endif
-    // general path (a ragged head group or row group): the same prefetch through compiler-visible loads
-    u32x4 raw_n = *(const u32x4*)(sp + ((h0 * p.ks) & ~7));
+    // the row's scores and current values of the NEXT head are requested while this head is processed (latency-bound kernel)
+    u32x4 raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + ((h0 * p.ks) & ~7) + kq * 8);   // (nontemporal loads of the scores measured no different: profiles/r6_ip_attn_folded_packed_aligned.txt)
     u32x4 old_n[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(hp + 32 * hf + 8 * kq);
+    for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(p.o + rc * p.o_ld + h0 * 64 + 32 * hf + 8 * kq);
     for (int hl = 0; hl < nh; ++hl) {
-      const u32x4 raw = raw_n, old0 = old_n[0], old1 = old_n[1];
-      bf16_t* op = hp + 64 * hl;
+      const int h = h0 + hl;
+      const u32x4 raw = raw_n;
+      bf16_t* op = p.o + rc * p.o_ld + h * 64;
+      const u32x4 old[2] = {old_n[0], old_n[1]};
       if (hl + 1 < nh) {
-        raw_n = *(const u32x4*)(sp + (((h0 + hl + 1) * p.ks) & ~7));
+        raw_n = *(const u32x4*)(p.scores + rc * p.s_ld + (((h + 1) * p.ks) & ~7) + kq * 8);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) old_n[hf] = *(const u32x4*)(op + 64 + 32 * hf + 8 * kq);
       }
-      head(hl, raw, old0, old1, op, row < row_hi);
+      float sv[8], m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sv[2 * e] = __uint_as_float(raw[e] << 16) * p.qscale;
+        sv[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u) * p.qscale;
+      }
+      const int shift = (p.ks * h) & 7;                           // slot of key 0 (wave-uniform)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if ((unsigned)(kq * 8 + e - shift) >= (unsigned)p.keys) sv[e] = -INFINITY;
+        m = fmaxf(m, sv[e]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - m); l += sv[e]; }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const u32x4 pw = {pack_bf2(sv[0], sv[1]), pack_bf2(sv[2], sv[3]), pack_bf2(sv[4], sv[5]), pack_bf2(sv[6], sv[7])};
+      const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
+      const float inv = p.out_scale / l;
+      const bf16_t* vh = vt + hl * 64 * 32 + kchunk;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {                            // features 32 hf + 8 kq .. + 7 of this lane's row
+        u32x4 nw;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                             // MFMA t = 2 hf + q: features 32 hf + 8 kq + 4 q .. + 3
+          const bf16x8 va = *(const bf16x8*)(vh + (dbase + 4 * q + 32 * hf) * 32);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc, 0, 0, 0);     // acc[i] = out[row = r16][d = 32 hf + 8 kq + 4 q + i]
+          const unsigned o0 = old[hf][2 * q], o1 = old[hf][2 * q + 1];
+          nw[2 * q] = pack_bf2(__uint_as_float(o0 << 16) + acc[0] * inv, __uint_as_float(o0 & 0xffff0000u) + acc[1] * inv);
+          nw[2 * q + 1] = pack_bf2(__uint_as_float(o1 << 16) + acc[2] * inv, __uint_as_float(o1 & 0xffff0000u) + acc[3] * inv);
+        }
+        if (row < row_hi) *(u32x4*)(op + 32 * hf + 8 * kq) = nw;
+      }
     }
   }
 }

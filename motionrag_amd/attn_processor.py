@@ -22,6 +22,18 @@ from torch import nn
 from . import ops
 
 
+def packed_score_layout(heads: int, keys: int):
+    """(key stride, score columns) of the folded motion branch's score GEMM: the heads' blocks of `keys` scores packed at the smallest even pitch that drops a
+    256-column GEMM tile against 32 columns per head (48 heads x 25 keys: pitch 26, 1 280 columns = five tiles instead of six), else (32, 32 * heads).
+    A block's keys must fit the 32 slots of the four aligned 16-byte chunks that cover it: ((pitch * h) mod 8) + keys <= 32 for every head
+    (mrag_ip_attn_folded_bf16); the column count is a whole number of tiles and holds the last block's aligned 32-element window."""
+    tiles32 = -(-(heads * 32) // 256)
+    for c in range(keys + (keys & 1), 32, 2):
+        if -(-((heads - 1) * c + 32) // 256) < tiles32 and all(((c * h) & 7) + keys <= 32 for h in range(min(heads, 8))):
+            return c, -(-((heads - 1) * c + 32) // 256) * 256
+    return 32, heads * 32
+
+
 PACK_SCORE_BLOCKS = True   # developer A/B knob (tools/r6_step_ab.py): False keeps the folded scores at 32 columns per head (round 5's layout)
 # fold `to_q_ip` into the motion keys once per clip (joint_attention_core); False reproduces the reference's op order literally
 FOLD_IP_QUERY = True
@@ -164,10 +176,7 @@ def _motion_branch(attn, proc, o, ip_hidden_states, scale):
             # KS = 32), else 32.  Both CFG samples' score GEMMs are ONE launch with per-sample weights (ops.linear_per_sample): 700 tiles = 3 rounds of
             # the persistent grid where two launches of 420 paid 2 + 2 (round 6).
             nk = ip.size(1)
-            # (a block's keys must fit the 32 slots of the four aligned 16-byte chunks that cover it: ((KS h) mod 8) + nk <= 32 -- mrag_ip_attn_folded_bf16)
-            KS = next((c for c in range(nk + (nk & 1), 32, 2)
-                       if -(-((H - 1) * c + 32) // 256) < -(-(H * 32) // 256) and all(((c * h) & 7) + nk <= 32 for h in range(min(H, 8)))), 32) if PACK_SCORE_BLOCKS else 32
-            NW = -(-((H - 1) * KS + 32) // 256) * 256 if KS != 32 else H * 32
+            KS, NW = packed_score_layout(H, nk) if PACK_SCORE_BLOCKS else (32, H * 32)
 
             def build():
                 kv0 = ops.linear(ip, wkv)                                         # :251-252 (one GEMM)

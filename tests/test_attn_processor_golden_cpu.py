@@ -118,3 +118,19 @@ def test_adapter_pipeline_glue_restated(golden_dir):
     # `_encode_image` returns TupleTensor([image_embedding (CFG: zeros first), action_emb]) (:113-119)
     np.testing.assert_array_equal(g["svd.action.tt1"], g["svd.action.mean"])
     assert g["svd.action.tt0"].shape[0] == 2 * bsz and not g["svd.action.tt0"][:bsz].any()
+
+
+def test_packed_score_layout_of_the_folded_motion_branch():
+    """host logic of round 6's packed score blocks (attn_processor.packed_score_layout): the pitch that drops a 256-column tile of the score GEMM, the
+    alignment constraint of mrag_ip_attn_folded_bf16, and the fall-back to 32 columns per head"""
+    from motionrag_amd.attn_processor import packed_score_layout
+    assert packed_score_layout(48, 25) == (26, 1280)            # the DiT: 48 x 26 = 1 248 -> five tiles instead of six
+    assert packed_score_layout(2, 25) == (32, 64)               # nothing to gain below one tile
+    assert packed_score_layout(48, 31) == (32, 1536)            # no even pitch below 32 holds 31 keys and their shift
+    assert packed_score_layout(16, 9) == (10, 256)              # 16 x 32 = 512 (two tiles) -> 15 x 10 + 32 = 182 (one)
+    for heads in (5, 8, 10, 16, 24, 40, 48, 64):
+        for keys in range(1, 33):
+            ks, nw = packed_score_layout(heads, keys)
+            assert keys <= ks <= 32 and nw % 4 == 0 and nw >= (((heads - 1) * ks) & ~7) + 32
+            assert all(((ks * h) & 7) + keys <= 32 for h in range(heads))
+            assert nw <= heads * 32 and (ks == 32 or nw % 256 == 0)

@@ -159,6 +159,8 @@ def _gemm_workspace(a: "GemmArgs", device: torch.device) -> None:
 M_SK_MIN_ROWS = 4096          # below this no 256x256 grid reaches a second round: skip the query
 GEMM_TUNE_STREAMK = 8
 GEMM_TUNE_NO_W4 = 1 << 16      # keep long-K linears on the 8-wave 256x256 tile (A/B knob; default: the persistent four-wave kernel where it applies)
+GEMM_TUNE_NO_SKINNY = 1 << 17  # keep few-row problems (M <= 256) on the tiled kernels (tests pin one kernel family with it)
+GEMM_TUNE_TAIL_RECT = 1 << 19  # opt-in: a small partial last round of the persistent GEMM as its own launch of 128x128 tiles (measured equal: DESIGN 3.7d)
 
 
 def ip_attn_folded_(scores: torch.Tensor, v: torch.Tensor, hidden: torch.Tensor, H: int, keys: int, kv_batch_div: int = 1, scale: float = 0.125,

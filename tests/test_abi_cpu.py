@@ -52,7 +52,7 @@ def test_tuning_constants_match_the_header():
     vals = {}
     for name, expr in re.findall(r"(MRAG_(?:GEMM|ATTN)_TUNE_\w+)\s*=\s*([^,}/]+)", hdr):
         vals[name] = eval(expr.strip(), {}, {})          # "8", "1 << 16"
-    for py in ("GEMM_TUNE_NO_WIDE", "GEMM_TUNE_NO_STAGED", "GEMM_TUNE_GEGLU_NO_STAGED", "GEMM_TUNE_STREAMK", "GEMM_TUNE_NO_W4",
+    for py in ("GEMM_TUNE_NO_WIDE", "GEMM_TUNE_NO_STAGED", "GEMM_TUNE_GEGLU_NO_STAGED", "GEMM_TUNE_STREAMK", "GEMM_TUNE_NO_W4", "GEMM_TUNE_NO_SKINNY", "GEMM_TUNE_TAIL_RECT",
                "ATTN_TUNE_NO_TINY", "ATTN_TUNE_LEGACY"):
         assert vals["MRAG_" + py] == getattr(ops, py), py
 

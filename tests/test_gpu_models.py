@@ -88,7 +88,7 @@ def test_cama_predict_against_reference_golden(hip, golden_dir):
     # ... and with every GEMM pinned to the tiled kernels (MRAG_GEMM_TUNE_NO_SKINNY: the few-row kernel's 256-row switch is what separates the forms on this
     # fixture) the same three statements hold BIT FOR BIT -- the 1 % bounds above are the summation order of one kernel family against another, nothing else
     from motionrag_amd import ops
-    ops.TUNING["gemm"] = 1 << 17
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_NO_SKINNY
     try:
         model.parallel_branches = True
         with ops.dispatched() as d:

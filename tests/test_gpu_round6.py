@@ -42,7 +42,7 @@ def test_gemm_w4_tail_rectangle(hip, tm, tn, K, epi):
     x, w, b = bf(torch.randn(M, K, generator=g)).to(DEV), bf(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV), bf(torch.randn(N, generator=g)).to(DEV)
     r = bf(torch.randn(M, N, generator=g)).to(DEV) if epi == "resid" else None
     kw = {"none": {}, "resid": dict(epilogue=ops.EPI_RESID, resid=r), "gelu": dict(epilogue=ops.EPI_GELU_TANH)}[epi]
-    ops.TUNING["gemm"] = 1 << 19                    # MRAG_GEMM_TUNE_TAIL_RECT (opt-in: measured equal to the partial round on the DiT's FF1)
+    ops.TUNING["gemm"] = ops.GEMM_TUNE_TAIL_RECT     # MRAG_GEMM_TUNE_TAIL_RECT (opt-in: measured equal to the partial round on the DiT's FF1)
     try:
         with ops.dispatched() as d:
             got = ops.linear(x, w, b, **kw)

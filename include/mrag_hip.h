@@ -86,6 +86,7 @@ enum mrag_kernel_id {
   MRAG_K_GEMM_W4_TAIL_RECT,    /* (opt-in, MRAG_GEMM_TUNE_TAIL_RECT) the 128x128-tile launch behind a persistent launch whose last round would be nearly empty */
   MRAG_K_GEMM_W4_BATCHED_W,    /* gemm_w4_kernel<NONE, true>: per-sample weights (w_batch_stride) */
   MRAG_K_GEMM_SKINNY_LNA,      /* gemm_skinny_kernel<.., LNA>: LayerNorm of the A rows fused into the few-row GEMM's A load */
+  MRAG_K_TOPK_DENSE,           /* topk_dense_kernel: the fan-out search in ONE launch (tables whose grid is resident at once: dense first scores, bounded grid wait, claimed finishing) */
   MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
   MRAG_K_COUNT
 };
@@ -519,6 +520,13 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       for bit, whatever the call shape (round 6; mode 2 of the oracle restates */
 /*       selection + second scoring).  "dot": 1 - chain, no second scoring.       */
 /*       n_queries >= 16, k <= 16, else MRAG_ENOTSUP;                            */
+/*       Tables of one resident round of workgroups (<= 65 536 rows; 10 000 x 256: BASELINE config #1) run it as ONE launch: the first scores of
+ *       every (query, row) leave as a dense matrix in the workspace, every workgroup waits -- bounded -- until the grid has arrived, and the
+ *       workgroups then claim queries and finish them (16 nearest under the first score, second scoring, filter order).  Larger tables stream: a
+ *       |q|^2 pre-pass, the fan-out kernel with in-kernel lists, a merge launch.  Both compute the SAME defined result.
+ *   3 = order 2, streaming (three-launch) form forced;   4 = order 2, one-launch form forced (MRAG_ENOTSUP where its plan does not apply) and
+ *       WITHOUT waiting: every workgroup but the last arriver leaves at once and the last one finishes every query -- diagnostics of the two forms'
+ *       equality and of the bounded wait's fall-back.                                                                                             */
 /*   0 = automatic: 2 where it applies (faster at every table size measured,     */
 /*       1 000 to 10^6 rows), else 1.  "l2": a row gets the same distance from   */
 /*       both; WHICH rows make the list can differ only where the k-th and a     */
@@ -527,9 +535,10 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       bits of a distance (never in a rank whose gap exceeds the fp32 rounding */
 /*       of the sum: tests compare both with the float64 oracle).                */
 /* ------------------------------------------------------------------------ */
-/* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch form
- * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges): they must be ZERO before the first call on a
- * workspace; every call leaves them zero, so a workspace is zeroed once when it is allocated.                                 */
+/* workspace: >= mrag_topk_workspace_bytes, 16-byte aligned.  Its first 64 bytes are arrival counters of the single-launch forms
+ * (n_queries <= 4: scan + merge in ONE launch, the last workgroup to arrive merges; the one-launch fan-out form: words 8..14, two
+ * counter sets used alternately): they must be ZERO before the first call on a workspace; every call leaves them ready for the next one
+ * (of any form, on the same stream), so a workspace is zeroed once when it is allocated and never written by the caller afterwards.   */
 int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries);
 int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim,
                   const float* queries, const int32_t* exclude, int32_t n_queries,

@@ -319,67 +319,49 @@ __global__ __launch_bounds__(256, QT == 16 ? 3 : 4) void topk_scan_kernel(const 
 // unique top-k under the total order (distance, row), whatever the merge order.
 // `sh` = 4 x 64 candidates + 1 of LDS scratch.
 // LIST = entries per partial list: 64 (the scan kernel's per-wave lists) or 16 (the fan-out kernel's per-workgroup lists; lanes >= 16 read +inf)
-template <int LIST>
-__device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
-  Cand* thr_s = sh + 256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int nparts = p.slices * p.wpb;
-  const Cand* lists = p.ws + (long long)q * nparts * LIST;
+// the tail of every merge: `run` = the sorted nearest candidates of query q across the lanes of the group's first wave (lt < 64) -> second scoring
+// (p.rescore), filter order, output.  lt = thread index inside the 256-thread group that merges this query (the merge kernels: threadIdx.x; the
+// one-launch fan-out form runs two groups per 512-thread workgroup), sh = the group's 257-candidate scratch, store = false: a group without a
+// query of its own walks through the barriers only.
+__device__ __forceinline__ void finish_query(const TopkP& p, const int q, Cand run, Cand* sh, const int lt, const bool store) {
+  const int lane = lt & 63, wave = lt >> 6;
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
-  Cand best = inf;
-  for (int base = wave * 64; base < nparts; base += nw * 64) {
-    const int part = base + lane;
-    Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
-    m = wave_sort(m, lane);
-    best = wave_merge_top(best, m, lane);
-  }
-  sh[wave * 64 + lane] = best;
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < nw; ++w) best = wave_merge_top(best, sh[w * 64 + lane], lane);
-    if (lane == p.k - 1) *thr_s = best;           // k-th smallest minimum
-  }
-  __syncthreads();
-  const Cand thr = *thr_s;
-  Cand run = inf;
-  for (int base = wave * 64; base < nparts; base += nw * 64) {
-    const int part = base + lane;
-    const Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
-    unsigned long long todo = __ballot(part < nparts && !cand_less(thr, m));   // min <= thr
-    while (todo) {
-      const int src = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const Cand c = lane < LIST ? lists[(long long)(base + src) * LIST + lane] : inf;
-      run = wave_merge_top(run, c, lane);
-    }
-  }
-  __syncthreads();
-  sh[wave * 64 + lane] = run;
-  __syncthreads();
-  if (wave == 0)
-    for (int w = 1; w < nw; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
   if (p.rescore) {
     // The fan-out form scores "l2" through |q|^2 + |x|^2 - 2 q.x: good for SELECTING neighbours, but its absolute error is an ulp of |q|^2 + |x|^2
     // (~1e-4 on unnormalised 768-d embeddings) -- a row's distance to itself came out as 1e-3, near-duplicates as noise or negative, and `_distance`
-    // feeds condition_fusion's weights (src/projects/condition/utils.py:7-36).  So the 16 nearest candidates under that score (always
-    // inside the union of the per-workgroup top-16 lists, whatever the plan) are scored AGAIN here with the scan kernel's definition -- the direct
-    // sum of (q - x)^2 on 16 interleaved fmaf chains + the fixed tree, oracle mode 0 -- and re-ranked: the distances a row gets no longer depend on
-    // the call shape, and ranks among near neighbours follow the exact form.  16 lanes per candidate, 16 candidates per pass of the workgroup.
+    // feeds condition_fusion's weights (src/projects/condition/utils.py:7-36).  So the 16 nearest candidates under that score are scored
+    // AGAIN here with the scan kernel's definition -- the direct sum of (q - x)^2 on 16 interleaved fmaf chains + the fixed tree, oracle mode 0 -- and
+    // re-ranked: the distances a row gets no longer depend on the call shape, and ranks among near neighbours follow the exact form.  16 lanes per
+    // candidate, 16 candidates per pass of the group.
     __syncthreads();
     if (wave == 0) sh[lane] = run;
     __syncthreads();
-    const int c = tid >> 4, s16 = tid & 15;
-    const Cand cc = sh[c];                                  // (blockDim.x == 256: c < 16)
+    const int c = lt >> 4, s16 = lt & 15;                   // (256 threads: c < 16)
+    const Cand cc = sh[c];
     float acc = 0.f;
     if (cc.r != INT_MAX) {
       const float* x = p.db + (long long)cc.r * p.dim;
       const float* qv = p.q + (long long)q * p.dim;
-      for (int k0 = 4 * s16; k0 < p.dim; k0 += 64) {        // chain s16: features 64 j + 4 s16 + {0, 1, 2, 3} (dim % 4 == 0)
-        const float4 xv = *(const float4*)(x + k0), q4 = *(const float4*)(qv + k0);
-        float df = q4.x - xv.x; acc = __builtin_fmaf(df, df, acc);
-        df = q4.y - xv.y; acc = __builtin_fmaf(df, df, acc);
-        df = q4.z - xv.z; acc = __builtin_fmaf(df, df, acc);
-        df = q4.w - xv.w; acc = __builtin_fmaf(df, df, acc);
+      // chain s16: features 64 j + 4 s16 + {0, 1, 2, 3} (dim % 4 == 0), j ascending.  The loads of twelve steps (all of a 768-d row) are issued together and the
+      // chain then runs over registers: as a plain loop every step waited for its own two loads -- twelve memory round trips per candidate, ~10 us of the merge.
+      // (A step past the row loads nothing and adds fmaf(0, 0, acc) = acc: the sum of squares is never -0.)
+      constexpr int UB = 12;
+      for (int kb = 4 * s16; kb < p.dim; kb += 64 * UB) {
+        float4 xv[UB], q4[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k0 = kb + 64 * u;
+          const bool in = k0 < p.dim;
+          xv[u] = in ? *(const float4*)(x + k0) : float4{0.f, 0.f, 0.f, 0.f};
+          q4[u] = in ? *(const float4*)(qv + k0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          float df = q4[u].x - xv[u].x; acc = __builtin_fmaf(df, df, acc);
+          df = q4[u].y - xv[u].y; acc = __builtin_fmaf(df, df, acc);
+          df = q4[u].z - xv[u].z; acc = __builtin_fmaf(df, df, acc);
+          df = q4[u].w - xv[u].w; acc = __builtin_fmaf(df, df, acc);
+        }
       }
     }
     acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);   // p[l] += p[l ^ 8], ^ 4, ^ 2, ^ 1
@@ -391,7 +373,7 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
       run = wave_sort(run, lane);
     }
   }
-  if (wave == 0) {
+  if (wave == 0 && store) {
     if (p.post_group) {
       // lancedb's postfilter: the k nearest are final; rows of the excluded group leave the list, the rest keep their order and move up
       const bool ok = lane < p.k && run.r != INT_MAX;
@@ -414,6 +396,48 @@ __device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
     }
   }
   __syncthreads();
+}
+
+template <int LIST>
+__device__ __forceinline__ void merge_query(const TopkP& p, int q, Cand* sh) {
+  Cand* thr_s = sh + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int nparts = p.slices * p.wpb;
+  const Cand* lists = p.ws + (long long)q * nparts * LIST;
+  Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
+  Cand best = inf;
+  for (int base = wave * 64; base < nparts; base += nw * 64) {
+    const int part = base + lane;
+    Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
+    m = wave_sort(m, lane);
+    best = wave_merge_top(best, m, lane);
+  }
+  sh[wave * 64 + lane] = best;
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < nw; ++w) best = wave_merge_top(best, sh[w * 64 + lane], lane);
+    if (lane == (p.rescore ? 16 : p.k) - 1) *thr_s = best;   // k-th smallest minimum (the 16th when a second scoring follows: it takes the 16 nearest)
+  }
+  __syncthreads();
+  const Cand thr = *thr_s;
+  Cand run = inf;
+  for (int base = wave * 64; base < nparts; base += nw * 64) {
+    const int part = base + lane;
+    const Cand m = part < nparts ? lists[(long long)part * LIST] : inf;
+    unsigned long long todo = __ballot(part < nparts && !cand_less(thr, m));   // min <= thr
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const Cand c = lane < LIST ? lists[(long long)(base + src) * LIST + lane] : inf;
+      run = wave_merge_top(run, c, lane);
+    }
+  }
+  __syncthreads();
+  sh[wave * 64 + lane] = run;
+  __syncthreads();
+  if (wave == 0)
+    for (int w = 1; w < nw; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
+  finish_query(p, q, run, sh, tid, true);
 }
 
 template <int LIST>
@@ -811,6 +835,379 @@ __global__ __launch_bounds__(256 * WN) void topk_mfma_kernel(const TopkMP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fan-out, ONE launch: tables that fit one round of workgroups
+// BASELINE config #1's own table (10 000 rows x 256 queries) is ONE row block per workgroup of the streaming form above: every workgroup paid its ~6
+// workgroup-synchronous selection rounds on a cold list (half of its time), and the call was three launches (|q|^2 pre-pass, fan-out, merge: 6.5 + 115 + 14 us
+// + the gaps between them).  This form drops the in-kernel selection and the extra launches:
+//   * the same LDS-DMA / fp32-MFMA stream over ONE row block per workgroup; |q|^2 is accumulated from the query fragments the MFMAs read anyway (the same
+//     two half-block chains, added once: bit-identical to topk_qq_kernel), |x|^2 as above;
+//   * the workgroup's 128 x QB first scores go through an LDS tile into a DENSE [query][row] matrix in the workspace (512-byte runs per query; rows past the
+//     table, excluded rows and NaNs as +inf) -- 10 MB at 10 000 x 256;
+//   * every workgroup then arrives at one counter and waits for the others (the plan launches this form only when the whole grid is resident at once --
+//     hipOccupancyMaxActiveBlocksPerMultiprocessor x 256 CUs; the wait is BOUNDED: a workgroup that gives up simply leaves), and the workgroups that have
+//     seen everybody arrive -- always including the last arriver -- CLAIM queries from a second counter and finish them: thread minima -> the 16th (k-th)
+//     smallest minimum bounds the answer -> the few scores under that bound are compacted per wave, sorted and merged -> finish_query (second scoring,
+//     filter order, output).  The result is the top-k under the total order (first score, row), i.e. what the streaming form and oracle mode 2 define.
+//   * the counters live in words 8..14 of the workspace's first 64 bytes (two sets used alternately: a call's last arriver zeroes the other set).
+// agent-coherent accesses of the one-launch form's hand-over data (first scores, group minima): written THROUGH the XCD's L2 (sc1) and read past it, i.e. what an
+// agent-scope atomic store / load compiles to, 16 bytes wide.  Nothing of the hand-over is then dirty in an L2, and the arrival needs no release fence: a
+// `buffer_wbl2` per workgroup walks the whole L2 (632 workgroups: 57 us of a 130-us call; 158: 11 us) -- a wait for the stores' acknowledgements is enough.
+__device__ __forceinline__ void store_agent_x4(float* ptr, const f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float load_agent(const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct TopkDP {
+  const float* db; const int* group; const float* q; const int* excl;
+  float* dist;            // [nq][ld] first scores
+  float* gmin;            // [nq][ld / 32]: the smallest first score of every 32-row group (a wave's rows of a workgroup's row block)
+  unsigned* sync;         // [7]: seq | {arrivals, go, claims} x 2 (see the kernel's hand-off): zero before the first call on a workspace
+  long long n_rows; int dim, nq, nslab, ld, total, spin_limit;
+  TopkP mp;               // what finish_query needs (k, rescore, outputs, post-filter ids)
+};
+
+constexpr int dense_stages(int tiles) { return tiles == 1 ? 2 : 3; }   // 32 queries per workgroup: two 20-KB stages, THREE workgroups per CU (10 000 x 256: 632 workgroups = 2.47 per CU)
+#ifndef MRAG_TOPK_DENSE_SLEEP
+#define MRAG_TOPK_DENSE_SLEEP 32     // x 64 cycles between two looks at the `go` word (~1 us)
+#endif
+constexpr int DENSE_BUF = 128;      // per-wave compaction buffer of the finishing phase: < 64 left over + <= 64 new candidates per step
+
+// finish query q from the dense first scores: one 256-thread group (lt = 0..255); scratch `sh` (257 candidates), `bufs` (4 x DENSE_BUF candidates) and
+// `glist` (1 + ld / 32 ints).  The 32-row groups' minima bound the answer (the keep-th smallest minimum: `keep` groups hold a score at or under it, so the
+// keep-th nearest row does too); only the groups whose minimum passes the bound are read at all -- about `keep` runs of 128 bytes out of the query's 40 KB at
+// 10 000 rows -- and ALL of them at once: the passing groups are listed first, then every thread loads its elements of the list (one memory round trip; the
+// first form walked the groups two at a time, a dependent load each: 18 us per query).
+__device__ __forceinline__ void dense_select(const TopkDP& p, const int q, const bool store, const int lt, Cand* sh, Cand* bufs, int* glist) {
+  const int lane = lt & 63, wave = lt >> 6;
+  const int ngrp = p.ld >> 5;
+  const float* D = p.dist + (long long)q * p.ld;
+  const float* G = p.gmin + (long long)q * ngrp;
+  const int keep = p.mp.rescore ? 16 : p.mp.k;
+  Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
+  // ---- the bound (a thread's minimum over its groups when there are more than 256 of them: still an upper bound)
+  Cand m = inf;
+  const float gm0 = lt < ngrp ? load_agent(G + lt) : INFINITY, gm1 = lt + 256 < ngrp ? load_agent(G + lt + 256) : INFINITY;   // (kept for the listing pass below)
+  for (int g = lt; g < ngrp; g += 256) {
+    const float v = g == lt ? gm0 : g == lt + 256 ? gm1 : load_agent(G + g);
+    const bool b = v < m.d;
+    m.d = b ? v : m.d; m.r = b ? g : m.r;
+  }
+  m = wave_sort(m, lane);
+  sh[wave * 64 + lane] = m;
+  if (lt == 0) glist[0] = 0;
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < 4; ++w) m = wave_merge_top(m, sh[w * 64 + lane], lane);
+    if (lane == keep - 1) sh[256] = m;                  // (+inf when fewer than `keep` groups hold a finite score: every finite score passes then)
+  }
+  __syncthreads();
+  const float thr = sh[256].d;
+  // ---- the groups with a score at or under the bound, listed (any order: the result is the top of a strict total order)
+  for (int base = wave * 64; base < ngrp; base += 256) {
+    const int g = base + lane;
+    const float gm = g == lt ? gm0 : g == lt + 256 ? gm1 : g < ngrp ? load_agent(G + g) : INFINITY;   // (g = lt + 256 i: the groups of the bound pass)
+    const bool pass = gm < INFINITY && gm <= thr;
+    const unsigned long long bal = __ballot(pass);
+    if (bal) {
+      int pos = 0;
+      if (lane == 0) pos = atomicAdd(glist, __popcll(bal));
+      pos = __shfl(pos, 0);
+      if (pass) glist[1 + pos + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+    }
+  }
+  __syncthreads();
+  const int nel = glist[0] * 32;
+  // ---- their scores: four independent loads per thread and step; compacted per wave, sorted 64 at a time, merged
+  Cand run = inf;
+  Cand* buf = bufs + wave * DENSE_BUF;
+  int cnt = 0;
+  for (int e0 = 0; e0 < nel; e0 += 1024) {
+    Cand c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256 + lt;
+      const bool in = e < nel;
+      c[u].r = in ? glist[1 + (e >> 5)] * 32 + (e & 31) : INT_MAX;
+      c[u].d = in ? load_agent(D + c[u].r) : INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool pass = c[u].d < INFINITY && c[u].d <= thr;
+      const unsigned long long bal = __ballot(pass);
+      if (pass) buf[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c[u];
+      cnt += __popcll(bal);
+      __builtin_amdgcn_wave_barrier();                  // (one wave, in-order LDS: the reads below see the writes above)
+      if (cnt >= 64) {
+        cnt -= 64;
+        const Cand t = buf[cnt + lane];
+        run = wave_merge_top(run, wave_sort(t, lane), lane);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  {
+    const Cand t = lane < cnt ? buf[lane] : inf;
+    run = wave_merge_top(run, wave_sort(t, lane), lane);
+  }
+  __syncthreads();
+  sh[wave * 64 + lane] = run;
+  __syncthreads();
+  if (wave == 0)
+    for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
+  finish_query(p.mp, q, run, sh, lt, store);
+}
+
+template <int METRIC, int TN, int WN>
+__global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void topk_dense_kernel(const TopkDP p) {   // (waves per SIMD: 3 / 2 / 2 workgroups per CU)
+  constexpr int WM = 4, NW = WM * WN, NT = 64 * NW, RB = 32 * WM, QB = 32 * TN * WN, NST = dense_stages(TN * WN);
+  constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = NPIECE / NW, NTAB = (RB / 8) / NW;
+  constexpr int LD = RB + 4;                           // floats per query of the LDS score tile (16-byte aligned rows, spread over the banks)
+  constexpr int NG = NT / 256;                         // 256-thread groups of the finishing phase
+  static_assert(NPIECE % NW == 0 && (RB / 8) % NW == 0 && PPW == NTAB + TN, "every wave issues the same number of LDS-DMA pieces per slab (the counted vmcnt wait relies on it)");
+  static_assert(NST * STAGE >= QB * LD * 4, "the score tile overlays the drained operand ring");
+  constexpr int SCR = (257 + 4 * DENSE_BUF) * 8 + (1 + 2048 + 3) / 4 * 16;   // bytes of finishing scratch per 256-thread group: candidates | list of passing groups (ld / 32 <= 2 048)
+  static_assert(NST * STAGE >= NG * SCR, "the finishing phase's scratch overlays it as well");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xxs = (float*)(smem + NST * STAGE);           // [4][32]: |x|^2 of the wave's 32 rows
+  unsigned* flag = (unsigned*)(xxs + 128);
+  float* gml = xxs + 132;                              // [QB][4]: the waves' minima per query (16-byte aligned)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & (WM - 1), wn = wave / WM;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * QB, part = blockIdx.x;
+  const long long row_begin = (long long)part * RB;
+  const long long row_end = row_begin + RB < p.n_rows ? row_begin + RB : p.n_rows;
+
+  int exclv[TN]; bool qok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int qi = q0 + (wn * TN + j) * 32 + r32;
+    qok[j] = qi < p.nq;
+    exclv[j] = (p.excl && p.group && qok[j]) ? p.excl[qi] : INT_MIN;
+  }
+  // ---- the LDS-DMA stream of topk_mfma_kernel over the row block's slabs (same image, same swizzle, same counted wait)
+  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const float* qptr[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    int qi = q0 + 8 * (wave + NW * i) + (lane >> 3);
+    qi = qi < p.nq ? qi : p.nq - 1;
+    qptr[i] = p.q + (long long)qi * p.dim;
+  }
+  const float* aptr[NTAB];
+#pragma unroll
+  for (int i = 0; i < NTAB; ++i) {
+    long long row = row_begin + 8 * (wave + NW * i) + (lane >> 3);
+    row = row < p.n_rows ? row : p.n_rows - 1;
+    aptr[i] = p.db + row * p.dim;
+  }
+  int d_s = 0;
+  auto issue_piece = [&](auto I, const int stage) {
+    constexpr int i = decltype(I)::value;
+    const int ds = d_s < p.nslab ? d_s : p.nslab - 1;   // (past the end the last slab is re-read into a stage nobody reads again: every iteration issues PPW pieces)
+    const int kk = ds * 32 + chunk * 4;
+    const float* src = i < NTAB ? aptr[i < NTAB ? i : 0] : qptr[i < NTAB ? 0 : i - NTAB];
+    src = kk < p.dim ? src + kk : g_topk_zero + chunk * 4;
+    char* dst = smem + stage * STAGE + ((i < NTAB ? 0 : RB / 8) + wave + NW * (i < NTAB ? i : i - NTAB)) * 1024;
+    glds16(src, dst);
+  };
+  auto issue_phase = [&](auto C, const int stage) {
+    constexpr int c = decltype(C)::value;
+    static_for<PPW>([&](auto I) __attribute__((always_inline)) {
+      if constexpr ((4 * decltype(I)::value) / PPW == c) issue_piece(I, stage);
+    });
+    if constexpr (c == 3) ++d_s;
+  };
+  auto issue_all = [&](const int stage) {
+    issue_phase(std::integral_constant<int, 0>{}, stage); issue_phase(std::integral_constant<int, 1>{}, stage);
+    issue_phase(std::integral_constant<int, 2>{}, stage); issue_phase(std::integral_constant<int, 3>{}, stage);
+  };
+  f32x16 acc[TN];
+  float qq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    qq[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  }
+  float xx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue_all(i);
+  int stg = 0;
+  for (int it = 0; it < p.nslab; ++it) {
+    // (the invariant of topk_mfma_kernel's counted wait holds here as well: no other vector-memory operation between a slab's pieces and this wait)
+#ifdef MRAG_DIAG_VMCNT0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (NST - 2)) : "memory");
+#endif
+    __syncthreads();
+    const int nstage = stg == 0 ? NST - 1 : stg - 1;
+    const char* st = smem + stg * STAGE;
+    stg = stg + 1 == NST ? 0 : stg + 1;
+    const char* arow = st + (wm * 32 + r32) * 128;
+    const char* qrow = st + (RB + wn * TN * 32 + r32) * 128;
+    const int sw = (r32 >> 1) & 7;
+    static_for<4>([&](auto C) __attribute__((always_inline)) {
+      constexpr int c = decltype(C)::value;
+      const int off = ((2 * c + h) ^ sw) * 16;
+      const f32x4 a4 = *(const f32x4*)(arow + off);
+      f32x4 b4[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b4[j] = *(const f32x4*)(qrow + j * 32 * 128 + off);
+      if constexpr (METRIC == 0) {                     // the half-block chains of |x|^2 (this lane's row) and |q|^2 (this lane's query of every tile)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xx = __builtin_fmaf(a4[t], a4[t], xx);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) qq[j] = __builtin_fmaf(b4[j][t], b4[j][t], qq[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[j][0], acc[j], 0, 0, 0);
+      issue_phase(C, nstage);
+#pragma unroll
+      for (int t = 1; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
+    });
+  }
+  // ---- first scores of the row block
+  if constexpr (METRIC == 0) {
+    const float xf = xx + __shfl_xor(xx, 32);          // the two half-row chains, added once (either lane: the same two addends)
+    if (h == 0 && wn == 0) xxs[wm * 32 + r32] = xf;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) qq[j] = qq[j] + __shfl_xor(qq[j], 32);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's last (redundant) slabs have landed: the stages are free for the score tile
+  __syncthreads();
+  const long long blk_row0 = row_begin + wm * 32;
+  int gid[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) gid[reg] = INT_MIN + 1;
+  if (p.group) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long long grow = blk_row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      gid[reg] = p.group[grow < row_end ? grow : row_end - 1];
+    }
+  }
+  float* tile = (float*)smem;                          // [QB][LD]
+  float mn[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) mn[j] = INFINITY;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int qn = (wn * TN + j) * 32 + r32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int reg = 4 * g4 + e, i = e + 8 * g4 + 4 * h;
+        const bool valid = blk_row0 + i < row_end;
+        const float xi = METRIC == 0 ? xxs[wm * 32 + i] : 0.f;
+        const float dot = acc[j][reg];
+        const float d = METRIC == 0 ? __builtin_fmaf(-2.0f, dot, qq[j] + xi) : 1.0f - dot;
+        o[e] = (valid && qok[j] && d <= INFINITY && gid[reg] != exclv[j]) ? d : INFINITY;   // (NaN scores drop out: the compare is false)
+      }
+      *(f32x4*)(tile + qn * LD + wm * 32 + 8 * g4 + 4 * h) = o;
+      mn[j] = fminf(fminf(mn[j], fminf(o[0], o[1])), fminf(o[2], o[3]));
+    }
+    mn[j] = fminf(mn[j], __shfl_xor(mn[j], 32));
+    if (h == 0) gml[qn * 4 + wm] = mn[j];
+  }
+  __syncthreads();
+  if (tid < QB && q0 + tid < p.nq) store_agent_x4(p.gmin + ((long long)(q0 + tid) * (p.ld >> 5) + part * 4), *(const f32x4*)(gml + tid * 4));
+  for (int idx = tid; idx < QB * (RB / 4); idx += NT) {
+    const int qn = idx / (RB / 4), c4 = idx % (RB / 4);
+    if (q0 + qn < p.nq) store_agent_x4(p.dist + (long long)(q0 + qn) * p.ld + row_begin + c4 * 4, *(const f32x4*)(tile + qn * LD + c4 * 4));
+  }
+#if defined(MRAG_TOPK_DENSE_DIAG) && MRAG_TOPK_DENSE_DIAG == 1   // developer timing build: the stream + the dense stores alone (results are NOT produced)
+  return;
+#endif
+  // ---- arrive; wait (bounded) until the grid has arrived; finish the queries of this workgroup's arrival ticket.
+  // Words (the workspace's zeroed first 64 bytes, words 8..14): seq | set 0 {arrivals, go, claims} | set 1 {..}.  A call uses set (seq & 1); its last arriver
+  // zeroes the OTHER set, publishes `go` and bumps seq, so nothing is reset behind anybody's back and no exit counter is needed (a third same-address atomic
+  // per workgroup).  The waiters poll `go`, not the arrival counter (632 pollers on the word the late arrivers still have to increment cost 55 us).
+  //   go = 1: every workgroup is here -> STATIC shares: arrival ticket t finishes queries t, t + total, .. (no claim traffic);
+  //   go = 2: somebody gave up waiting (it added 0x10000 to the arrival word before it left, so the last arriver -- whose own increment returns the word --
+  //           cannot miss it) -> the workgroups that are here CLAIM queries from the set's third word; the last arriver is always among them.
+  //   A workgroup that gives up and learns from its own 0x10000 increment that everybody HAS arrived meanwhile stays: `go` is already on its way.
+  // Hand-off: agent-coherent (write-through) stores of the scores -> every wave waits for their acknowledgements -> barrier -> one lane: relaxed agent
+  // fetch_add; waiters: relaxed agent loads of `go`, barrier, agent-coherent loads of the scores (store_agent_x4 / load_agent above: no L2-wide fences).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned seq = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* set = p.sync + 1 + 3 * (seq & 1u);
+    unsigned* other = p.sync + 1 + 3 * ((seq & 1u) ^ 1u);
+#ifdef MRAG_TOPK_DENSE_FENCES   // developer A/B build: the fences of the textbook hand-off on top of the write-through stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    const unsigned ret = __hip_atomic_fetch_add(set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = ret & 0xffffu;
+    unsigned mode = 0;
+    if (ticket + 1u == (unsigned)p.total) {
+#ifdef MRAG_TOPK_DENSE_FENCES
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+#endif
+      mode = (ret >> 16) ? 2u : 1u;
+      __hip_atomic_store(other + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(other + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(other + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(set + 1, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.sync, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (int spin = 0; spin < p.spin_limit && !mode; ++spin) {
+        __builtin_amdgcn_s_sleep(MRAG_TOPK_DENSE_SLEEP);
+        mode = __hip_atomic_load(set + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!mode) {
+        const unsigned r2 = __hip_atomic_fetch_add(set, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((r2 & 0xffffu) == (unsigned)p.total)
+          do {
+            __builtin_amdgcn_s_sleep(MRAG_TOPK_DENSE_SLEEP);
+            mode = __hip_atomic_load(set + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while (!mode);
+      }
+    }
+#ifdef MRAG_TOPK_DENSE_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    flag[0] = mode; flag[1] = ticket; flag[2] = seq & 1u;
+  }
+  __syncthreads();
+  const unsigned mode = flag[0], ticket = flag[1];
+  unsigned* claims = p.sync + 1 + 3 * flag[2] + 2;
+  __syncthreads();
+#if defined(MRAG_TOPK_DENSE_DIAG) && MRAG_TOPK_DENSE_DIAG == 2   // developer timing build: ... + the grid wait, no finishing phase
+  return;
+#endif
+  if (mode == 0) return;
+  Cand* sh = (Cand*)(smem + (tid >> 8) * SCR);
+  Cand* bufs = sh + 257;
+  int* glist = (int*)(bufs + 4 * DENSE_BUF);
+  if (mode == 1) {
+    for (long long idx = ticket; idx * NG < p.nq; idx += p.total) {
+      const int q = (int)idx * NG + (tid >> 8);
+      dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist);
+    }
+    return;
+  }
+  for (;;) {
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(claims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned claim = flag[0];
+    __syncthreads();
+    if ((long long)claim * NG >= p.nq) break;
+    const int q = (int)claim * NG + (tid >> 8);
+    dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist);
+  }
+}
+
 // the fan-out plan: queries per workgroup (32 TN), parts (workgroups along the table), rows per part
 struct MfmaPlan { int TN, WN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
 inline MfmaPlan plan_mfma(long long n_rows, int nq) {
@@ -852,6 +1249,44 @@ inline MfmaPlan plan_mfma(long long n_rows, int nq) {
 }
 
 inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 && dim % 4 == 0; }
+
+// the one-launch plan: the smallest query tile whose grid fits ONE resident round (checked against the runtime's occupancy at launch: dense_launch)
+struct DensePlan { bool ok; int TN, WN, QB, gy, parts, ld; size_t lds, bytes; };
+inline size_t dense_lds(int tn, int wn) {
+  return (size_t)dense_stages(tn * wn) * (128 + 32 * tn * wn) * 128 + 132 * sizeof(float) + (size_t)32 * tn * wn * 4 * sizeof(float);   // ring | |x|^2, flag | group minima
+}
+inline DensePlan plan_dense(long long n_rows, int nq, int dim = 768) {
+  DensePlan pl{};
+  const int qtiles = (nq + 31) / 32;
+  const long long blocks = (n_rows + 127) / 128;
+  if (blocks > 512 || (long long)nq * blocks * 128 > (16LL << 20)) return pl;          // (<= 64 MB of first scores)
+  // Tile = the cheapest of (TN, WN) = 32 queries on four waves, 64 on eight / four, 128 on eight under a two-term model measured at 10 000 x 256 x 768
+  // (profiles/r6_topk_one_launch.txt): the busiest CU's MFMA time -- workgroups per CU x 32-query tiles per workgroup x 0.49 us per 32-feature slab -- plus the
+  // arrivals at the grid wait, which are same-address atomics and serialise at ~0.045 us each (632 workgroups of 32 queries: 35 + 28 us; 158 of 128: 47 + 7).
+  // Small tables take the small tiles (4 000 x 256: 256 workgroups of one tile), BASELINE config #1's takes 128 queries per workgroup.
+#ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 12, 21, 22 = TN WN of every plan
+  const int cand[1][2] = {{MRAG_TOPK_DENSE_TILE / 10, MRAG_TOPK_DENSE_TILE % 10}};
+#else
+  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+#endif
+  double best = 0;
+  for (const auto& c : cand) {
+    const int tiles = c[0] * c[1], qb = 32 * tiles, gy = (nq + qb - 1) / qb;
+    const int cap = tiles == 1 ? 3 : tiles == 2 ? 2 : 1;                                // (the kernels' launch bounds: workgroups per CU)
+    int per_cu = (int)((160 * 1024) / dense_lds(c[0], c[1]));
+    per_cu = per_cu > cap ? cap : per_cu;
+    if (qb > 32 * qtiles && qb > 32) continue;                                         // (a tile wider than the batch)
+    const long long wgs = blocks * gy;
+    if (wgs > 256LL * per_cu) continue;
+    const double t = (double)((wgs + 255) / 256) * tiles * ((dim + 31) / 32) * 0.49 + 0.045 * (double)wgs;
+    if (pl.ok && t >= best) continue;
+    best = t;
+    pl.ok = true; pl.TN = c[0]; pl.WN = c[1]; pl.QB = qb; pl.gy = gy; pl.parts = (int)blocks; pl.ld = (int)blocks * 128;
+    pl.lds = dense_lds(c[0], c[1]);
+    pl.bytes = (size_t)nq * pl.ld * sizeof(float) + (size_t)nq * (pl.ld / 32) * sizeof(float);     // first scores | group minima (the same for every tile)
+  }
+  return pl;
+}
 // `order = 0` (automatic) takes the fan-out form whenever it applies.  Measured on MI355X (tools/topk_sizes.py, k = 12, D = 768; fan-out / scan kernel):
 // 1 000 rows x 256 queries 94 / 164 us, 10 000 x 256 140 / 228 us, 10^5 x 256 0.59 / 2.0 ms, 10^6 x 256 3.8 / 17.2 ms; 10 000 x 16 90 / 158 us
 // (profiles/r5_topk_fanout_vs_scan_by_size.txt).  (Until the |q|^2 pre-pass became a wave per query -- it took 91 us as a thread per query -- the two forms were
@@ -895,7 +1330,9 @@ extern "C" int64_t mrag_topk_workspace_bytes(int64_t n_rows, int32_t n_queries) 
   plan(n_rows, n_queries, &slices, &rps);
   const int64_t scan = kTicketBytes + (int64_t)n_queries * slices * 4 * 64 * (int64_t)sizeof(Cand);
   const int64_t fan = n_queries >= 16 ? kTicketBytes + (int64_t)plan_mfma(n_rows, n_queries).bytes : 0;   // either form fits (the `order` argument picks one)
-  return scan > fan ? scan : fan;
+  const int64_t dense = n_queries >= 16 ? kTicketBytes + (int64_t)plan_dense(n_rows, n_queries).bytes : 0;  // (0 bytes when the one-launch plan does not apply)
+  const int64_t m = scan > fan ? scan : fan;
+  return m > dense ? m : dense;
 }
 
 extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group, int64_t n_rows, int32_t dim, const float* queries,
@@ -919,13 +1356,52 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
   p.wpb = 4;
   const bool small = small_db(n_rows, n_queries);
   hipStream_t s = (hipStream_t)stream;
-  if (order < 0 || order > 2) return MRAG_EINVAL;
-  if (order == 2 && !mfma_applies(n_queries, k, dim)) return MRAG_ENOTSUP;
-  if (order == 2 || (order == 0 && mfma_auto(n_rows, n_queries, k, dim))) {
+  if (order < 0 || order > 4) return MRAG_EINVAL;
+  if (order >= 2 && !mfma_applies(n_queries, k, dim)) return MRAG_ENOTSUP;
+  if (order >= 2 || (order == 0 && mfma_auto(n_rows, n_queries, k, dim))) {
+    // ---- the fan-out form in ONE launch: tables whose grid is resident at once (order 3 = never, order 4 = this form without waiting: diagnostics)
+    if (order != 3) {
+      const DensePlan dp = plan_dense(n_rows, n_queries, dim);
+      TopkDP d{};
+      d.db = db; d.group = p.group; d.q = queries; d.excl = exclude; d.n_rows = n_rows; d.dim = dim; d.nq = n_queries; d.nslab = (dim + 31) / 32;
+      d.dist = (float*)((char*)workspace + kTicketBytes); d.sync = (unsigned*)workspace + 8;
+      d.gmin = d.dist + (size_t)n_queries * dp.ld;
+      d.ld = dp.ld; d.total = dp.parts * dp.gy;
+      d.spin_limit = order == 4 ? 0 : 40000;                // x ~1 us of s_sleep: a workgroup that has not seen the grid arrive by then leaves (the last arriver finishes alone)
+      d.mp = p; d.mp.rescore = metric == 0 ? 1 : 0;
+      int done = 0;
+#define MRAG_TOPK_DENSE(M, T, W)                                                                                              \
+      if (dp.ok && !done && metric == M && dp.TN == T && dp.WN == W) {                                                         \
+        auto kfn = topk_dense_kernel<M, T, W>;                                                                                  \
+        static int occ = -1;                                                                                                    \
+        if (occ < 0) {                                                                                                          \
+          hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp.lds);       \
+          if (e != hipSuccess) return (int)e;                                                                                  \
+          int o = 0;                                                                                                            \
+          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)kfn, 256 * W, dp.lds);                             \
+          if (e != hipSuccess) return (int)e;                                                                                  \
+          occ = o;                                                                                                              \
+        }                                                                                                                       \
+        if ((long long)d.total <= 256LL * occ) {               /* the whole grid is resident at once: the wait is safe */        \
+          MRAG_LAUNCH(kfn, dim3(dp.parts, dp.gy), dim3(256 * W), dp.lds, s, d);                                                 \
+          done = 1;                                                                                                             \
+        }                                                                                                                       \
+      }
+      MRAG_TOPK_DENSE(0, 1, 1) MRAG_TOPK_DENSE(0, 1, 2) MRAG_TOPK_DENSE(0, 2, 1) MRAG_TOPK_DENSE(0, 2, 2)
+      MRAG_TOPK_DENSE(1, 1, 1) MRAG_TOPK_DENSE(1, 1, 2) MRAG_TOPK_DENSE(1, 2, 1) MRAG_TOPK_DENSE(1, 2, 2)
+#undef MRAG_TOPK_DENSE
+      if (done) {
+        MRAG_LAUNCH_CHECK();
+        MRAG_COUNT(MRAG_K_TOPK_DENSE);
+        return MRAG_OK;
+      }
+      if (order == 4) return MRAG_ENOTSUP;
+    }
     // ---- the fan-out form: one fp32 MFMA pass over the table per 256 queries
     const MfmaPlan pl = plan_mfma(n_rows, n_queries);
     TopkMP m{};
-    m.db = db; m.group = p.group; m.q = queries; m.excl = exclude; m.n_rows = n_rows; m.dim = dim; m.nq = n_queries; m.k = k;
+    m.db = db; m.group = p.group; m.q = queries; m.excl = exclude; m.n_rows = n_rows; m.dim = dim; m.nq = n_queries;
+    m.k = metric == 0 ? 16 : k;      // "l2": the second scoring takes the 16 nearest under the first score, so the lists (and their thresholds) are 16 deep
     m.nparts = pl.parts; m.rows_per_part = pl.rows_per_part; m.nslab = (dim + 31) / 32;
     const size_t qbytes = ((size_t)n_queries * sizeof(float) + 255) / 256 * 256;
     float* qq = (float*)((char*)workspace + kTicketBytes);

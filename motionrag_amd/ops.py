@@ -624,7 +624,7 @@ def topk_workspace(device: torch.device, N: int, Q: int) -> torch.Tensor:
     return ws
 
 
-TOPK_ORDER = {"auto": 0, "chain16": 1, "mfma": 2}
+TOPK_ORDER = {"auto": 0, "chain16": 1, "mfma": 2, "mfma_stream": 3, "mfma_nowait": 4}   # 3 / 4: the fan-out form's two launch shapes forced (diagnostics; include/mrag_hip.h)
 
 
 def topk(db: torch.Tensor, queries: torch.Tensor, k: int, *, metric: str = "l2", group: Optional[torch.Tensor] = None,

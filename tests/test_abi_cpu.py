@@ -24,6 +24,10 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.mrag_abi_version() == _lib.ABI_VERSION and lib.mrag_target_arch() == b"gfx950"
     assert lib.mrag_topk_workspace_bytes(10000, 256) > 0
+    # the fan-out form's ONE-launch plan (tables of one resident round of workgroups) keeps every (query, row) first score + the 32-row groups' minima in the
+    # workspace: BASELINE config #1's table = 79 row blocks of 128 -> 256 x 10 112 scores + 256 x 316 minima behind the 64 counter bytes; a 10^6-row table streams
+    assert lib.mrag_topk_workspace_bytes(10000, 256) >= 64 + 256 * 10112 * 4 + 256 * 316 * 4
+    assert lib.mrag_topk_workspace_bytes(1000000, 256) < 256 * 1000000 * 4
 
 
 def test_struct_layouts_match_the_header():

@@ -696,7 +696,7 @@ def test_topk_bit_exact(hip, metric, N, Q, D, k):
         with ops.dispatched() as d:
             rows, dist = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric,
                                   group=torch.from_numpy(group).to(DEV), exclude=torch.from_numpy(excl).to(DEV), order=order)
-        assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+        assert ("TOPK_DENSE" in d.counts) == (mode == "f32mfma") and "TOPK_MFMA" not in d.counts, (order, d.counts)   # (tables of one resident round: the fan-out form's ONE-launch shape)
         np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
         np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))      # same fmaf chain -> same bits
         rows2, _ = ops.topk(torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV), k, metric=metric, order=order)
@@ -729,7 +729,7 @@ def test_topk_filter_order_bit_exact(hip, metric, Q):
             want_r, want_d = topk_ref.topk(db, q, 12, metric, group, own, mode=mode, postfilter=post)
             with ops.dispatched() as d:
                 rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post, order=order)
-            assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+            assert ("TOPK_DENSE" in d.counts) == (mode == "f32mfma") and "TOPK_MFMA" not in d.counts, (order, d.counts)
             np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
             np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
         lists[post] = rows.cpu().numpy()
@@ -774,10 +774,12 @@ def test_topk_baseline_size(hip):
     q[:64] = db[excl[:64]] + 0.01 * q[:64]                                   # queries whose own row must be filtered out
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
     # "auto" = the fan-out kernel (ONE pass over the table, oracle mode f32mfma); order="chain16" = the scan kernel, 16 passes of 16 queries (mode f32chain)
-    for order, mode in (("auto", "f32mfma"), ("chain16", "f32chain"), ("mfma", "f32mfma")):
+    for order, mode in (("auto", "f32mfma"), ("chain16", "f32chain"), ("mfma", "f32mfma"), ("mfma_stream", "f32mfma"), ("mfma_nowait", "f32mfma")):
         with ops.dispatched() as d:
             rows, dist = ops.topk(dbd, qd, 12, metric="l2", group=gd, exclude=ed, order=order)
-        assert ("TOPK_MFMA" in d.counts) == (mode == "f32mfma"), (order, d.counts)
+        # the fan-out form: ONE launch at this size ("mfma_stream" forces its three-launch shape, "mfma_nowait" the one launch without the grid wait: the same defined result)
+        want = {"TOPK_SCAN": 1, "TOPK_MERGE": 1} if mode == "f32chain" else {"TOPK_MFMA": 1, "TOPK_MERGE": 1} if order == "mfma_stream" else {"TOPK_DENSE": 1}
+        assert d.counts == want, (order, d.counts)
         rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
         want_r, want_d = topk_ref.topk(db, q, 12, "l2", group, excl, mode=mode)
         np.testing.assert_array_equal(rows, want_r)
@@ -801,17 +803,22 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     excl = group[rng.integers(0, N, Q)].astype(np.int32)
     q[: Q // 4] = db[(2 * excl[: Q // 4])] + 0.01 * q[: Q // 4]                   # queries next to a row of the excluded video
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
+    one_launch = N <= 65536                                                       # (a table of one resident round of workgroups: topk.hip plan_dense)
     for post in (False, True):
         want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32mfma", postfilter=post)
-        with ops.dispatched() as d:
-            rows, dist = ops.topk(dbd, qd, k, metric=metric, group=gd, exclude=ed, postfilter=post, order="mfma")
-        assert d.counts.get("TOPK_MFMA", 0) == 1 and "TOPK_SCAN" not in d.counts, d.counts
-        np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
-        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
+        # "mfma": the shape the plan picks; "mfma_stream": pre-pass + streaming kernel + merge launch; "mfma_nowait": ONE launch whose workgroups do not wait
+        # for each other (the last arriver finishes every query: the bounded wait's fall-back) -- the same defined result from all three
+        for order in ("mfma", "mfma_stream") + (("mfma_nowait",) if one_launch else ()):
+            with ops.dispatched() as d:
+                rows, dist = ops.topk(dbd, qd, k, metric=metric, group=gd, exclude=ed, postfilter=post, order=order)
+            dense = one_launch and order != "mfma_stream"
+            assert d.counts == ({"TOPK_DENSE": 1} if dense else {"TOPK_MFMA": 1, "TOPK_MERGE": 1}), (order, d.counts)
+            np.testing.assert_array_equal(rows.cpu().numpy(), want_r, err_msg=order)
+            np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32), err_msg=order)
     want_r, want_d = topk_ref.topk(db, q, k, metric, mode="f32mfma")
     with ops.dispatched() as d:
-        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out kernel wherever it applies
-    assert "TOPK_MFMA" in d.counts and "TOPK_SCAN" not in d.counts, d.counts
+        rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out form wherever it applies
+    assert ("TOPK_DENSE" in d.counts) == one_launch and ("TOPK_MFMA" in d.counts) != one_launch and "TOPK_SCAN" not in d.counts, d.counts
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 

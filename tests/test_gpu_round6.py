@@ -289,7 +289,9 @@ def test_topk_fanout_l2_distances_are_the_scan_forms(hip):
     dbd, qd = torch.from_numpy(db).to(DEV), torch.from_numpy(q).to(DEV)
     with ops.dispatched() as d:
         rows, dist = ops.topk(dbd, qd, 12)
-    assert "TOPK_MFMA" in d.counts, d.counts
+    assert d.counts == {"TOPK_DENSE": 1}, d.counts
+    rs, ds = ops.topk(dbd, qd, 12, order="mfma_stream")                        # the streaming shape of the fan-out form: the same rows and bits
+    assert torch.equal(rs, rows) and torch.equal(ds, dist)
     rows, dist = rows.cpu().numpy(), dist.cpu().numpy()
     assert np.all(dist[:, 0] == 0.0) and np.all(rows[:, 0] == np.arange(32)) and np.all(dist >= 0.0)
     wr, wd = topk_ref.topk(db, q, 12, "l2", mode="f32mfma")

@@ -491,9 +491,23 @@ def copy_probe():
 def topk_small():
     """the fan-out kernel at BASELINE config #1's table size (10 000 rows) x 256 queries, for a kernel trace (tools/prof.sh topk_small)"""
     db = torch.randn(10000, 768, device=DEV); q = torch.randn(256, 768, device=DEV)
-    for order in ("mfma", "chain16"):
+    for order in ("mfma", "mfma_stream", "chain16"):
         dt = timeit(lambda: ops.topk(db, q, 12, order=order), iters=50, warm=5)
         print(f"topk 10000 x 256 order {order}: {dt*1e6:.1f} us")
+
+
+def topk_sizes():
+    """the fan-out form's two launch shapes over table sizes and batch widths (one launch: tables of one resident round; streaming: three launches)"""
+    for N, Q in ((1000, 256), (4000, 256), (10000, 256), (10000, 64), (10000, 16), (20000, 256), (40000, 128), (65536, 64), (1000000, 256)):
+        db = torch.randn(N, 768, device=DEV); q = torch.randn(Q, 768, device=DEV)
+        line = f"topk N={N} Q={Q}:"
+        for order in ("mfma", "mfma_stream"):
+            with ops.dispatched() as d:
+                ops.topk(db, q, 12, order=order)
+            dt = timeit(lambda: ops.topk(db, q, 12, order=order), iters=30 if N < 100000 else 5, warm=5)
+            line += f"  {order} {dt*1e6:.1f} us ({'+'.join(sorted(d.counts))})"
+        print(line)
+        del db, q
 
 
 if __name__ == "__main__":

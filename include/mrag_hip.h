@@ -87,6 +87,7 @@ enum mrag_kernel_id {
   MRAG_K_GEMM_W4_BATCHED_W,    /* gemm_w4_kernel<NONE, true>: per-sample weights (w_batch_stride) */
   MRAG_K_GEMM_SKINNY_LNA,      /* gemm_skinny_kernel<.., LNA>: LayerNorm of the A rows fused into the few-row GEMM's A load */
   MRAG_K_TOPK_DENSE,           /* topk_dense_kernel: the fan-out search in ONE launch (tables whose grid is resident at once: dense first scores, bounded grid wait, claimed finishing) */
+  MRAG_K_TOPK_DENSE_FINISH,    /* topk_dense_finish_kernel: the finishing phase as its own launch (tables whose dense grid is not resident at once) */
   MRAG_K_GEMM_SKINNY,          /* gemm_skinny_kernel: M <= 256 (CAMA's latents / encoder tokens, the query embedder): eight waves split K, no LDS ring */
   MRAG_K_COUNT
 };
@@ -520,10 +521,11 @@ int mrag_cfg_dpm_step_bf16(void* stream, const void* v_pred, void* latents, void
 /*       for bit, whatever the call shape (round 6; mode 2 of the oracle restates */
 /*       selection + second scoring).  "dot": 1 - chain, no second scoring.       */
 /*       n_queries >= 16, k <= 16, else MRAG_ENOTSUP;                            */
-/*       Tables of one resident round of workgroups (<= 65 536 rows; 10 000 x 256: BASELINE config #1) run it as ONE launch: the first scores of
- *       every (query, row) leave as a dense matrix in the workspace, every workgroup waits -- bounded -- until the grid has arrived, and the
- *       workgroups then claim queries and finish them (16 nearest under the first score, second scoring, filter order).  Larger tables stream: a
- *       |q|^2 pre-pass, the fan-out kernel with in-kernel lists, a merge launch.  Both compute the SAME defined result.
+/*       Tables of one resident round of workgroups (10 000 x 256: BASELINE config #1) run it as ONE launch: the first scores of every (query,
+ *       row) leave as a dense matrix in the workspace, every workgroup waits -- bounded -- until the grid has arrived, and the workgroups then
+ *       finish the queries (16 nearest under the first score, second scoring, filter order).  Tables up to 65 536 rows / 64 MB of first scores
+ *       whose grid is not resident at once do the same in TWO launches (no wait).  Larger tables stream: a |q|^2 pre-pass, the fan-out kernel
+ *       with in-kernel lists, a merge launch.  All three compute the SAME defined result.
  *   3 = order 2, streaming (three-launch) form forced;   4 = order 2, one-launch form forced (MRAG_ENOTSUP where its plan does not apply) and
  *       WITHOUT waiting: every workgroup but the last arriver leaves at once and the last one finishes every query -- diagnostics of the two forms'
  *       equality and of the bounded wait's fall-back.                                                                                             */

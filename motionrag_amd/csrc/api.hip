@@ -28,7 +28,7 @@ extern "C" const char* mrag_dispatch_name(int32_t id) {
       "CONVT_W4", "CONVT_256x256", "CONVT_256x320", "CONVT_128x128", "CONVT_192x256", "CONVT_256x128",
       "ATTN16", "ATTN16_KSPLIT", "ATTN_FLASH", "ATTN_FLASH_KSPLIT", "ATTN_COMBINE", "ATTN_TINY", "ATTN_SMALL", "ATTN_FP8", "IP_ATTN_FOLDED",
       "LAYERNORM", "LAYERNORM_ROWS", "QKNORM_ROPE", "GN_STATS", "GN_FOLD", "GN_APPLY", "GN_APPLY_MOD", "LAYERNORM_STREAM", "GN_STATS_FOLD",
-      "TOPK_SCAN", "TOPK_SCAN_FUSED_MERGE", "TOPK_MERGE", "TOPK_MFMA", "GEMM_W4_TAIL_RECT", "GEMM_W4_BATCHED_W", "GEMM_SKINNY_LNA", "TOPK_DENSE", "GEMM_SKINNY"};
+      "TOPK_SCAN", "TOPK_SCAN_FUSED_MERGE", "TOPK_MERGE", "TOPK_MFMA", "GEMM_W4_TAIL_RECT", "GEMM_W4_BATCHED_W", "GEMM_SKINNY_LNA", "TOPK_DENSE", "TOPK_DENSE_FINISH", "GEMM_SKINNY"};
   static_assert(sizeof(names) / sizeof(names[0]) == MRAG_K_COUNT, "one name per enum mrag_kernel_id");
   return (id >= 0 && id < (int)MRAG_K_COUNT) ? names[id] : nullptr;
 }

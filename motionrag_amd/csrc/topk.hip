@@ -40,6 +40,23 @@ struct Cand { float d; int r; };
 
 __device__ __forceinline__ bool cand_less(const Cand a, const Cand b) { return a.d < b.d || (a.d == b.d && a.r < b.r); }
 
+// rank of this lane's candidate among the candidates of lanes 0 .. n - 1 (n wave-uniform): the number of them that come before it in the strict order
+// (distance, row).  Lane j's candidate reaches every lane through v_readlane (an SGPR broadcast) as ONE 64-bit key -- the order-preserving image of the
+// distance (float_key below; -0 counted as +0, as cand_less does) over the row -- so a step is two readlanes, one 64-bit compare and an add: n short steps
+// without memory.  (A 64-lane bitonic network is 21 dependent shuffle stages; counting over an LDS array exposed one LDS round trip per element.)
+__device__ __forceinline__ int cand_rank(const Cand c, const int n) {
+  const unsigned u = __float_as_uint(c.d + 0.0f);
+  const unsigned long long kc = ((unsigned long long)((u & 0x80000000u) ? ~u : (u | 0x80000000u)) << 32) | (unsigned)c.r;
+  const int klo = (int)(unsigned)kc, khi = (int)(unsigned)(kc >> 32);
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long ko = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(khi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, j);
+    rank += ko < kc ? 1 : 0;
+  }
+  return rank;
+}
+
 __device__ __forceinline__ Cand cand_shfl_xor(const Cand c, int m) {
   Cand o; o.d = __shfl_xor(c.d, m); o.r = __shfl_xor(c.r, m); return o;
 }
@@ -368,9 +385,15 @@ __device__ __forceinline__ void finish_query(const TopkP& p, const int q, Cand r
     __syncthreads();
     if (s16 == 0 && cc.r != INT_MAX) sh[c].d = acc;
     __syncthreads();
-    if (wave == 0) {
-      run = lane < 16 ? sh[lane] : inf;
-      run = wave_sort(run, lane);
+    if (wave == 0) {                                        // re-rank the (up to) 16 by counting: sh[0..15] -> sh[64..79]
+      const Cand c = lane < 16 ? sh[lane] : inf;
+      const bool have = c.r != INT_MAX;
+      const int rank = cand_rank(c, 16);
+      if (lane < 16) sh[64 + lane] = inf;
+      __builtin_amdgcn_wave_barrier();
+      if (have) sh[64 + rank] = c;
+      __builtin_amdgcn_wave_barrier();
+      run = lane < 16 ? sh[64 + lane] : inf;
     }
   }
   if (wave == 0 && store) {
@@ -857,6 +880,18 @@ __device__ __forceinline__ void store_agent_x4(float* ptr, const f32x4 v) {
 }
 __device__ __forceinline__ float load_agent(const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifdef MRAG_TOPK_DIAG_STATS   // developer timing build of the one-launch form: sums (and maxima) of phase durations in s_memtime ticks -- tools/topk_diag.py names them
+__device__ unsigned long long g_topk_dense_dbg[24];
+extern "C" int mrag_debug_topk_dense_stats(unsigned long long* out_host, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_topk_dense_dbg), sizeof(g_topk_dense_dbg));
+  if (e == hipSuccess && reset) { unsigned long long z[24] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_topk_dense_dbg), z, sizeof(z)); }
+  return (int)e;
+}
+#define MRAG_DSTAMP(T) do { if (threadIdx.x == 0) MRAG_TSTAMP(T); } while (0)
+#else
+#define MRAG_DSTAMP(T) do { } while (0)
+#endif
+
 struct TopkDP {
   const float* db; const int* group; const float* q; const int* excl;
   float* dist;            // [nq][ld] first scores
@@ -871,70 +906,139 @@ constexpr int dense_stages(int tiles) { return tiles == 1 ? 2 : 3; }   // 32 que
 #define MRAG_TOPK_DENSE_SLEEP 32     // x 64 cycles between two looks at the `go` word (~1 us)
 #endif
 constexpr int DENSE_BUF = 128;      // per-wave compaction buffer of the finishing phase: < 64 left over + <= 64 new candidates per step
+constexpr int DENSE_SCR = ((257 + 4 * DENSE_BUF) * 8 + (2 + 2048 + 2 + 2048) * 4 + 15) / 16 * 16;   // bytes of finishing scratch per 256-thread group: candidates | 2 counters, list of passing groups | the group minima (ld / 32 <= 2 048)
 
 // finish query q from the dense first scores: one 256-thread group (lt = 0..255); scratch `sh` (257 candidates), `bufs` (4 x DENSE_BUF candidates) and
-// `glist` (1 + ld / 32 ints).  The 32-row groups' minima bound the answer (the keep-th smallest minimum: `keep` groups hold a score at or under it, so the
-// keep-th nearest row does too); only the groups whose minimum passes the bound are read at all -- about `keep` runs of 128 bytes out of the query's 40 KB at
-// 10 000 rows -- and ALL of them at once: the passing groups are listed first, then every thread loads its elements of the list (one memory round trip; the
-// first form walked the groups two at a time, a dependent load each: 18 us per query).
-__device__ __forceinline__ void dense_select(const TopkDP& p, const int q, const bool store, const int lt, Cand* sh, Cand* bufs, int* glist) {
+// `ctr` (2 + ld / 32 ints: listed groups, surviving scores, the list).  The 32-row groups' minima bound the answer (the keep-th smallest of the lanes'
+// minima: `keep` groups hold a score at or under it, so the keep-th nearest row does too); only the groups whose minimum passes the bound are read at all --
+// about `keep` runs of 128 bytes out of the query's 40 KB at 10 000 rows -- and ALL of them at once: the passing groups are listed first, then every thread
+// loads its elements of the list (one memory round trip; the first form walked the groups two at a time, a dependent load each: 18 us per query).  The
+// scores at or under the bound (about `keep` again) meet in one LDS array and are ordered by counting ranks.
+__device__ __forceinline__ void dense_select(const TopkDP& p, const int q, const bool store, const int lt, Cand* sh, Cand* bufs, int* ctr, unsigned long long* dacc) {
+  (void)dacc;
+  constexpr int CAP = 4 * DENSE_BUF;
   const int lane = lt & 63, wave = lt >> 6;
   const int ngrp = p.ld >> 5;
   const float* D = p.dist + (long long)q * p.ld;
   const float* G = p.gmin + (long long)q * ngrp;
   const int keep = p.mp.rescore ? 16 : p.mp.k;
+  int* glist = ctr + 2;
+  float* gsh = (float*)(glist + 2048 + 2);              // [ngrp]: the query's group minima, loaded ONCE by the 256 threads (two loads in flight each)
   Cand inf; inf.d = INFINITY; inf.r = INT_MAX;
-  // ---- the bound (a thread's minimum over its groups when there are more than 256 of them: still an upper bound)
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+  (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5;
+  MRAG_DSTAMP(a0);
+  if (lt < 2) ctr[lt] = 0;
+  // (every wave loading all of the minima for itself -- 8 waves x 128 workgroups x 5 uncached loads on 323 KB, i.e. on a handful of memory channels -- made
+  // this first access after the wait 5 us)
+  for (int g0 = 0; g0 < ngrp; g0 += 512) {
+    float gv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = g0 + u * 256 + lt;
+      const float* a = G + (g < ngrp ? g : 0);
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(gv[u]) : "v"(a) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv[0]), "+v"(gv[1]) :: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = g0 + u * 256 + lt;
+      if (g < ngrp) gsh[g] = gv[u];
+    }
+  }
+  __syncthreads();
+  // ---- the bound, by every wave for itself: lane minima over ALL groups (g = lane + 64 i), the keep-th smallest of the 64 by rank counting
   Cand m = inf;
-  const float gm0 = lt < ngrp ? load_agent(G + lt) : INFINITY, gm1 = lt + 256 < ngrp ? load_agent(G + lt + 256) : INFINITY;   // (kept for the listing pass below)
-  for (int g = lt; g < ngrp; g += 256) {
-    const float v = g == lt ? gm0 : g == lt + 256 ? gm1 : load_agent(G + g);
+  for (int g = lane; g < ngrp; g += 64) {
+    const float v = gsh[g];
     const bool b = v < m.d;
     m.d = b ? v : m.d; m.r = b ? g : m.r;
   }
-  m = wave_sort(m, lane);
-  sh[wave * 64 + lane] = m;
-  if (lt == 0) glist[0] = 0;
-  __syncthreads();
-  if (wave == 0) {
-    for (int w = 1; w < 4; ++w) m = wave_merge_top(m, sh[w * 64 + lane], lane);
-    if (lane == keep - 1) sh[256] = m;                  // (+inf when fewer than `keep` groups hold a finite score: every finite score passes then)
+  unsigned long long b1 = 0, b2 = 0; (void)b1; (void)b2;
+  MRAG_DSTAMP(b1);
+  float thr;
+  {
+    const int rank = cand_rank(m, 64);
+    const unsigned long long bal = __ballot(rank == keep - 1 && m.d < INFINITY);
+    thr = bal ? __shfl(m.d, __builtin_ctzll(bal)) : INFINITY;   // (+inf when fewer than `keep` lanes saw a finite score: every finite score passes then)
   }
-  __syncthreads();
-  const float thr = sh[256].d;
+  MRAG_DSTAMP(b2);
+  __syncthreads();                                      // (the counters are zero; the rank scratch is free again)
+  MRAG_DSTAMP(a1);
   // ---- the groups with a score at or under the bound, listed (any order: the result is the top of a strict total order)
-  for (int base = wave * 64; base < ngrp; base += 256) {
-    const int g = base + lane;
-    const float gm = g == lt ? gm0 : g == lt + 256 ? gm1 : g < ngrp ? load_agent(G + g) : INFINITY;   // (g = lt + 256 i: the groups of the bound pass)
+  for (int g = lane + 64 * wave; g < ngrp; g += 256) {
+    const float gm = gsh[g];
     const bool pass = gm < INFINITY && gm <= thr;
     const unsigned long long bal = __ballot(pass);
     if (bal) {
       int pos = 0;
-      if (lane == 0) pos = atomicAdd(glist, __popcll(bal));
+      if (lane == 0) pos = atomicAdd(ctr, __popcll(bal));
       pos = __shfl(pos, 0);
-      if (pass) glist[1 + pos + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+      if (pass) glist[pos + __popcll(bal & ((1ull << lane) - 1ull))] = g;
     }
   }
   __syncthreads();
-  const int nel = glist[0] * 32;
-  // ---- their scores: four independent loads per thread and step; compacted per wave, sorted 64 at a time, merged
-  Cand run = inf;
-  Cand* buf = bufs + wave * DENSE_BUF;
-  int cnt = 0;
+  MRAG_DSTAMP(a2);
+  const int nel = ctr[0] * 32;
+  // ---- their scores: four independent loads per thread and step; the ones at or under the bound are appended to `bufs`
   for (int e0 = 0; e0 < nel; e0 += 1024) {
     Cand c[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * 256 + lt;
       const bool in = e < nel;
-      c[u].r = in ? glist[1 + (e >> 5)] * 32 + (e & 31) : INT_MAX;
-      c[u].d = in ? load_agent(D + c[u].r) : INFINITY;
+      c[u].r = in ? glist[e >> 5] * 32 + (e & 31) : INT_MAX;
+      const float* a = D + (in ? c[u].r : 0);
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(c[u].d) : "v"(a) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c[0].d), "+v"(c[1].d), "+v"(c[2].d), "+v"(c[3].d) :: "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u].d = c[u].r != INT_MAX ? c[u].d : INFINITY;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool pass = c[u].d < INFINITY && c[u].d <= thr;
       const unsigned long long bal = __ballot(pass);
-      if (pass) buf[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c[u];
+      if (bal) {
+        int pos = 0;
+        if (lane == 0) pos = atomicAdd(ctr + 1, __popcll(bal));
+        pos = __shfl(pos, 0) + __popcll(bal & ((1ull << lane) - 1ull));
+        if (pass && pos < CAP) bufs[pos] = c[u];
+      }
+    }
+  }
+  __syncthreads();
+  MRAG_DSTAMP(a3);
+  const int ns = ctr[1];
+  Cand run = inf;
+  if (ns <= CAP) {
+    if (wave == 0) {
+      if (ns <= 64) {                                   // the usual case: one rank count puts them in order
+        const Cand c = lane < ns ? bufs[lane] : inf;
+        const int rank = cand_rank(c, ns);
+        if (lane < ns) sh[rank] = c;
+        __builtin_amdgcn_wave_barrier();
+        run = lane < ns ? sh[lane] : inf;
+      } else {
+        for (int b0 = 0; b0 < ns; b0 += 64) {
+          const Cand c = b0 + lane < ns ? bufs[b0 + lane] : inf;
+          run = wave_merge_top(run, wave_sort(c, lane), lane);
+        }
+      }
+    }
+  } else {
+    // more scores at or under the bound than the array holds (thousands of equal scores, or a table with fewer than `keep` finite scores per lane): the
+    // listed groups are read again, every wave compacts its own share, sorts 64 at a time and merges; the four runs meet in wave 0
+    __syncthreads();
+    Cand* buf = bufs + wave * DENSE_BUF;
+    int cnt = 0;
+    for (int e0 = 0; e0 < nel; e0 += 256) {
+      const int e = e0 + lt;
+      Cand c;
+      c.r = e < nel ? glist[e >> 5] * 32 + (e & 31) : INT_MAX;
+      c.d = e < nel ? load_agent(D + c.r) : INFINITY;
+      const bool pass = c.d < INFINITY && c.d <= thr;
+      const unsigned long long bal = __ballot(pass);
+      if (pass) buf[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
       cnt += __popcll(bal);
       __builtin_amdgcn_wave_barrier();                  // (one wave, in-order LDS: the reads below see the writes above)
       if (cnt >= 64) {
@@ -944,17 +1048,23 @@ __device__ __forceinline__ void dense_select(const TopkDP& p, const int q, const
         __builtin_amdgcn_wave_barrier();
       }
     }
-  }
-  {
     const Cand t = lane < cnt ? buf[lane] : inf;
     run = wave_merge_top(run, wave_sort(t, lane), lane);
+    __syncthreads();
+    sh[wave * 64 + lane] = run;
+    __syncthreads();
+    if (wave == 0)
+      for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
   }
-  __syncthreads();
-  sh[wave * 64 + lane] = run;
-  __syncthreads();
-  if (wave == 0)
-    for (int w = 1; w < 4; ++w) run = wave_merge_top(run, sh[w * 64 + lane], lane);
+  MRAG_DSTAMP(a4);
   finish_query(p.mp, q, run, sh, lt, store);
+  MRAG_DSTAMP(a5);
+#ifdef MRAG_TOPK_DIAG_STATS   // (accumulated in the caller's registers and flushed at the end of the kernel: an atomic issued here would sit in front of the next vmcnt wait)
+  if (threadIdx.x == 0) {
+    dacc[0] += 1; dacc[1] += a1 - a0; dacc[2] += a2 - a1; dacc[3] += a3 - a2; dacc[4] += a4 - a3; dacc[5] += a5 - a4;
+    dacc[6] = dacc[6] > a5 - a0 ? dacc[6] : a5 - a0; dacc[7] += b1 - a0; dacc[8] += b2 - b1; dacc[9] += a1 - b2;
+  }
+#endif
 }
 
 template <int METRIC, int TN, int WN>
@@ -965,7 +1075,7 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
   constexpr int NG = NT / 256;                         // 256-thread groups of the finishing phase
   static_assert(NPIECE % NW == 0 && (RB / 8) % NW == 0 && PPW == NTAB + TN, "every wave issues the same number of LDS-DMA pieces per slab (the counted vmcnt wait relies on it)");
   static_assert(NST * STAGE >= QB * LD * 4, "the score tile overlays the drained operand ring");
-  constexpr int SCR = (257 + 4 * DENSE_BUF) * 8 + (1 + 2048 + 3) / 4 * 16;   // bytes of finishing scratch per 256-thread group: candidates | list of passing groups (ld / 32 <= 2 048)
+  constexpr int SCR = DENSE_SCR;
   static_assert(NST * STAGE >= NG * SCR, "the finishing phase's scratch overlays it as well");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xxs = (float*)(smem + NST * STAGE);           // [4][32]: |x|^2 of the wave's 32 rows
@@ -977,6 +1087,9 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
   const int q0 = blockIdx.y * QB, part = blockIdx.x;
   const long long row_begin = (long long)part * RB;
   const long long row_end = row_begin + RB < p.n_rows ? row_begin + RB : p.n_rows;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  (void)s0; (void)s1; (void)s2; (void)s3; (void)s4;
+  MRAG_DSTAMP(s0);
 
   int exclv[TN]; bool qok[TN];
 #pragma unroll
@@ -1072,6 +1185,7 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
         for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
     });
   }
+  MRAG_DSTAMP(s1);
   // ---- first scores of the row block
   if constexpr (METRIC == 0) {
     const float xf = xx + __shfl_xor(xx, 32);          // the two half-row chains, added once (either lane: the same two addends)
@@ -1121,11 +1235,18 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
   if (tid < QB && q0 + tid < p.nq) store_agent_x4(p.gmin + ((long long)(q0 + tid) * (p.ld >> 5) + part * 4), *(const f32x4*)(gml + tid * 4));
   for (int idx = tid; idx < QB * (RB / 4); idx += NT) {
     const int qn = idx / (RB / 4), c4 = idx % (RB / 4);
+#if defined(MRAG_TOPK_DENSE_DIAG_NOD) && MRAG_TOPK_DENSE_DIAG_NOD == 1     // developer timing builds (results are NOT valid): no score stores / plain (cached) stores
+    (void)qn; (void)c4;
+#elif defined(MRAG_TOPK_DENSE_DIAG_NOD) && MRAG_TOPK_DENSE_DIAG_NOD == 2
+    if (q0 + qn < p.nq) *(f32x4*)(p.dist + (long long)(q0 + qn) * p.ld + row_begin + c4 * 4) = *(const f32x4*)(tile + qn * LD + c4 * 4);
+#else
     if (q0 + qn < p.nq) store_agent_x4(p.dist + (long long)(q0 + qn) * p.ld + row_begin + c4 * 4, *(const f32x4*)(tile + qn * LD + c4 * 4));
+#endif
   }
 #if defined(MRAG_TOPK_DENSE_DIAG) && MRAG_TOPK_DENSE_DIAG == 1   // developer timing build: the stream + the dense stores alone (results are NOT produced)
   return;
 #endif
+  if (p.total == 0) return;                            // the two-launch form: topk_dense_finish_kernel follows (kernel boundary = the hand-over)
   // ---- arrive; wait (bounded) until the grid has arrived; finish the queries of this workgroup's arrival ticket.
   // Words (the workspace's zeroed first 64 bytes, words 8..14): seq | set 0 {arrivals, go, claims} | set 1 {..}.  A call uses set (seq & 1); its last arriver
   // zeroes the OTHER set, publishes `go` and bumps seq, so nothing is reset behind anybody's back and no exit counter is needed (a third same-address atomic
@@ -1138,15 +1259,35 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
   // fetch_add; waiters: relaxed agent loads of `go`, barrier, agent-coherent loads of the scores (store_agent_x4 / load_agent above: no L2-wide fences).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MRAG_DSTAMP(s2);
+  unsigned seq = 0, ret = 0;                           // (lane 0's)
+  unsigned *set = nullptr, *other = nullptr;
   if (tid == 0) {
-    const unsigned seq = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned* set = p.sync + 1 + 3 * (seq & 1u);
-    unsigned* other = p.sync + 1 + 3 * ((seq & 1u) ^ 1u);
+    seq = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    set = p.sync + 1 + 3 * (seq & 1u);
+    other = p.sync + 1 + 3 * ((seq & 1u) ^ 1u);
 #ifdef MRAG_TOPK_DENSE_FENCES   // developer A/B build: the fences of the textbook hand-off on top of the write-through stores
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    const unsigned ret = __hip_atomic_fetch_add(set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ret = __hip_atomic_fetch_add(set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[1] = ret & 0xffffu;
+  }
+#ifndef MRAG_TOPK_DENSE_NO_TOUCH
+  // a workgroup that waits is idle: one load per wave from the minima and the first scores of the query it will finish brings their translations (and the path
+  // to them) in before `go` -- the first access after the wait measured ~5 us otherwise.  (The values may be stale: they are discarded.)
+  __syncthreads();                                     // (the ticket is in LDS)
+  {
+    const long long qn = (long long)flag[1] * NG + (tid >> 8);
+    if (qn < p.nq && (tid & 63) == 1 && flag[1] + 1u != (unsigned)p.total) {   // (not the last arriver: everybody is waiting for it)
+      float t0, t1;
+      const float* a0 = p.gmin + qn * (p.ld >> 5);
+      const float* a1 = p.dist + qn * p.ld + ((tid >> 6) & 3) * (p.ld >> 2);
+      asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t0), "=v"(t1) : "v"(a0), "v"(a1) : "memory");
+    }
+  }
+#endif
+  if (tid == 0) {
     const unsigned ticket = ret & 0xffffu;
     unsigned mode = 0;
     if (ticket + 1u == (unsigned)p.total) {
@@ -1177,24 +1318,42 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    flag[0] = mode; flag[1] = ticket; flag[2] = seq & 1u;
+    flag[0] = mode; flag[2] = seq & 1u;
   }
   __syncthreads();
   const unsigned mode = flag[0], ticket = flag[1];
+  MRAG_DSTAMP(s3);
+  unsigned long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  (void)dacc;
   unsigned* claims = p.sync + 1 + 3 * flag[2] + 2;
   __syncthreads();
 #if defined(MRAG_TOPK_DENSE_DIAG) && MRAG_TOPK_DENSE_DIAG == 2   // developer timing build: ... + the grid wait, no finishing phase
   return;
 #endif
-  if (mode == 0) return;
+#ifdef MRAG_TOPK_DIAG_STATS
+#define MRAG_DENSE_FLUSH()                                                                                                                              \
+  if (tid == 0) {                                                                                                                                        \
+    atomicAdd(&g_topk_dense_dbg[0], 1ull); atomicAdd(&g_topk_dense_dbg[1], s1 - s0); atomicAdd(&g_topk_dense_dbg[2], s2 - s1); atomicAdd(&g_topk_dense_dbg[3], s3 - s2); \
+    atomicMax(&g_topk_dense_dbg[4], s1 - s0); atomicMax(&g_topk_dense_dbg[5], s2 - s0); atomicMax(&g_topk_dense_dbg[6], s3 - s0);                     \
+    if (dacc[0]) {                                                                                                                                       \
+      atomicAdd(&g_topk_dense_dbg[8], dacc[0]); atomicAdd(&g_topk_dense_dbg[9], dacc[1]); atomicAdd(&g_topk_dense_dbg[10], dacc[2]); atomicAdd(&g_topk_dense_dbg[11], dacc[3]); \
+      atomicAdd(&g_topk_dense_dbg[12], dacc[4]); atomicAdd(&g_topk_dense_dbg[13], dacc[5]); atomicMax(&g_topk_dense_dbg[14], dacc[6]);                 \
+      atomicAdd(&g_topk_dense_dbg[15], dacc[7]); atomicAdd(&g_topk_dense_dbg[16], dacc[8]); atomicAdd(&g_topk_dense_dbg[17], dacc[9]);                 \
+    }                                                                                                                                                    \
+  }
+#else
+#define MRAG_DENSE_FLUSH()
+#endif
+  if (mode == 0) { MRAG_DENSE_FLUSH(); return; }
   Cand* sh = (Cand*)(smem + (tid >> 8) * SCR);
   Cand* bufs = sh + 257;
-  int* glist = (int*)(bufs + 4 * DENSE_BUF);
+  int* glist = (int*)(bufs + 4 * DENSE_BUF);   // (2 counters + the list)
   if (mode == 1) {
     for (long long idx = ticket; idx * NG < p.nq; idx += p.total) {
       const int q = (int)idx * NG + (tid >> 8);
-      dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist);
+      dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist, dacc);
     }
+    MRAG_DENSE_FLUSH();
     return;
   }
   for (;;) {
@@ -1204,8 +1363,19 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
     __syncthreads();
     if ((long long)claim * NG >= p.nq) break;
     const int q = (int)claim * NG + (tid >> 8);
-    dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist);
+    dense_select(p, q < p.nq ? q : p.nq - 1, q < p.nq, tid & 255, sh, bufs, glist, dacc);
   }
+  MRAG_DENSE_FLUSH();
+}
+#undef MRAG_DENSE_FLUSH
+
+// the finishing phase as a launch of its own (a workgroup per query): the dense form of tables whose grid is not resident at once
+__global__ __launch_bounds__(256) void topk_dense_finish_kernel(const TopkDP p) {
+  __shared__ __attribute__((aligned(16))) char scr[DENSE_SCR];
+  Cand* sh = (Cand*)scr;
+  Cand* bufs = sh + 257;
+  unsigned long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  dense_select(p, blockIdx.x, true, threadIdx.x, sh, bufs, (int*)(bufs + 4 * DENSE_BUF), dacc);
 }
 
 // the fan-out plan: queries per workgroup (32 TN), parts (workgroups along the table), rows per part
@@ -1250,8 +1420,10 @@ inline MfmaPlan plan_mfma(long long n_rows, int nq) {
 
 inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 && dim % 4 == 0; }
 
-// the one-launch plan: the smallest query tile whose grid fits ONE resident round (checked against the runtime's occupancy at launch: dense_launch)
-struct DensePlan { bool ok; int TN, WN, QB, gy, parts, ld; size_t lds, bytes; };
+// the plan of the dense forms: `ok` = the first scores fit the workspace (<= 65 536 rows, <= 64 MB); `resident` = a tile exists whose whole grid is on the chip at
+// once -> ONE launch with the grid wait (checked against the runtime's occupancy at launch); otherwise TWO launches: the same kernel without the wait, then
+// topk_dense_finish_kernel (a workgroup per query) -- still no pre-pass and no in-kernel selection rounds (20 000 x 256: 200 -> ~100 us).
+struct DensePlan { bool ok, resident; int TN, WN, QB, gy, parts, ld; size_t lds, bytes; };
 inline size_t dense_lds(int tn, int wn) {
   return (size_t)dense_stages(tn * wn) * (128 + 32 * tn * wn) * 128 + 132 * sizeof(float) + (size_t)32 * tn * wn * 4 * sizeof(float);   // ring | |x|^2, flag | group minima
 }
@@ -1260,31 +1432,40 @@ inline DensePlan plan_dense(long long n_rows, int nq, int dim = 768) {
   const int qtiles = (nq + 31) / 32;
   const long long blocks = (n_rows + 127) / 128;
   if (blocks > 512 || (long long)nq * blocks * 128 > (16LL << 20)) return pl;          // (<= 64 MB of first scores)
-  // Tile = the cheapest of (TN, WN) = 32 queries on four waves, 64 on eight / four, 128 on eight under a two-term model measured at 10 000 x 256 x 768
+  pl.ok = true; pl.parts = (int)blocks; pl.ld = (int)blocks * 128;
+  pl.bytes = (size_t)nq * pl.ld * sizeof(float) + (size_t)nq * (pl.ld / 32) * sizeof(float);     // first scores | group minima (the same for every tile)
+  // Tile = the cheapest of (TN, WN) = 128 queries on eight waves, 64 on four / eight, 32 on four under a two-term model measured at 10 000 x 256 x 768
   // (profiles/r6_topk_one_launch.txt): the busiest CU's MFMA time -- workgroups per CU x 32-query tiles per workgroup x 0.49 us per 32-feature slab -- plus the
   // arrivals at the grid wait, which are same-address atomics and serialise at ~0.045 us each (632 workgroups of 32 queries: 35 + 28 us; 158 of 128: 47 + 7).
-  // Small tables take the small tiles (4 000 x 256: 256 workgroups of one tile), BASELINE config #1's takes 128 queries per workgroup.
+  // Small tables take the small tiles (4 000 x 256: 256 workgroups of one tile), BASELINE config #1's takes 128 queries per workgroup.  A grid that is not
+  // resident at once (two launches, no wait) is priced by its rounds alone.
 #ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 12, 21, 22 = TN WN of every plan
   const int cand[1][2] = {{MRAG_TOPK_DENSE_TILE / 10, MRAG_TOPK_DENSE_TILE % 10}};
 #else
   const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
 #endif
   double best = 0;
-  for (const auto& c : cand) {
-    const int tiles = c[0] * c[1], qb = 32 * tiles, gy = (nq + qb - 1) / qb;
-    const int cap = tiles == 1 ? 3 : tiles == 2 ? 2 : 1;                                // (the kernels' launch bounds: workgroups per CU)
-    int per_cu = (int)((160 * 1024) / dense_lds(c[0], c[1]));
-    per_cu = per_cu > cap ? cap : per_cu;
-    if (qb > 32 * qtiles && qb > 32) continue;                                         // (a tile wider than the batch)
-    const long long wgs = blocks * gy;
-    if (wgs > 256LL * per_cu) continue;
-    const double t = (double)((wgs + 255) / 256) * tiles * ((dim + 31) / 32) * 0.49 + 0.045 * (double)wgs;
-    if (pl.ok && t >= best) continue;
-    best = t;
-    pl.ok = true; pl.TN = c[0]; pl.WN = c[1]; pl.QB = qb; pl.gy = gy; pl.parts = (int)blocks; pl.ld = (int)blocks * 128;
-    pl.lds = dense_lds(c[0], c[1]);
-    pl.bytes = (size_t)nq * pl.ld * sizeof(float) + (size_t)nq * (pl.ld / 32) * sizeof(float);     // first scores | group minima (the same for every tile)
-  }
+  bool have = false;
+  for (int pass = 0; pass < 2 && !have; ++pass)                                        // pass 0: resident grids; pass 1: any
+    for (const auto& c : cand) {
+      const int tiles = c[0] * c[1], qb = 32 * tiles, gy = (nq + qb - 1) / qb;
+      const int cap = tiles == 1 ? 3 : tiles == 2 ? 2 : 1;                              // (the kernels' launch bounds: workgroups per CU)
+      int per_cu = (int)((160 * 1024) / dense_lds(c[0], c[1]));
+      per_cu = per_cu > cap ? cap : per_cu;
+      if (qb > 32 * qtiles && qb > 32) continue;                                       // (a tile wider than the batch)
+      const long long wgs = blocks * gy;
+      const bool res = wgs <= 256LL * per_cu;
+      if (pass == 0 && !res) continue;
+      const double slab = ((dim + 31) / 32) * 0.49;
+      const double t = res ? (double)((wgs + 255) / 256) * tiles * slab + 0.045 * (double)wgs
+                           : (double)((wgs + 256LL * per_cu - 1) / (256LL * per_cu)) * per_cu * tiles * slab;
+      if (have && t >= best) continue;
+      best = t; have = true;
+      pl.resident = res; pl.TN = c[0]; pl.WN = c[1]; pl.QB = qb; pl.gy = gy;
+      pl.lds = dense_lds(c[0], c[1]);
+    }
+  pl.ok = have;
+  if (!have) pl.bytes = 0;
   return pl;
 }
 // `order = 0` (automatic) takes the fan-out form whenever it applies.  Measured on MI355X (tools/topk_sizes.py, k = 12, D = 768; fan-out / scan kernel):
@@ -1366,7 +1547,7 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
       d.db = db; d.group = p.group; d.q = queries; d.excl = exclude; d.n_rows = n_rows; d.dim = dim; d.nq = n_queries; d.nslab = (dim + 31) / 32;
       d.dist = (float*)((char*)workspace + kTicketBytes); d.sync = (unsigned*)workspace + 8;
       d.gmin = d.dist + (size_t)n_queries * dp.ld;
-      d.ld = dp.ld; d.total = dp.parts * dp.gy;
+      d.ld = dp.ld; d.total = dp.resident ? dp.parts * dp.gy : 0;
       d.spin_limit = order == 4 ? 0 : 40000;                // x ~1 us of s_sleep: a workgroup that has not seen the grid arrive by then leaves (the last arriver finishes alone)
       d.mp = p; d.mp.rescore = metric == 0 ? 1 : 0;
       int done = 0;
@@ -1382,7 +1563,8 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
           if (e != hipSuccess) return (int)e;                                                                                  \
           occ = o;                                                                                                              \
         }                                                                                                                       \
-        if ((long long)d.total <= 256LL * occ) {               /* the whole grid is resident at once: the wait is safe */        \
+        if (d.total && (long long)d.total > 256LL * occ) d.total = 0;   /* (the runtime fits fewer workgroups than planned: no wait, two launches) */ \
+        if (d.total || order != 4) {                                                                                            \
           MRAG_LAUNCH(kfn, dim3(dp.parts, dp.gy), dim3(256 * W), dp.lds, s, d);                                                 \
           done = 1;                                                                                                             \
         }                                                                                                                       \
@@ -1393,6 +1575,11 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
       if (done) {
         MRAG_LAUNCH_CHECK();
         MRAG_COUNT(MRAG_K_TOPK_DENSE);
+        if (d.total == 0) {
+          MRAG_LAUNCH(topk_dense_finish_kernel, dim3(n_queries), dim3(256), 0, s, d);
+          MRAG_LAUNCH_CHECK();
+          MRAG_COUNT(MRAG_K_TOPK_DENSE_FINISH);
+        }
         return MRAG_OK;
       }
       if (order == 4) return MRAG_ENOTSUP;

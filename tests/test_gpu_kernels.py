@@ -787,8 +787,27 @@ def test_topk_baseline_size(hip):
         assert np.all(np.diff(dist, axis=1) >= 0) and not np.any(rows == excl[:, None])
 
 
+def _fanout_shape(N, Q):
+    """which launch shape the fan-out form's plan takes (topk.hip plan_dense): 'one' launch (the dense grid is resident at once), 'two' (dense scores, then the
+    finishing launch) or 'stream' (pre-pass, streaming kernel with in-kernel lists, merge)"""
+    blocks, qtiles = -(-N // 128), -(-Q // 32)
+    if blocks > 512 or Q * blocks * 128 > (16 << 20):
+        return "stream"
+    for tiles, per_cu in ((4, 1), (2, 2), (2, 2), (1, 3)):
+        qb = 32 * tiles
+        if qb > 32 * qtiles and qb > 32:
+            continue
+        if blocks * -(-Q // qb) <= 256 * per_cu:
+            return "one"
+    return "two"
+
+
+_FANOUT_COUNTS = {"one": {"TOPK_DENSE": 1}, "two": {"TOPK_DENSE": 1, "TOPK_DENSE_FINISH": 1}, "stream": {"TOPK_MFMA": 1, "TOPK_MERGE": 1}}
+
+
 @pytest.mark.parametrize("metric", ["l2", "dot"])
-@pytest.mark.parametrize("N,Q,D,k", [(3000, 130, 768, 12), (70001, 40, 768, 12), (66000, 256, 256, 16), (5000, 20, 100, 1), (9000, 300, 64, 7), (130, 16, 32, 12)])
+@pytest.mark.parametrize("N,Q,D,k", [(3000, 130, 768, 12), (70001, 40, 768, 12), (66000, 256, 256, 16), (5000, 20, 100, 1), (9000, 300, 64, 7), (130, 16, 32, 12),
+                                     (20000, 256, 64, 12), (40000, 100, 96, 16)])
 def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     """the fan-out kernel (fp32 MFMA, `order="mfma"`) against mode 2 of the C oracle, rows AND distances bit for bit, in every configuration of its plan:
     a small table with many queries (the waves split the queries: 32 rows x 4 x 32 TN queries per workgroup), a large table (4 x 32 rows per workgroup,
@@ -803,22 +822,24 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     excl = group[rng.integers(0, N, Q)].astype(np.int32)
     q[: Q // 4] = db[(2 * excl[: Q // 4])] + 0.01 * q[: Q // 4]                   # queries next to a row of the excluded video
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
-    one_launch = N <= 65536                                                       # (a table of one resident round of workgroups: topk.hip plan_dense)
+    shape = _fanout_shape(N, Q)                                                   # (3000, 130) .. (130, 16): one launch; (20000, 256), (40000, 100): two; 66 000 / 70 001 rows: streaming
+    assert shape == {3000: "one", 70001: "stream", 66000: "stream", 5000: "one", 9000: "one", 130: "one", 20000: "two", 40000: "two"}[N]
+    one_launch = shape == "one"
     for post in (False, True):
         want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32mfma", postfilter=post)
-        # "mfma": the shape the plan picks; "mfma_stream": pre-pass + streaming kernel + merge launch; "mfma_nowait": ONE launch whose workgroups do not wait
-        # for each other (the last arriver finishes every query: the bounded wait's fall-back) -- the same defined result from all three
+        # "mfma": the shape the plan picks (one launch / dense scores + finishing launch / streaming); "mfma_stream": pre-pass + streaming kernel + merge launch;
+        # "mfma_nowait": ONE launch whose workgroups do not wait for each other (the last arriver finishes every query: the bounded wait's fall-back) -- the same
+        # defined result from all of them
         for order in ("mfma", "mfma_stream") + (("mfma_nowait",) if one_launch else ()):
             with ops.dispatched() as d:
                 rows, dist = ops.topk(dbd, qd, k, metric=metric, group=gd, exclude=ed, postfilter=post, order=order)
-            dense = one_launch and order != "mfma_stream"
-            assert d.counts == ({"TOPK_DENSE": 1} if dense else {"TOPK_MFMA": 1, "TOPK_MERGE": 1}), (order, d.counts)
+            assert d.counts == _FANOUT_COUNTS["stream" if order == "mfma_stream" else shape], (order, d.counts)
             np.testing.assert_array_equal(rows.cpu().numpy(), want_r, err_msg=order)
             np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32), err_msg=order)
     want_r, want_d = topk_ref.topk(db, q, k, metric, mode="f32mfma")
     with ops.dispatched() as d:
         rows, dist = ops.topk(dbd, qd, k, metric=metric, order="auto")            # automatic: the fan-out form wherever it applies
-    assert ("TOPK_DENSE" in d.counts) == one_launch and ("TOPK_MFMA" in d.counts) != one_launch and "TOPK_SCAN" not in d.counts, d.counts
+    assert d.counts == _FANOUT_COUNTS[shape], d.counts
     np.testing.assert_array_equal(rows.cpu().numpy(), want_r)
     np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32))
 

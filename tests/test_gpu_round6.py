@@ -300,3 +300,30 @@ def test_topk_fanout_l2_distances_are_the_scan_forms(hip):
     assert np.array_equal(r1.cpu().numpy(), rows[:3]) and np.array_equal(d1.cpu().numpy(), dist[:3])
     raw_r, raw_d = topk_ref.topk(db, q, 12, "l2", mode="f32mfma_raw")          # what the expansion alone gives: self-distance is rounding noise
     assert np.abs(raw_d[:, 0]).max() > 1e-5
+
+
+@pytest.mark.parametrize("dups", [100, 800])
+def test_topk_one_launch_with_many_equal_scores(hip, dups):
+    """the one-launch fan-out form orders the scores under its bound by counting ranks in one LDS array (usually ~16 of them); `dups` identical rows next to
+    the queries put 100 (several 64-candidate chunks) / 800 (more than the array holds: the streaming fall-back) equal scores under the bound -- the answer is
+    still the top of the strict order (distance, row), equal to the oracle's and to the streaming form's, in both filter orders"""
+    from motionrag_amd import ops
+    from oracle import topk_ref
+    rng = np.random.default_rng(dups)
+    N, Q, D = 3000, 32, 64
+    db = rng.standard_normal((N, D)).astype(np.float32)
+    db[100:100 + dups] = db[100]
+    q = (db[100][None] + 0.05 * rng.standard_normal((Q, D))).astype(np.float32)
+    group = (np.arange(N) // 4).astype(np.int32)
+    excl = np.full(Q, 25, dtype=np.int32)                                       # rows 100..103 carry the excluded id
+    dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
+    for metric in ("l2", "dot"):
+        for post in (False, True):
+            want_r, want_d = topk_ref.topk(db, q, 12, metric, group, excl, mode="f32mfma", postfilter=post)
+            for order in ("mfma", "mfma_stream", "mfma_nowait"):
+                with ops.dispatched() as d:
+                    rows, dist = ops.topk(dbd, qd, 12, metric=metric, group=gd, exclude=ed, postfilter=post, order=order)
+                assert ("TOPK_DENSE" in d.counts) == (order != "mfma_stream"), (order, d.counts)
+                np.testing.assert_array_equal(rows.cpu().numpy(), want_r, err_msg=f"{metric} {post} {order}")
+                np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32), err_msg=f"{metric} {post} {order}")
+    assert np.array_equal(want_r[0, :8], np.arange(104, 112))                   # post-filter, dot: the 12 nearest are rows 100..111, the first four leave

@@ -1067,9 +1067,12 @@ __device__ __forceinline__ void dense_select(const TopkDP& p, const int q, const
 #endif
 }
 
-template <int METRIC, int TN, int WN>
+// QBU = queries a workgroup USES of the 32 TN WN its LDS image holds.  96 of 128 (the eight-wave workgroup whose second query group computes ONE of its two tiles):
+// three 32-query tiles per workgroup -- BASELINE config #1's 632 tiles then quantise to 3 per busy CU (237 workgroups) instead of 4 (158), with two waves per SIMD.
+template <int METRIC, int TN, int WN, int QBU = 32 * TN * WN>
 __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void topk_dense_kernel(const TopkDP p) {   // (waves per SIMD: 3 / 2 / 2 workgroups per CU)
   constexpr int WM = 4, NW = WM * WN, NT = 64 * NW, RB = 32 * WM, QB = 32 * TN * WN, NST = dense_stages(TN * WN);
+  static_assert(QBU % 32 == 0 && QBU <= QB && QBU > QB - 32 * TN, "only the last query group may run short");
   constexpr int STAGE = (RB + QB) * 128, NPIECE = (RB + QB) / 8, PPW = NPIECE / NW, NTAB = (RB / 8) / NW;
   constexpr int LD = RB + 4;                           // floats per query of the LDS score tile (16-byte aligned rows, spread over the banks)
   constexpr int NG = NT / 256;                         // 256-thread groups of the finishing phase
@@ -1084,7 +1087,8 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & (WM - 1), wn = wave / WM;
   const int r32 = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * QB, part = blockIdx.x;
+  const int q0 = blockIdx.y * QBU, part = blockIdx.x;
+  const bool all_tiles = QBU == QB || (wn * TN + TN) * 32 <= QBU;   // (wave-uniform) this wave's query group computes all of its TN tiles
   const long long row_begin = (long long)part * RB;
   const long long row_end = row_begin + RB < p.n_rows ? row_begin + RB : p.n_rows;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int qi = q0 + (wn * TN + j) * 32 + r32;
-    qok[j] = qi < p.nq;
+    qok[j] = qi < p.nq && (wn * TN + j) * 32 < QBU;
     exclv[j] = (p.excl && p.group && qok[j]) ? p.excl[qi] : INT_MIN;
   }
   // ---- the LDS-DMA stream of topk_mfma_kernel over the row block's slabs (same image, same swizzle, same counted wait)
@@ -1161,30 +1165,39 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
     const char* arow = st + (wm * 32 + r32) * 128;
     const char* qrow = st + (RB + wn * TN * 32 + r32) * 128;
     const int sw = (r32 >> 1) & 7;
-    static_for<4>([&](auto C) __attribute__((always_inline)) {
-      constexpr int c = decltype(C)::value;
-      const int off = ((2 * c + h) ^ sw) * 16;
-      const f32x4 a4 = *(const f32x4*)(arow + off);
-      f32x4 b4[TN];
+    auto slab = [&](auto NTL) __attribute__((always_inline)) {           // NTL = tiles this wave computes (TN, or fewer in a short last query group)
+      constexpr int ntl = decltype(NTL)::value;
+      static_for<4>([&](auto C) __attribute__((always_inline)) {
+        constexpr int c = decltype(C)::value;
+        const int off = ((2 * c + h) ^ sw) * 16;
+        const f32x4 a4 = *(const f32x4*)(arow + off);
+        f32x4 b4[ntl];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b4[j] = *(const f32x4*)(qrow + j * 32 * 128 + off);
-      if constexpr (METRIC == 0) {                     // the half-block chains of |x|^2 (this lane's row) and |q|^2 (this lane's query of every tile)
+        for (int j = 0; j < ntl; ++j) b4[j] = *(const f32x4*)(qrow + j * 32 * 128 + off);
+        if constexpr (METRIC == 0) {                   // the half-block chains of |x|^2 (this lane's row) and |q|^2 (this lane's query of every tile)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xx = __builtin_fmaf(a4[t], a4[t], xx);
+          for (int t = 0; t < 4; ++t) xx = __builtin_fmaf(a4[t], a4[t], xx);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < ntl; ++j)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) qq[j] = __builtin_fmaf(b4[j][t], b4[j][t], qq[j]);
-      }
+            for (int t = 0; t < 4; ++t) qq[j] = __builtin_fmaf(b4[j][t], b4[j][t], qq[j]);
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[j][0], acc[j], 0, 0, 0);
-      issue_phase(C, nstage);
+        for (int j = 0; j < ntl; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b4[j][0], acc[j], 0, 0, 0);
+        issue_phase(C, nstage);
 #pragma unroll
-      for (int t = 1; t < 4; ++t)
+        for (int t = 1; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
-    });
+          for (int j = 0; j < ntl; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[j][t], acc[j], 0, 0, 0);
+      });
+    };
+    if constexpr (QBU == QB) slab(std::integral_constant<int, TN>{});
+    else {
+      if (all_tiles) slab(std::integral_constant<int, TN>{});
+      else slab(std::integral_constant<int, (QBU / 32) % TN>{});
+    }
   }
+  (void)all_tiles;
   MRAG_DSTAMP(s1);
   // ---- first scores of the row block
   if constexpr (METRIC == 0) {
@@ -1232,8 +1245,8 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
     if (h == 0) gml[qn * 4 + wm] = mn[j];
   }
   __syncthreads();
-  if (tid < QB && q0 + tid < p.nq) store_agent_x4(p.gmin + ((long long)(q0 + tid) * (p.ld >> 5) + part * 4), *(const f32x4*)(gml + tid * 4));
-  for (int idx = tid; idx < QB * (RB / 4); idx += NT) {
+  if (tid < QBU && q0 + tid < p.nq) store_agent_x4(p.gmin + ((long long)(q0 + tid) * (p.ld >> 5) + part * 4), *(const f32x4*)(gml + tid * 4));
+  for (int idx = tid; idx < QBU * (RB / 4); idx += NT) {
     const int qn = idx / (RB / 4), c4 = idx % (RB / 4);
 #if defined(MRAG_TOPK_DENSE_DIAG_NOD) && MRAG_TOPK_DENSE_DIAG_NOD == 1     // developer timing builds (results are NOT valid): no score stores / plain (cached) stores
     (void)qn; (void)c4;
@@ -1423,7 +1436,7 @@ inline bool mfma_applies(int nq, int k, int dim) { return nq >= 16 && k <= 16 &&
 // the plan of the dense forms: `ok` = the first scores fit the workspace (<= 65 536 rows, <= 64 MB); `resident` = a tile exists whose whole grid is on the chip at
 // once -> ONE launch with the grid wait (checked against the runtime's occupancy at launch); otherwise TWO launches: the same kernel without the wait, then
 // topk_dense_finish_kernel (a workgroup per query) -- still no pre-pass and no in-kernel selection rounds (20 000 x 256: 200 -> ~100 us).
-struct DensePlan { bool ok, resident; int TN, WN, QB, gy, parts, ld; size_t lds, bytes; };
+struct DensePlan { bool ok, resident; int TN, WN, QB, gy, parts, ld; size_t lds, bytes; };   // QB = queries a workgroup covers (96: the eight-wave workgroup of three tiles)
 inline size_t dense_lds(int tn, int wn) {
   return (size_t)dense_stages(tn * wn) * (128 + 32 * tn * wn) * 128 + 132 * sizeof(float) + (size_t)32 * tn * wn * 4 * sizeof(float);   // ring | |x|^2, flag | group minima
 }
@@ -1438,18 +1451,19 @@ inline DensePlan plan_dense(long long n_rows, int nq, int dim = 768) {
   // (profiles/r6_topk_one_launch.txt): the busiest CU's MFMA time -- workgroups per CU x 32-query tiles per workgroup x 0.49 us per 32-feature slab -- plus the
   // arrivals at the grid wait, which are same-address atomics and serialise at ~0.045 us each (632 workgroups of 32 queries: 35 + 28 us; 158 of 128: 47 + 7).
   // Small tables take the small tiles (4 000 x 256: 256 workgroups of one tile), BASELINE config #1's takes 128 queries per workgroup.  A grid that is not
-  // resident at once (two launches, no wait) is priced by its rounds alone.
-#ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 12, 21, 22 = TN WN of every plan
-  const int cand[1][2] = {{MRAG_TOPK_DENSE_TILE / 10, MRAG_TOPK_DENSE_TILE % 10}};
+  // resident at once (two launches, no wait) is priced by its work per CU plus one workgroup's duration (the tail): it takes the small tiles.  The three-tile
+  // workgroup (96 of the 128 queries an eight-wave workgroup holds) exists for config #1's size: 632 tiles = 237 x 3 -> 3 per busy CU (75.7 us) instead of 158 x 4 (80.8).
+#ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 12, 21, 22 = TN WN of every plan; 23 = the three-tile workgroup
+  const int cand[1][3] = {{MRAG_TOPK_DENSE_TILE == 23 ? 2 : MRAG_TOPK_DENSE_TILE / 10, MRAG_TOPK_DENSE_TILE == 23 ? 2 : MRAG_TOPK_DENSE_TILE % 10, MRAG_TOPK_DENSE_TILE == 23 ? 3 : 0}};
 #else
-  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const int cand[5][3] = {{2, 2, 0}, {2, 2, 3}, {2, 1, 0}, {1, 2, 0}, {1, 1, 0}};                // TN, WN, tiles used (0 = all)
 #endif
   double best = 0;
   bool have = false;
   for (int pass = 0; pass < 2 && !have; ++pass)                                        // pass 0: resident grids; pass 1: any
     for (const auto& c : cand) {
-      const int tiles = c[0] * c[1], qb = 32 * tiles, gy = (nq + qb - 1) / qb;
-      const int cap = tiles == 1 ? 3 : tiles == 2 ? 2 : 1;                              // (the kernels' launch bounds: workgroups per CU)
+      const int held = c[0] * c[1], tiles = c[2] ? c[2] : held, qb = 32 * tiles, gy = (nq + qb - 1) / qb;
+      const int cap = held == 1 ? 3 : held == 2 ? 2 : 1;                                // (the kernels' launch bounds: workgroups per CU)
       int per_cu = (int)((160 * 1024) / dense_lds(c[0], c[1]));
       per_cu = per_cu > cap ? cap : per_cu;
       if (qb > 32 * qtiles && qb > 32) continue;                                       // (a tile wider than the batch)
@@ -1458,7 +1472,7 @@ inline DensePlan plan_dense(long long n_rows, int nq, int dim = 768) {
       if (pass == 0 && !res) continue;
       const double slab = ((dim + 31) / 32) * 0.49;
       const double t = res ? (double)((wgs + 255) / 256) * tiles * slab + 0.045 * (double)wgs
-                           : (double)((wgs + 256LL * per_cu - 1) / (256LL * per_cu)) * per_cu * tiles * slab;
+                           : ((double)wgs * tiles / 256.0 + tiles) * slab;              // (dispatched as CUs free up: the work per CU + one workgroup's duration as the tail)
       if (have && t >= best) continue;
       best = t; have = true;
       pl.resident = res; pl.TN = c[0]; pl.WN = c[1]; pl.QB = qb; pl.gy = gy;
@@ -1551,9 +1565,9 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
       d.spin_limit = order == 4 ? 0 : 40000;                // x ~1 us of s_sleep: a workgroup that has not seen the grid arrive by then leaves (the last arriver finishes alone)
       d.mp = p; d.mp.rescore = metric == 0 ? 1 : 0;
       int done = 0;
-#define MRAG_TOPK_DENSE(M, T, W)                                                                                              \
-      if (dp.ok && !done && metric == M && dp.TN == T && dp.WN == W) {                                                         \
-        auto kfn = topk_dense_kernel<M, T, W>;                                                                                  \
+#define MRAG_TOPK_DENSE(M, T, W, U)                                                                                            \
+      if (dp.ok && !done && metric == M && dp.TN == T && dp.WN == W && dp.QB == U) {                                           \
+        auto kfn = topk_dense_kernel<M, T, W, U>;                                                                                  \
         static int occ = -1;                                                                                                    \
         if (occ < 0) {                                                                                                          \
           hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp.lds);       \
@@ -1569,8 +1583,8 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
           done = 1;                                                                                                             \
         }                                                                                                                       \
       }
-      MRAG_TOPK_DENSE(0, 1, 1) MRAG_TOPK_DENSE(0, 1, 2) MRAG_TOPK_DENSE(0, 2, 1) MRAG_TOPK_DENSE(0, 2, 2)
-      MRAG_TOPK_DENSE(1, 1, 1) MRAG_TOPK_DENSE(1, 1, 2) MRAG_TOPK_DENSE(1, 2, 1) MRAG_TOPK_DENSE(1, 2, 2)
+      MRAG_TOPK_DENSE(0, 1, 1, 32) MRAG_TOPK_DENSE(0, 1, 2, 64) MRAG_TOPK_DENSE(0, 2, 1, 64) MRAG_TOPK_DENSE(0, 2, 2, 128) MRAG_TOPK_DENSE(0, 2, 2, 96)
+      MRAG_TOPK_DENSE(1, 1, 1, 32) MRAG_TOPK_DENSE(1, 1, 2, 64) MRAG_TOPK_DENSE(1, 2, 1, 64) MRAG_TOPK_DENSE(1, 2, 2, 128) MRAG_TOPK_DENSE(1, 2, 2, 96)
 #undef MRAG_TOPK_DENSE
       if (done) {
         MRAG_LAUNCH_CHECK();

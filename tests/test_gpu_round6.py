@@ -327,3 +327,34 @@ def test_topk_one_launch_with_many_equal_scores(hip, dups):
                 np.testing.assert_array_equal(rows.cpu().numpy(), want_r, err_msg=f"{metric} {post} {order}")
                 np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32), err_msg=f"{metric} {post} {order}")
     assert np.array_equal(want_r[0, :8], np.arange(104, 112))                   # post-filter, dot: the 12 nearest are rows 100..111, the first four leave
+
+
+def test_topk_one_launch_counters_survive_replays_and_mixed_shapes(hip):
+    """the one-launch fan-out form keeps a sequence number and two alternating counter sets in the workspace's first 64 bytes: a prepared batch plan replayed as a
+    HIP graph many times (odd and even sequence numbers), with new queries between replays, and calls of the OTHER shapes on the same workspace in between
+    (single query: the fused scan + merge launch with its own counters in words 0..3; the no-wait diagnostic; the streaming form) keep giving the oracle's rows"""
+    from motionrag_amd import ops, _lib
+    from oracle import topk_ref
+    rng = np.random.default_rng(5)
+    N, Q, D = 6000, 48, 96
+    db = rng.standard_normal((N, D)).astype(np.float32)
+    dbd = torch.from_numpy(db).to(DEV)
+    plan = ops.TopkPlan(dbd, Q, 12, graph=True)
+    for it in range(7):
+        q = rng.standard_normal((Q, D)).astype(np.float32)
+        plan.queries.copy_(torch.from_numpy(q).to(DEV))
+        rows, dist = plan.replay()
+        torch.cuda.synchronize()
+        want_r, want_d = topk_ref.topk(db, q, 12, "l2", mode="f32mfma")
+        np.testing.assert_array_equal(rows.cpu().numpy(), want_r, err_msg=f"replay {it}")
+        np.testing.assert_array_equal(dist.cpu().numpy(), want_d.astype(np.float32), err_msg=f"replay {it}")
+    counters = plan._ws[:64].view(torch.int32).cpu().numpy()
+    assert counters[8] == 8 and not counters[:8].any(), counters          # word 8 = the sequence number: the plan's eager run + 7 replays (a capture launches nothing); words 0..7 untouched
+    # the shared (per device, N, Q) workspace of ops.topk under alternating shapes
+    qd = torch.from_numpy(q).to(DEV)
+    for order in ("mfma", "mfma_nowait", "mfma", "mfma_stream", "mfma", "mfma"):
+        r, d_ = ops.topk(dbd, qd, 12, order=order)
+        np.testing.assert_array_equal(r.cpu().numpy(), want_r, err_msg=order)
+        np.testing.assert_array_equal(d_.cpu().numpy(), want_d.astype(np.float32), err_msg=order)
+        r1, _ = ops.topk(dbd, qd[:1], 12)                                    # (its own workspace key: Q = 1)
+        assert np.array_equal(r1.cpu().numpy()[0], topk_ref.topk(db, q[:1], 12, "l2", mode="f32chain")[0][0])

@@ -193,7 +193,8 @@ def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
     for N, Q in cases:
         db = torch.randn(N, 768, device=DEV)
         q = torch.randn(Q, 768, device=DEV)
-        dt = timeit(lambda: ops.topk(db, q, 12), iters=5)
+        small = N <= 100000                                                  # (a search of tens of microseconds: enough calls that the queue, not the first launches, is timed)
+        dt = timeit(lambda: ops.topk(db, q, 12), iters=50 if small else 5, warm=5 if small else 2)
         print(f"topk N={N} Q={Q}: {dt*1e6:.1f} us  db stream {N*768*4/dt/1e9:.0f} GB/s  ({Q/dt:.0f} queries/s)")
         res[f"N{N}_Q{Q}"] = {"us": round(dt * 1e6, 1), "db_stream_GBps": round(N * 768 * 4 / dt / 1e9), "queries_per_s": round(Q / dt)}
         if Q >= 16:     # batches run the fan-out kernel (fp32 MFMA, one pass over the table per 256 queries); the 16-chain scan kernel beside it
@@ -201,6 +202,16 @@ def topk(cases=((10000, 1), (10000, 256), (1000000, 1), (1000000, 64))):
             dtc = timeit(lambda: ops.topk(db, q, 12, order="chain16"), iters=3)
             print(f"   scan kernel (order chain16): {dtc*1e6:.1f} us; fan-out kernel {2.0*N*Q*768/dt/1e12:.1f} TFLOP/s of fp32 MFMA (peak 157)")
             res[f"N{N}_Q{Q}"]["chain16_us"] = round(dtc * 1e6, 1)
+            with ops.dispatched() as dsp:
+                ops.topk(db, q, 12)
+            res[f"N{N}_Q{Q}"]["launches"] = "+".join(f"{k}:{v}" for k, v in sorted(dsp.counts.items()))
+            planb = ops.TopkPlan(db, Q, 12)                                      # the batch through a prepared plan: nothing allocated per call, host cost = one C-ABI call
+            planb.queries.copy_(q)
+            dtp = timeit(planb.run, iters=50 if small else 5, warm=5 if small else 2)
+            assert torch.equal(planb.rows, ops.topk(db, q, 12)[0])
+            print(f"   launches {res[f'N{N}_Q{Q}']['launches']}; prepared plan: {dtp*1e6:.1f} us per call")
+            res[f"N{N}_Q{Q}"]["plan_us"] = round(dtp * 1e6, 1)
+            del planb
         if Q <= 4:      # the interactive query through a prepared plan: one C-ABI call = one kernel launch, nothing allocated
             plan = ops.TopkPlan(db, Q, 12, graph=True)
             plan.queries.copy_(q)

@@ -20,7 +20,7 @@ LOG2E = 1.4426950408889634
 
 # Developer tuning knobs (tools/microbench.py, A/B tests): explicit `tuning` fields of the C-ABI argument structs, 0 = the shipped behaviour.
 # Nothing on the launch path reads the environment.
-TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False, "no_batched_w": False}
+TUNING = {"gemm": 0, "attn": 0, "attn_no_split": False, "no_qkv_fuse": False, "no_batched_w": False, "gn_fold": False}
 GEMM_TUNE_NO_WIDE, GEMM_TUNE_NO_STAGED, GEMM_TUNE_GEGLU_NO_STAGED = 1, 2, 4
 ATTN_TUNE_NO_TINY, ATTN_TUNE_LEGACY = 1, 8
 
@@ -724,7 +724,7 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     a = GroupNormArgs()
     a.x, a.y, a.gamma, a.beta, a.workspace = _p(x), _p(out), _p(gamma), _p(beta), _p(ws)
     a.N, a.HW, a.C, a.G, a.chunks, a.silu, a.eps = N, HW, C, groups, chunks, 1 if silu else 0, eps
-    a.fold = 1 if fold else 0                    # opt-in: statistics + fold in one launch (measured slower than the separate fold: include/mrag_hip.h)
+    a.fold = 1 if (fold or TUNING.get("gn_fold")) else 0                    # opt-in: statistics + fold in one launch (measured slower than the separate fold: include/mrag_hip.h)
     if emb is not None:
         _dev(emb, name="emb")
         if emb.shape != (N, C) or emb.stride(1) != 1:

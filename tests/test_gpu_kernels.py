@@ -807,7 +807,7 @@ _FANOUT_COUNTS = {"one": {"TOPK_DENSE": 1}, "two": {"TOPK_DENSE": 1, "TOPK_DENSE
 
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 @pytest.mark.parametrize("N,Q,D,k", [(3000, 130, 768, 12), (70001, 40, 768, 12), (66000, 256, 256, 16), (5000, 20, 100, 1), (9000, 300, 64, 7), (130, 16, 32, 12),
-                                     (20000, 256, 64, 12), (40000, 100, 96, 16)])
+                                     (20000, 256, 64, 12), (40000, 100, 96, 16), (39000, 64, 64, 12)])
 def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     """the fan-out kernel (fp32 MFMA, `order="mfma"`) against mode 2 of the C oracle, rows AND distances bit for bit, in every configuration of its plan:
     a small table with many queries (the waves split the queries: 32 rows x 4 x 32 TN queries per workgroup), a large table (4 x 32 rows per workgroup,
@@ -823,7 +823,7 @@ def test_topk_fanout_bit_exact(hip, metric, N, Q, D, k):
     q[: Q // 4] = db[(2 * excl[: Q // 4])] + 0.01 * q[: Q // 4]                   # queries next to a row of the excluded video
     dbd, qd, gd, ed = (torch.from_numpy(a).to(DEV) for a in (db, q, group, excl))
     shape = _fanout_shape(N, Q)                                                   # (3000, 130) .. (130, 16): one launch; (20000, 256), (40000, 100): two; 66 000 / 70 001 rows: streaming
-    assert shape == {3000: "one", 70001: "stream", 66000: "stream", 5000: "one", 9000: "one", 130: "one", 20000: "two", 40000: "two"}[N]
+    assert shape == {3000: "one", 70001: "stream", 66000: "stream", 5000: "one", 9000: "one", 130: "one", 20000: "two", 40000: "two", 39000: "one"}[N]   # (39000, 64): 64 queries on FOUR waves per workgroup
     one_launch = shape == "one"
     for post in (False, True):
         want_r, want_d = topk_ref.topk(db, q, k, metric, group, excl, mode="f32mfma", postfilter=post)

@@ -1285,22 +1285,6 @@ __global__ __launch_bounds__(256 * WN, TN * WN == 1 ? 3 : WN == 1 ? 2 : 1) void 
 #endif
     ret = __hip_atomic_fetch_add(set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flag[1] = ret & 0xffffu;
-  }
-#ifndef MRAG_TOPK_DENSE_NO_TOUCH
-  // a workgroup that waits is idle: one load per wave from the minima and the first scores of the query it will finish brings their translations (and the path
-  // to them) in before `go` -- the first access after the wait measured ~5 us otherwise.  (The values may be stale: they are discarded.)
-  __syncthreads();                                     // (the ticket is in LDS)
-  {
-    const long long qn = (long long)flag[1] * NG + (tid >> 8);
-    if (qn < p.nq && (tid & 63) == 1 && flag[1] + 1u != (unsigned)p.total) {   // (not the last arriver: everybody is waiting for it)
-      float t0, t1;
-      const float* a0 = p.gmin + qn * (p.ld >> 5);
-      const float* a1 = p.dist + qn * p.ld + ((tid >> 6) & 3) * (p.ld >> 2);
-      asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t0), "=v"(t1) : "v"(a0), "v"(a1) : "memory");
-    }
-  }
-#endif
-  if (tid == 0) {
     const unsigned ticket = ret & 0xffffu;
     unsigned mode = 0;
     if (ticket + 1u == (unsigned)p.total) {
@@ -1391,6 +1375,17 @@ __global__ __launch_bounds__(256) void topk_dense_finish_kernel(const TopkDP p) 
   dense_select(p, blockIdx.x, true, threadIdx.x, sh, bufs, (int*)(bufs + 4 * DENSE_BUF), dacc);
 }
 
+// compute units of the current device (the grid wait of the one-launch form is taken only when the runtime's occupancy x this count holds the whole grid)
+inline int dense_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+    cus = n;
+  }
+  return cus;
+}
+
 // the fan-out plan: queries per workgroup (32 TN), parts (workgroups along the table), rows per part
 struct MfmaPlan { int TN, WN, QB, RB, gy, parts, rows_per_part; size_t lds, bytes; };
 inline MfmaPlan plan_mfma(long long n_rows, int nq) {
@@ -1453,10 +1448,10 @@ inline DensePlan plan_dense(long long n_rows, int nq, int dim = 768) {
   // Small tables take the small tiles (4 000 x 256: 256 workgroups of one tile), BASELINE config #1's takes 128 queries per workgroup.  A grid that is not
   // resident at once (two launches, no wait) is priced by its work per CU plus one workgroup's duration (the tail): it takes the small tiles.  The three-tile
   // workgroup (96 of the 128 queries an eight-wave workgroup holds) exists for config #1's size: 632 tiles = 237 x 3 -> 3 per busy CU (75.7 us) instead of 158 x 4 (80.8).
-#ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 12, 21, 22 = TN WN of every plan; 23 = the three-tile workgroup
+#ifdef MRAG_TOPK_DENSE_TILE       // developer knob: 11, 21, 22 = TN WN of every plan; 23 = the three-tile workgroup
   const int cand[1][3] = {{MRAG_TOPK_DENSE_TILE == 23 ? 2 : MRAG_TOPK_DENSE_TILE / 10, MRAG_TOPK_DENSE_TILE == 23 ? 2 : MRAG_TOPK_DENSE_TILE % 10, MRAG_TOPK_DENSE_TILE == 23 ? 3 : 0}};
 #else
-  const int cand[5][3] = {{2, 2, 0}, {2, 2, 3}, {2, 1, 0}, {1, 2, 0}, {1, 1, 0}};                // TN, WN, tiles used (0 = all)
+  const int cand[4][3] = {{2, 2, 0}, {2, 2, 3}, {2, 1, 0}, {1, 1, 0}};                           // TN, WN, tiles used (0 = all).  (64 queries on EIGHT waves -- TN 1, WN 2 -- measured 3 % behind four waves and was never the rule's choice: not instantiated)
 #endif
   double best = 0;
   bool have = false;
@@ -1577,14 +1572,14 @@ extern "C" int mrag_topk_f32(void* stream, const float* db, const int32_t* group
           if (e != hipSuccess) return (int)e;                                                                                  \
           occ = o;                                                                                                              \
         }                                                                                                                       \
-        if (d.total && (long long)d.total > 256LL * occ) d.total = 0;   /* (the runtime fits fewer workgroups than planned: no wait, two launches) */ \
+        if (d.total && (long long)d.total > (long long)dense_cus() * occ) d.total = 0;   /* (fewer resident workgroups than planned: no wait, two launches) */ \
         if (d.total || order != 4) {                                                                                            \
           MRAG_LAUNCH(kfn, dim3(dp.parts, dp.gy), dim3(256 * W), dp.lds, s, d);                                                 \
           done = 1;                                                                                                             \
         }                                                                                                                       \
       }
-      MRAG_TOPK_DENSE(0, 1, 1, 32) MRAG_TOPK_DENSE(0, 1, 2, 64) MRAG_TOPK_DENSE(0, 2, 1, 64) MRAG_TOPK_DENSE(0, 2, 2, 128) MRAG_TOPK_DENSE(0, 2, 2, 96)
-      MRAG_TOPK_DENSE(1, 1, 1, 32) MRAG_TOPK_DENSE(1, 1, 2, 64) MRAG_TOPK_DENSE(1, 2, 1, 64) MRAG_TOPK_DENSE(1, 2, 2, 128) MRAG_TOPK_DENSE(1, 2, 2, 96)
+      MRAG_TOPK_DENSE(0, 1, 1, 32) MRAG_TOPK_DENSE(0, 2, 1, 64) MRAG_TOPK_DENSE(0, 2, 2, 128) MRAG_TOPK_DENSE(0, 2, 2, 96)
+      MRAG_TOPK_DENSE(1, 1, 1, 32) MRAG_TOPK_DENSE(1, 2, 1, 64) MRAG_TOPK_DENSE(1, 2, 2, 128) MRAG_TOPK_DENSE(1, 2, 2, 96)
 #undef MRAG_TOPK_DENSE
       if (done) {
         MRAG_LAUNCH_CHECK();
